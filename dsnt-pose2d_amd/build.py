@@ -1,0 +1,47 @@
+"""Build libdsnt_hip.so in-tree: hipcc --offload-arch=gfx950 over csrc/*.hip + api.cpp.
+
+Cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
+repo snapshot.  Usage: python dsnt-pose2d_amd/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(CSRC, 'libdsnt_hip.so')
+SOURCES = ['api.cpp', 'conv.hip', 'elementwise.hip', 'head.hip']
+FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value',
+         '-Wno-unused-result']
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    deps = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'dsnt_hip.h')]
+    objs, jobs = [], []
+    os.makedirs(os.path.join(CSRC, 'build'), exist_ok=True)
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, 'build', os.path.splitext(src)[0] + '.o')
+        objs.append(o)
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            cmd = [hipcc] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
+            jobs.append(cmd)
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([hipcc, '-shared', '--offload-arch=gfx950', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

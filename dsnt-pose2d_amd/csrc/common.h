@@ -1,0 +1,72 @@
+// Shared host/device helpers for libdsnt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/dsnt_hip.h"
+
+#define DSNT_WAVE 64
+
+int dsnt_set_error(int code, const char* fmt, ...);
+
+#define DSNT_REQUIRE(cond, code, ...)                         \
+    do {                                                      \
+        if (!(cond)) return dsnt_set_error(code, __VA_ARGS__); \
+    } while (0)
+
+#define DSNT_CHECK_LAUNCH(name)                                                   \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess)                                                     \
+            return dsnt_set_error(DSNT_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+        return DSNT_OK;                                                           \
+    } while (0)
+
+static inline bool dsnt_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+#ifdef __HIPCC__
+// Sum across the 64 lanes of a wave; every lane gets the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide reductions for 256-thread blocks (4 waves).  `red` is >= 4*NV floats of LDS.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();  // protect `red` from a previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += red[w * NV + i];
+        v[i] = s;
+    }
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float m = red[0];
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
+    return m;
+}
+#endif

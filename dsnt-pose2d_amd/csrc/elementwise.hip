@@ -1,0 +1,527 @@
+// HBM-bound NHWC kernels around the convolutions: batch-norm statistics / finalisation /
+// activation and their backward, 2x2 max-pool, nearest-upsample + add, axpy, layout changes,
+// the flat optimiser updates and the PCKh hit test.  All 16-byte vectorised (C % 4 == 0),
+// grid-stride where the work is flat, one workgroup per 128-row tile where a per-channel
+// reduction is produced (partials are combined in fp64 by the finalise kernels: deterministic,
+// no atomics).
+#include "common.h"
+
+#define TILE_ROWS 128
+
+// ---------------------------------------------------------------- per-channel tile reductions
+// MODE 0: (sum x, sum x^2)          MODE 1: (sum dz, sum dz*xhat) for y = relu?(bn(x))
+template <int MODE>
+__global__ __launch_bounds__(256) void tile_reduce_kernel(
+    const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, int relu, float* __restrict__ partial, long M, int C) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x;
+    const int C4 = C >> 2;
+    const int cgs = C4 < 256 ? C4 : 256;      // column groups handled per pass
+    const int rpar = 256 / cgs;               // row lanes
+    const int cg_l = tid % cgs, rl = tid / cgs;
+    const bool active = rl < rpar;
+    const long row0 = (long)blockIdx.x * TILE_ROWS;
+    const long row1 = row0 + TILE_ROWS < M ? row0 + TILE_ROWS : M;
+    for (int cg0 = 0; cg0 < C4; cg0 += cgs) {
+        const int cg = cg0 + cg_l;
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+        if (active && cg < C4) {
+            float4 sc, sh, mu, is;
+            if (MODE == 1) {
+                sc = reinterpret_cast<const float4*>(scale)[cg];
+                sh = reinterpret_cast<const float4*>(shift)[cg];
+                mu = reinterpret_cast<const float4*>(mean)[cg];
+                is = reinterpret_cast<const float4*>(invstd)[cg];
+            }
+            for (long r = row0 + rl; r < row1; r += rpar) {
+                const float4 v = reinterpret_cast<const float4*>(a + r * C)[cg];
+                if (MODE == 0) {
+                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                    s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+                    s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+                } else {
+                    const float4 xv = reinterpret_cast<const float4*>(x + r * C)[cg];
+                    float4 dz = v;
+                    if (relu) {
+                        if (fmaf(xv.x, sc.x, sh.x) <= 0.f) dz.x = 0.f;
+                        if (fmaf(xv.y, sc.y, sh.y) <= 0.f) dz.y = 0.f;
+                        if (fmaf(xv.z, sc.z, sh.z) <= 0.f) dz.z = 0.f;
+                        if (fmaf(xv.w, sc.w, sh.w) <= 0.f) dz.w = 0.f;
+                    }
+                    s1.x += dz.x; s1.y += dz.y; s1.z += dz.z; s1.w += dz.w;
+                    s2.x = fmaf(dz.x, (xv.x - mu.x) * is.x, s2.x);
+                    s2.y = fmaf(dz.y, (xv.y - mu.y) * is.y, s2.y);
+                    s2.z = fmaf(dz.z, (xv.z - mu.z) * is.z, s2.z);
+                    s2.w = fmaf(dz.w, (xv.w - mu.w) * is.w, s2.w);
+                }
+            }
+        }
+        __syncthreads();
+        float* mine = red + tid * 8;
+        mine[0] = s1.x; mine[1] = s1.y; mine[2] = s1.z; mine[3] = s1.w;
+        mine[4] = s2.x; mine[5] = s2.y; mine[6] = s2.z; mine[7] = s2.w;
+        __syncthreads();
+        if (tid < cgs && cg0 + tid < C4) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < rpar; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += red[(j * cgs + tid) * 8 + e];
+            float* p0 = partial + ((size_t)blockIdx.x * 2 + 0) * C + (size_t)(cg0 + tid) * 4;
+            float* p1 = partial + ((size_t)blockIdx.x * 2 + 1) * C + (size_t)(cg0 + tid) * 4;
+            *reinterpret_cast<float4*>(p0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(p1) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+}
+
+extern "C" int dsnt_bn_stats(const float* x, float* partial, int64_t M, int C, void* stream) {
+    DSNT_REQUIRE(x && partial && M > 0 && C > 0, DSNT_ERR_ARG, "dsnt_bn_stats: bad argument");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(partial), DSNT_ERR_ALIGN,
+                 "dsnt_bn_stats: C %% 4 and 16-byte alignment required");
+    const int tiles = (int)((M + TILE_ROWS - 1) / TILE_ROWS);
+    hipLaunchKernelGGL(tile_reduce_kernel<0>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial, (long)M, C);
+    DSNT_CHECK_LAUNCH("dsnt_bn_stats");
+}
+
+extern "C" int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const float* scale,
+                                      const float* shift, const float* mean, const float* invstd,
+                                      int relu, float* partial, int64_t M, int C, void* stream) {
+    DSNT_REQUIRE(da && x && scale && shift && mean && invstd && partial && M > 0 && C > 0,
+                 DSNT_ERR_ARG, "dsnt_bn_act_bwd_reduce: bad argument");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(da) && dsnt_aligned16(partial) &&
+                 dsnt_aligned16(scale) && dsnt_aligned16(shift) && dsnt_aligned16(mean) &&
+                 dsnt_aligned16(invstd), DSNT_ERR_ALIGN,
+                 "dsnt_bn_act_bwd_reduce: C %% 4 and 16-byte alignment required");
+    const int tiles = (int)((M + TILE_ROWS - 1) / TILE_ROWS);
+    hipLaunchKernelGGL(tile_reduce_kernel<1>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, da, x,
+                       scale, shift, mean, invstd, relu, partial, (long)M, C);
+    DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_reduce");
+}
+
+// Combine tile partials: 16 channels x 16 tile-lanes per block, fp64 accumulation.
+// MODE 0: forward statistics.  MODE 1: backward sums.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partial, int ntiles, double invM, double unbias, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, float momentum, float eps, int training, float* o0, float* o1, float* o2,
+    float* o3, int accumulate) {
+    __shared__ double r0[256], r1[256];
+    const int tid = threadIdx.x, cl = tid & 15, part = tid >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C && (MODE == 1 || training)) {
+        for (int t = part; t < ntiles; t += 16) {
+            a0 += (double)partial[((size_t)t * 2 + 0) * C + c];
+            a1 += (double)partial[((size_t)t * 2 + 1) * C + c];
+        }
+    }
+    r0[tid] = a0; r1[tid] = a1;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        for (int j = 1; j < 16; ++j) { a0 += r0[j * 16 + cl]; a1 += r1[j * 16 + cl]; }
+        if (MODE == 0) {
+            double mean, var;
+            if (training) {
+                mean = a0 * invM;
+                var = a1 * invM - mean * mean;
+                if (var < 0.0) var = 0.0;
+                if (running_mean) {
+                    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+                    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * unbias);
+                }
+            } else {
+                mean = running_mean[c];
+                var = running_var[c];
+            }
+            const float is = (float)(1.0 / sqrt(var + (double)eps));
+            const float mu = (float)mean;
+            const float sc = gamma ? gamma[c] * is : is;
+            o0[c] = mu; o1[c] = is; o2[c] = sc;
+            o3[c] = (beta ? beta[c] : 0.f) - mu * sc;
+        } else {
+            // o0 = dgamma, o1 = dbeta, o2 = coef [2][C]
+            const float sdz = (float)a0, sdzx = (float)a1;
+            if (o0) o0[c] = accumulate ? o0[c] + sdzx : sdzx;
+            if (o1) o1[c] = accumulate ? o1[c] + sdz : sdz;
+            o2[c] = (float)(a0 * invM);
+            o2[C + c] = (float)(a1 * invM);
+        }
+    }
+}
+
+extern "C" int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int C,
+                                const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, float momentum, float eps, int training,
+                                float* mean, float* invstd, float* scale, float* shift,
+                                void* stream) {
+    DSNT_REQUIRE(mean && invstd && scale && shift && C > 0 && M > 0, DSNT_ERR_ARG,
+                 "dsnt_bn_finalize: bad argument");
+    DSNT_REQUIRE(training ? (partial != nullptr && ntiles > 0) : (running_mean && running_var),
+                 DSNT_ERR_ARG, "dsnt_bn_finalize: missing statistics source");
+    DSNT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DSNT_ERR_ARG,
+                 "dsnt_bn_finalize: running_mean/var must be given together");
+    const double unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                       partial, ntiles, 1.0 / (double)M, unbias, C, gamma, beta, running_mean,
+                       running_var, momentum, eps, training, mean, invstd, scale, shift, 0);
+    DSNT_CHECK_LAUNCH("dsnt_bn_finalize");
+}
+
+extern "C" int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M, int C,
+                                    float* dgamma, float* dbeta, int accumulate, float* coef,
+                                    void* stream) {
+    DSNT_REQUIRE(partial && coef && ntiles > 0 && C > 0 && M > 0, DSNT_ERR_ARG,
+                 "dsnt_bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                       partial, ntiles, 1.0 / (double)M, 1.0, C, nullptr, nullptr, nullptr, nullptr,
+                       0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate);
+    DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize");
+}
+
+// ---------------------------------------------------------------- flat elementwise
+__global__ void bn_act_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ scale,
+                                  const float4* __restrict__ shift, int relu, float4* __restrict__ y,
+                                  long n4, int C4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        const float4 v = x[i], sc = scale[cg], sh = shift[cg];
+        float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z),
+                               fmaf(v.w, sc.w, sh.w));
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        y[i] = o;
+    }
+}
+
+static inline int flat_grid(long n, int block) {
+    long g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+extern "C" int dsnt_bn_act_fwd(const float* x, const float* scale, const float* shift, int relu,
+                               float* y, int64_t M, int C, void* stream) {
+    DSNT_REQUIRE(x && scale && shift && y && M > 0 && C > 0, DSNT_ERR_ARG, "dsnt_bn_act_fwd: bad argument");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(scale) &&
+                 dsnt_aligned16(shift), DSNT_ERR_ALIGN, "dsnt_bn_act_fwd: alignment");
+    const long n4 = (long)M * C / 4;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, (const float4*)scale, (const float4*)shift, relu, (float4*)y,
+                       n4, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_bn_act_fwd");
+}
+
+__global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const float4* __restrict__ x,
+                                        const float4* __restrict__ scale, const float4* __restrict__ shift,
+                                        const float4* __restrict__ mean, const float4* __restrict__ invstd,
+                                        const float4* __restrict__ coef, int relu, float4* dx,
+                                        int accumulate, long n4, int C4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        const float4 g = da[i], xv = x[i], sc = scale[cg], sh = shift[cg], mu = mean[cg],
+                     is = invstd[cg], c0 = coef[cg], c1 = coef[C4 + cg];
+        float4 dz = g;
+        if (relu) {
+            if (fmaf(xv.x, sc.x, sh.x) <= 0.f) dz.x = 0.f;
+            if (fmaf(xv.y, sc.y, sh.y) <= 0.f) dz.y = 0.f;
+            if (fmaf(xv.z, sc.z, sh.z) <= 0.f) dz.z = 0.f;
+            if (fmaf(xv.w, sc.w, sh.w) <= 0.f) dz.w = 0.f;
+        }
+        float4 o;
+        o.x = sc.x * (dz.x - c0.x - (xv.x - mu.x) * is.x * c1.x);
+        o.y = sc.y * (dz.y - c0.y - (xv.y - mu.y) * is.y * c1.y);
+        o.z = sc.z * (dz.z - c0.z - (xv.z - mu.z) * is.z * c1.z);
+        o.w = sc.w * (dz.w - c0.w - (xv.w - mu.w) * is.w * c1.w);
+        if (accumulate) { const float4 p = dx[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        dx[i] = o;
+    }
+}
+
+extern "C" int dsnt_bn_act_bwd_apply(const float* da, const float* x, const float* scale,
+                                     const float* shift, const float* mean, const float* invstd,
+                                     const float* coef, int relu, float* dx, int accumulate,
+                                     int64_t M, int C, void* stream) {
+    DSNT_REQUIRE(da && x && scale && shift && mean && invstd && coef && dx && M > 0 && C > 0,
+                 DSNT_ERR_ARG, "dsnt_bn_act_bwd_apply: bad argument");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(da) && dsnt_aligned16(x) && dsnt_aligned16(dx) &&
+                 dsnt_aligned16(coef), DSNT_ERR_ALIGN, "dsnt_bn_act_bwd_apply: alignment");
+    const long n4 = (long)M * C / 4;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
+                       (const float4*)shift, (const float4*)mean, (const float4*)invstd,
+                       (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_apply");
+}
+
+// ---------------------------------------------------------------- pooling / upsampling
+__global__ void maxpool2_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+                                    uchar4* __restrict__ idx, int N, int H, int W, int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        long t = i / C4;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const float4* base = x + (((long)n * H + 2 * oh) * W + 2 * ow) * C4 + cg;
+        const float4 v0 = base[0], v1 = base[C4], v2 = base[(long)W * C4], v3 = base[(long)W * C4 + C4];
+        float4 m = v0;
+        uchar4 k = make_uchar4(0, 0, 0, 0);
+#define POOL_STEP(V, P)                                  \
+        if (V.x > m.x || V.x != V.x) { m.x = V.x; k.x = P; } \
+        if (V.y > m.y || V.y != V.y) { m.y = V.y; k.y = P; } \
+        if (V.z > m.z || V.z != V.z) { m.z = V.z; k.z = P; } \
+        if (V.w > m.w || V.w != V.w) { m.w = V.w; k.w = P; }
+        POOL_STEP(v1, 1) POOL_STEP(v2, 2) POOL_STEP(v3, 3)
+#undef POOL_STEP
+        y[i] = m;
+        idx[i] = k;
+    }
+}
+
+extern "C" int dsnt_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C,
+                                 void* stream) {
+    DSNT_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG, "dsnt_maxpool2_fwd: bad argument");
+    DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_fwd: H and W must be even (got %dx%d)", H, W);
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && (((uintptr_t)idx) & 3) == 0,
+                 DSNT_ERR_ALIGN, "dsnt_maxpool2_fwd: alignment");
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, (float4*)y, (uchar4*)idx, N, H, W, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_maxpool2_fwd");
+}
+
+__global__ void maxpool2_bwd_kernel(const float4* __restrict__ dy, const uchar4* __restrict__ idx,
+                                    float4* dx, int accumulate, int N, int H, int W, int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        long t = i / C4;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const float4 g = dy[i];
+        const uchar4 k = idx[i];
+        float4* base = dx + (((long)n * H + 2 * oh) * W + 2 * ow) * C4 + cg;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float4* q = base + (p >> 1) * (long)W * C4 + (p & 1) * C4;
+            float4 o = make_float4(k.x == p ? g.x : 0.f, k.y == p ? g.y : 0.f, k.z == p ? g.z : 0.f,
+                                   k.w == p ? g.w : 0.f);
+            if (accumulate) { const float4 c = *q; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+            *q = o;
+        }
+    }
+}
+
+extern "C" int dsnt_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int accumulate,
+                                 int N, int H, int W, int C, void* stream) {
+    DSNT_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG, "dsnt_maxpool2_bwd: bad argument");
+    DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_bwd: H and W must be even");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dy) && dsnt_aligned16(dx), DSNT_ERR_ALIGN, "dsnt_maxpool2_bwd: alignment");
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, N, H, W, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_maxpool2_bwd");
+}
+
+__global__ void upsample2_add_fwd_kernel(const float4* __restrict__ up, const float4* __restrict__ low,
+                                         float4* __restrict__ out, int N, int H, int W, int C4) {
+    const long total = (long)N * H * W * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        long t = i / C4;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const float4 a = up[i];
+        const float4 b = low[(((long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * C4 + cg];
+        out[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+extern "C" int dsnt_upsample2_add_fwd(const float* up, const float* low, float* out, int N, int H,
+                                      int W, int C, void* stream) {
+    DSNT_REQUIRE(up && low && out && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG, "dsnt_upsample2_add_fwd: bad argument");
+    DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_upsample2_add_fwd: H and W must be even");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(up) && dsnt_aligned16(low) && dsnt_aligned16(out),
+                 DSNT_ERR_ALIGN, "dsnt_upsample2_add_fwd: alignment");
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2_add_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)up, (const float4*)low, (float4*)out, N, H, W, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_upsample2_add_fwd");
+}
+
+__global__ void upsample2_bwd_kernel(const float4* __restrict__ dout, float4* dlow, int accumulate,
+                                     int N, int H, int W, int C4) {
+    const int Hl = H >> 1, Wl = W >> 1;
+    const long total = (long)N * Hl * Wl * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        long t = i / C4;
+        const int w = (int)(t % Wl); t /= Wl;
+        const int h = (int)(t % Hl);
+        const int n = (int)(t / Hl);
+        const float4* b = dout + (((long)n * H + 2 * h) * W + 2 * w) * C4 + cg;
+        const float4 v0 = b[0], v1 = b[C4], v2 = b[(long)W * C4], v3 = b[(long)W * C4 + C4];
+        float4 o = make_float4((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
+                               (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w));
+        if (accumulate) { const float4 c = dlow[i]; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+        dlow[i] = o;
+    }
+}
+
+extern "C" int dsnt_upsample2_bwd(const float* dout, float* dlow, int accumulate, int N, int H, int W,
+                                  int C, void* stream) {
+    DSNT_REQUIRE(dout && dlow && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG, "dsnt_upsample2_bwd: bad argument");
+    DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_upsample2_bwd: H and W must be even");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dout) && dsnt_aligned16(dlow), DSNT_ERR_ALIGN, "dsnt_upsample2_bwd: alignment");
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dout, (float4*)dlow, accumulate, N, H, W, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_upsample2_bwd");
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, float* y, float a, int accumulate, long n) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 o = make_float4(a * v.x, a * v.y, a * v.z, a * v.w);
+        if (accumulate) {
+            const float4 c = reinterpret_cast<float4*>(y)[i];
+            o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+        }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x)
+        y[i] = accumulate ? y[i] + a * x[i] : a * x[i];
+}
+
+extern "C" int dsnt_axpy(const float* x, float* y, float a, int accumulate, int64_t n, void* stream) {
+    DSNT_REQUIRE(x && y && n > 0, DSNT_ERR_ARG, "dsnt_axpy: bad argument");
+    DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(y), DSNT_ERR_ALIGN, "dsnt_axpy: alignment");
+    hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       a, accumulate, (long)n);
+    DSNT_CHECK_LAUNCH("dsnt_axpy");
+}
+
+// ---------------------------------------------------------------- layout changes
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C,
+                                    int HW, int Cpad) {
+    const long total = (long)N * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const long n = i / HW;
+        for (int c = 0; c < Cpad; ++c)
+            dst[i * Cpad + c] = c < C ? src[(n * C + c) * HW + p] : 0.f;
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C,
+                                    int HW, int Cpad) {
+    const long total = (long)N * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const long n = i / HW;
+        for (int c = 0; c < C; ++c) dst[(n * C + c) * HW + p] = src[i * Cpad + c];
+    }
+}
+
+extern "C" int dsnt_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int Cpad, void* stream) {
+    DSNT_REQUIRE(src && dst && N > 0 && C > 0 && HW > 0 && Cpad >= C, DSNT_ERR_ARG, "dsnt_nchw_to_nhwc: bad argument");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(flat_grid((long)N * HW, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, N, C, HW, Cpad);
+    DSNT_CHECK_LAUNCH("dsnt_nchw_to_nhwc");
+}
+extern "C" int dsnt_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int Cpad, void* stream) {
+    DSNT_REQUIRE(src && dst && N > 0 && C > 0 && HW > 0 && Cpad >= C, DSNT_ERR_ARG, "dsnt_nhwc_to_nchw: bad argument");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(flat_grid((long)N * HW, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, N, C, HW, Cpad);
+    DSNT_CHECK_LAUNCH("dsnt_nhwc_to_nchw");
+}
+
+// ---------------------------------------------------------------- optimiser (flat arena)
+__global__ void rmsprop_kernel(float* p, const float* __restrict__ g, float* sq, long n, float lr,
+                               float alpha, float eps, float wd, float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float s = alpha * sq[i] + (1.f - alpha) * gi * gi;
+        sq[i] = s;
+        p[i] = pi - lr * gi / (sqrtf(s) + eps);
+    }
+}
+extern "C" int dsnt_rmsprop_step(float* p, const float* g, float* square_avg, int64_t n, float lr,
+                                 float alpha, float eps, float weight_decay, float grad_scale, void* stream) {
+    DSNT_REQUIRE(p && g && square_avg && n > 0, DSNT_ERR_ARG, "dsnt_rmsprop_step: bad argument");
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
+                       square_avg, (long)n, lr, alpha, eps, weight_decay, grad_scale);
+    DSNT_CHECK_LAUNCH("dsnt_rmsprop_step");
+}
+
+__global__ void sgd_kernel(float* p, const float* __restrict__ g, float* buf, long n, float lr,
+                           float momentum, float wd, float gscale, int first) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        if (buf) {
+            const float b = first ? gi : momentum * buf[i] + gi;
+            buf[i] = b;
+            gi = b;
+        }
+        p[i] = pi - lr * gi;
+    }
+}
+extern "C" int dsnt_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr,
+                             float momentum, float weight_decay, float grad_scale, int first_step,
+                             void* stream) {
+    DSNT_REQUIRE(p && g && n > 0, DSNT_ERR_ARG, "dsnt_sgd_step: bad argument");
+    hipLaunchKernelGGL(sgd_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
+                       momentum != 0.f ? momentum_buf : nullptr, (long)n, lr, momentum, weight_decay,
+                       grad_scale, first_step);
+    DSNT_CHECK_LAUNCH("dsnt_sgd_step");
+}
+
+// ---------------------------------------------------------------- PCKh hits
+__global__ void pckh_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                            const double* __restrict__ m, const double* __restrict__ b,
+                            const float* __restrict__ mask, const double* __restrict__ head,
+                            float thr, float* hits, float* valid, int B, int J) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * J) return;
+    const int n = i / J;
+    const double* mm = m + (size_t)n * 4;
+    const double* bb = b + (size_t)n * 2;
+    const double px = pred[2 * i], py = pred[2 * i + 1], tx = target[2 * i], ty = target[2 * i + 1];
+    // row-vector times matrix plus offset (train.py:243-258: bmm(norm, transform_m) + transform_b)
+    const double ox = px * mm[0] + py * mm[2] + bb[0], oy = px * mm[1] + py * mm[3] + bb[1];
+    const double gx = tx * mm[0] + ty * mm[2] + bb[0], gy = tx * mm[1] + ty * mm[3] + bb[1];
+    const double d = sqrt((ox - gx) * (ox - gx) + (oy - gy) * (oy - gy)) / head[n];
+    const bool v = mask[i] == 1.f;
+    valid[i] = v ? 1.f : 0.f;
+    hits[i] = (v && d <= (double)thr) ? 1.f : 0.f;
+}
+extern "C" int dsnt_pckh(const float* pred, const float* target, const double* m, const double* b,
+                         const float* mask, const double* head, float threshold, float* hits,
+                         float* valid, int B, int J, void* stream) {
+    DSNT_REQUIRE(pred && target && m && b && mask && head && hits && valid && B > 0 && J > 0,
+                 DSNT_ERR_ARG, "dsnt_pckh: bad argument");
+    hipLaunchKernelGGL(pckh_kernel, dim3((B * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred,
+                       target, m, b, mask, head, threshold, hits, valid, B, J);
+    DSNT_CHECK_LAUNCH("dsnt_pckh");
+}

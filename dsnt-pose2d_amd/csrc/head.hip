@@ -1,0 +1,606 @@
+// DSNT head kernels: heat-map normalisation (spatial softmax and its variants), coordinate
+// expectation against the X/Y meshgrids, Gaussian targets, JS / KL / MSE / variance
+// regularisers, Euclidean loss, masked average — and the fused forward / backward of the whole
+// head.  HBM-bound: one 256-thread workgroup per (image, joint) row of H*W floats; the row is
+// read from HBM once and kept in registers (16 floats per thread for H*W <= 4096, 16-byte loads
+// when H*W % 4 == 0) while wavefront reductions produce the softmax denominator, the
+// coordinate moments and the divergence sums.  Longer rows fall back to re-reading the row
+// (served by L2).  Meshgrids are never materialised: x_w = (2w - (W-1))/W, y_h = (2h - (H-1))/H.
+#include "common.h"
+#include <math.h>
+
+#define HB 256   // threads per row
+
+template <int VEC, bool CACHED>
+struct Row {
+    float v[16];
+    const float* src;
+    int hw;
+    __device__ __forceinline__ void load(const float* row, int n) {
+        src = row; hw = n;
+        if (CACHED) {
+            const int tid = threadIdx.x;
+            if (VEC == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = (k * HB + tid) * 4;
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < hw) t = *reinterpret_cast<const float4*>(row + i);
+                    v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = k * HB + tid;
+                    v[k] = i < hw ? row[i] : 0.f;
+                }
+            }
+        }
+    }
+    // f(index, value) for every element this thread owns
+    template <typename F>
+    __device__ __forceinline__ void each(F f) const {
+        const int tid = threadIdx.x;
+        if (CACHED) {
+            if (VEC == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = (k * HB + tid) * 4;
+                    if (i < hw) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f(i + e, v[4 * k + e]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = k * HB + tid;
+                    if (i < hw) f(i, v[k]);
+                }
+            }
+        } else {
+            for (int i = tid; i < hw; i += HB) f(i, src[i]);
+        }
+    }
+};
+
+struct Grid2 {
+    int W, H; float offx, offy;
+    __device__ __forceinline__ Grid2(int h, int w)
+        : W(w), H(h), offx((float)(w - 1)), offy((float)(h - 1)) {}
+    __device__ __forceinline__ void xy(int i, float& x, float& y) const {
+        const int r = i / W, c = i - r * W;
+        x = (2.f * c - offx) / (float)W;   // exact closed form of linspace(-(W-1)/W, (W-1)/W, W)
+        y = (2.f * r - offy) / (float)H;
+    }
+};
+
+// ------------------------------------------------------------------ preact (model.py:24-45)
+template <int VEC, bool CACHED>
+__global__ __launch_bounds__(HB) void preact_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         int hw, int mode, float thr, float eps) {
+    __shared__ float red[16];
+    const size_t off = (size_t)blockIdx.x * hw;
+    Row<VEC, CACHED> row;
+    row.load(x + off, hw);
+    float* out = y + off;
+    if (mode <= 1) {
+        float m = -INFINITY;
+        row.each([&](int, float v) { m = fmaxf(m, v); });
+        m = block_max(m, red);
+        float s[1] = {0.f};
+        row.each([&](int, float v) {
+            const float e = expf(v - m);
+            s[0] += (mode == 1 && !(v >= thr)) ? 0.f : e;
+        });
+        block_sum<1>(s, red);
+        const float denom = mode == 1 ? s[0] + eps : s[0];
+        row.each([&](int i, float v) {
+            const float e = (mode == 1 && !(v >= thr)) ? 0.f : expf(v - m);
+            out[i] = e / denom;
+        });
+    } else {
+        auto f = [&](float v) {
+            return mode == 2 ? fabsf(v) : mode == 3 ? fmaxf(v, 0.f) : 1.f / (1.f + expf(-v));
+        };
+        float s[1] = {0.f};
+        row.each([&](int, float v) { s[0] += f(v); });
+        block_sum<1>(s, red);
+        const float denom = s[0] + eps;
+        row.each([&](int i, float v) { out[i] = f(v) / denom; });
+    }
+}
+
+template <int VEC, bool CACHED>
+__global__ __launch_bounds__(HB) void preact_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ gy, float* __restrict__ gx,
+                                                         int hw, int mode, float eps) {
+    __shared__ float red[16];
+    const size_t off = (size_t)blockIdx.x * hw;
+    Row<VEC, CACHED> py;
+    py.load(y + off, hw);
+    const float* g = gy + off;
+    float* out = gx + off;
+    if (mode <= 1) {
+        float s[1] = {0.f};
+        py.each([&](int i, float p) { s[0] = fmaf(p, g[i], s[0]); });
+        block_sum<1>(s, red);
+        py.each([&](int i, float p) { out[i] = p * (g[i] - s[0]); });
+    } else {
+        const float* xr = x + off;
+        auto f = [&](float v) {
+            return mode == 2 ? fabsf(v) : mode == 3 ? fmaxf(v, 0.f) : 1.f / (1.f + expf(-v));
+        };
+        float s[2] = {0.f, 0.f};   // sum f(x), sum g*y
+        py.each([&](int i, float p) { s[0] += f(xr[i]); s[1] = fmaf(p, g[i], s[1]); });
+        block_sum<2>(s, red);
+        const float inv = 1.f / (s[0] + eps);
+        py.each([&](int i, float) {
+            const float v = xr[i];
+            float d;
+            if (mode == 2) d = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+            else if (mode == 3) d = v > 0.f ? 1.f : 0.f;
+            else { const float sg = 1.f / (1.f + expf(-v)); d = sg * (1.f - sg); }
+            out[i] = d * (g[i] - s[1]) * inv;
+        });
+    }
+}
+
+// ------------------------------------------------------------------ dsnt (nn.py:25-78)
+template <int VEC, bool CACHED>
+__global__ __launch_bounds__(HB) void expect_fwd_kernel(const float* __restrict__ hm, float* __restrict__ coords,
+                                                         int h, int w) {
+    __shared__ float red[16];
+    const int hw = h * w;
+    Row<VEC, CACHED> row;
+    row.load(hm + (size_t)blockIdx.x * hw, hw);
+    const Grid2 g(h, w);
+    float s[2] = {0.f, 0.f};
+    row.each([&](int i, float p) {
+        float x, y; g.xy(i, x, y);
+        s[0] = fmaf(x, p, s[0]); s[1] = fmaf(y, p, s[1]);
+    });
+    block_sum<2>(s, red);
+    if (threadIdx.x == 0) { coords[2 * (size_t)blockIdx.x] = s[0]; coords[2 * (size_t)blockIdx.x + 1] = s[1]; }
+}
+
+__global__ __launch_bounds__(HB) void expect_bwd_kernel(const float* __restrict__ gc, float* __restrict__ ghm,
+                                                         int h, int w) {
+    const int hw = h * w;
+    const float gx = gc[2 * (size_t)blockIdx.x], gy = gc[2 * (size_t)blockIdx.x + 1];
+    float* out = ghm + (size_t)blockIdx.x * hw;
+    const Grid2 g(h, w);
+    for (int i = threadIdx.x; i < hw; i += HB) {
+        float x, y; g.xy(i, x, y);
+        out[i] = gx * x + gy * y;
+    }
+}
+
+// ------------------------------------------------------------------ make_gauss (nn.py:168-205)
+__global__ __launch_bounds__(HB) void make_gauss_kernel(const float* __restrict__ coords, float* __restrict__ out,
+                                                         int h, int w, float k) {
+    __shared__ float red[16];
+    const int hw = h * w;
+    const float mx = coords[2 * (size_t)blockIdx.x], my = coords[2 * (size_t)blockIdx.x + 1];
+    float* o = out + (size_t)blockIdx.x * hw;
+    const Grid2 g(h, w);
+    float s[1] = {0.f};
+    for (int i = threadIdx.x; i < hw; i += HB) {
+        float x, y; g.xy(i, x, y);
+        s[0] += expf(((x - mx) * (x - mx) + (y - my) * (y - my)) * k);
+    }
+    block_sum<1>(s, red);
+    const float z = s[0] + 1e-24f;
+    for (int i = threadIdx.x; i < hw; i += HB) {
+        float x, y; g.xy(i, x, y);
+        o[i] = expf(((x - mx) * (x - mx) + (y - my) * (y - my)) * k) / z;
+    }
+}
+
+// ------------------------------------------------------------------ regularisers (nn.py:208-298)
+#define REG_EPS 1e-24f
+
+// Per-row context shared by forward and backward: Gaussian normaliser, or the moments for `var`.
+struct RegCtx { float z, mx, my, sp, vx, vy; };
+
+template <typename ROW>
+__device__ __forceinline__ RegCtx reg_context(const ROW& row, const Grid2& g, float tx, float ty, float k,
+                                              int kind, float* red) {
+    RegCtx c = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (kind == 3) {
+        float s[3] = {0.f, 0.f, 0.f};
+        row.each([&](int i, float p) {
+            float x, y; g.xy(i, x, y);
+            s[0] = fmaf(x, p, s[0]); s[1] = fmaf(y, p, s[1]); s[2] += p;
+        });
+        block_sum<3>(s, red);
+        c.mx = s[0]; c.my = s[1]; c.sp = s[2];
+        float v[2] = {0.f, 0.f};
+        row.each([&](int i, float p) {
+            float x, y; g.xy(i, x, y);
+            v[0] = fmaf((x - c.mx) * (x - c.mx), p, v[0]);
+            v[1] = fmaf((y - c.my) * (y - c.my), p, v[1]);
+        });
+        block_sum<2>(v, red);
+        c.vx = v[0]; c.vy = v[1];
+    } else {
+        float s[1] = {0.f};
+        row.each([&](int i, float) {
+            float x, y; g.xy(i, x, y);
+            s[0] += expf(((x - tx) * (x - tx) + (y - ty) * (y - ty)) * k);
+        });
+        block_sum<1>(s, red);
+        c.z = s[0] + 1e-24f;
+    }
+    return c;
+}
+
+template <typename ROW>
+__device__ __forceinline__ float reg_value(const ROW& row, const Grid2& g, const RegCtx& c, float tx,
+                                           float ty, float k, float sigma, int kind, float* red) {
+    if (kind == 3) {
+        const float s2 = sigma * sigma;
+        return (c.vx - s2) * (c.vx - s2) + (c.vy - s2) * (c.vy - s2);
+    }
+    float s[1] = {0.f};
+    row.each([&](int i, float p) {
+        float x, y; g.xy(i, x, y);
+        const float q = expf(((x - tx) * (x - tx) + (y - ty) * (y - ty)) * k) / c.z;
+        if (kind == 0) {
+            const float m = 0.5f * (p + q), lm = logf(m + REG_EPS);
+            s[0] += 0.5f * (p * (logf(p + REG_EPS) - lm)) + 0.5f * (q * (logf(q + REG_EPS) - lm));
+        } else if (kind == 1) {
+            s[0] += p * (logf(p + REG_EPS) - logf(q + REG_EPS));
+        } else {
+            s[0] += (p - q) * (p - q);
+        }
+    });
+    block_sum<1>(s, red);
+    return s[0];
+}
+
+// d(reg)/d(p_i)
+__device__ __forceinline__ float reg_grad(float p, float x, float y, const RegCtx& c, float tx, float ty,
+                                          float k, float sigma, int kind) {
+    if (kind == 3) {
+        const float s2 = sigma * sigma;
+        const float dvx = (x - c.mx) * (x - c.mx) - 2.f * x * c.mx * (1.f - c.sp);
+        const float dvy = (y - c.my) * (y - c.my) - 2.f * y * c.my * (1.f - c.sp);
+        return 2.f * (c.vx - s2) * dvx + 2.f * (c.vy - s2) * dvy;
+    }
+    const float q = expf(((x - tx) * (x - tx) + (y - ty) * (y - ty)) * k) / c.z;
+    if (kind == 0) {
+        const float m = 0.5f * (p + q);
+        return 0.5f * (logf(p + REG_EPS) - logf(m + REG_EPS) + p / (p + REG_EPS) - m / (m + REG_EPS));
+    }
+    if (kind == 1) return logf(p + REG_EPS) - logf(q + REG_EPS) + p / (p + REG_EPS);
+    return 2.f * (p - q);
+}
+
+template <int VEC, bool CACHED>
+__global__ __launch_bounds__(HB) void reg_fwd_kernel(const float* __restrict__ hm, const float* __restrict__ target,
+                                                      float* __restrict__ per_row, int h, int w, float sigma,
+                                                      float k, int kind) {
+    __shared__ float red[16];
+    const int hw = h * w;
+    Row<VEC, CACHED> row;
+    row.load(hm + (size_t)blockIdx.x * hw, hw);
+    const Grid2 g(h, w);
+    float tx = 0.f, ty = 0.f;
+    if (kind != 3) { tx = target[2 * (size_t)blockIdx.x]; ty = target[2 * (size_t)blockIdx.x + 1]; }
+    const RegCtx c = reg_context(row, g, tx, ty, k, kind, red);
+    const float val = reg_value(row, g, c, tx, ty, k, sigma, kind, red);
+    if (threadIdx.x == 0) per_row[blockIdx.x] = val;
+}
+
+template <int VEC, bool CACHED>
+__global__ __launch_bounds__(HB) void reg_bwd_kernel(const float* __restrict__ hm, const float* __restrict__ target,
+                                                      const float* __restrict__ g_row, float* __restrict__ ghm,
+                                                      int h, int w, float sigma, float k, int kind) {
+    __shared__ float red[16];
+    const int hw = h * w;
+    Row<VEC, CACHED> row;
+    row.load(hm + (size_t)blockIdx.x * hw, hw);
+    const Grid2 g(h, w);
+    float tx = 0.f, ty = 0.f;
+    if (kind != 3) { tx = target[2 * (size_t)blockIdx.x]; ty = target[2 * (size_t)blockIdx.x + 1]; }
+    const RegCtx c = reg_context(row, g, tx, ty, k, kind, red);
+    const float gr = g_row[blockIdx.x];
+    float* out = ghm + (size_t)blockIdx.x * hw;
+    row.each([&](int i, float p) {
+        float x, y; g.xy(i, x, y);
+        out[i] = gr * reg_grad(p, x, y, c, tx, ty, k, sigma, kind);
+    });
+}
+
+// ------------------------------------------------------------------ euclid / masked average
+__global__ void euclid_fwd_kernel(const float* __restrict__ a, const float* __restrict__ t, float* __restrict__ dist,
+                                  long n, int d) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int j = 0; j < d; ++j) { const float df = a[i * d + j] - t[i * d + j]; s += df * df; }
+    dist[i] = sqrtf(s);
+}
+__global__ void euclid_bwd_kernel(const float* __restrict__ a, const float* __restrict__ t,
+                                  const float* __restrict__ dist, const float* __restrict__ gd,
+                                  float* __restrict__ ga, long n, int d) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // d sqrt(s)/da = (a-t)/dist; at dist == 0 the reference's autograd gives 0 * inf = NaN
+    const float f = gd[i] / (2.f * dist[i]);
+    for (int j = 0; j < d; ++j) ga[i * d + j] = f * (2.f * (a[i * d + j] - t[i * d + j]));
+}
+
+__global__ __launch_bounds__(HB) void masked_avg_fwd_kernel(const float* __restrict__ l, const float* __restrict__ m,
+                                                             float* __restrict__ out2, long n) {
+    __shared__ float red[16];
+    float s[2] = {0.f, 0.f};
+    for (long i = threadIdx.x; i < n; i += HB) {
+        const float w = m ? m[i] : 1.f;
+        s[0] += m ? l[i] * w : l[i];
+        s[1] += w;
+    }
+    block_sum<2>(s, red);
+    if (threadIdx.x == 0) {
+        const float denom = fmaxf(s[1], 1.f);
+        out2[0] = s[0] / denom;
+        out2[1] = denom;
+    }
+}
+__global__ void masked_avg_bwd_kernel(const float* __restrict__ g, const float* __restrict__ m,
+                                      const float* __restrict__ out2, float* __restrict__ gl, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gl[i] = g[0] * (m ? m[i] : 1.f) / out2[1];
+}
+
+// ------------------------------------------------------------------ fused head
+// forward: softmax over the row + coordinate moments, one HBM read of the logits.
+template <int VEC, bool CACHED>
+__global__ __launch_bounds__(HB) void head_fwd_kernel(const float* __restrict__ logits, float* __restrict__ hm,
+                                                       float* __restrict__ coords, int h, int w) {
+    __shared__ float red[16];
+    const int hw = h * w;
+    const size_t off = (size_t)blockIdx.x * hw;
+    Row<VEC, CACHED> row;
+    row.load(logits + off, hw);
+    float m = -INFINITY;
+    row.each([&](int, float v) { m = fmaxf(m, v); });
+    m = block_max(m, red);
+    float s[1] = {0.f};
+    row.each([&](int, float v) { s[0] += expf(v - m); });
+    block_sum<1>(s, red);
+    const float denom = s[0];
+    const Grid2 g(h, w);
+    float* out = hm + off;
+    float c[2] = {0.f, 0.f};
+    if (CACHED && VEC == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = (k * HB + threadIdx.x) * 4;
+            if (i < hw) {
+                float p[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[e] = expf(row.v[4 * k + e] - m) / denom;
+                    float x, y; g.xy(i + e, x, y);
+                    c[0] = fmaf(x, p[e], c[0]); c[1] = fmaf(y, p[e], c[1]);
+                }
+                *reinterpret_cast<float4*>(out + i) = make_float4(p[0], p[1], p[2], p[3]);
+            }
+        }
+    } else {
+        row.each([&](int i, float v) {
+            const float p = expf(v - m) / denom;
+            out[i] = p;
+            float x, y; g.xy(i, x, y);
+            c[0] = fmaf(x, p, c[0]); c[1] = fmaf(y, p, c[1]);
+        });
+    }
+    block_sum<2>(c, red);
+    if (threadIdx.x == 0) { coords[2 * (size_t)blockIdx.x] = c[0]; coords[2 * (size_t)blockIdx.x + 1] = c[1]; }
+}
+
+template <int VEC, bool CACHED>
+__global__ __launch_bounds__(HB) void head_loss_rows_kernel(const float* __restrict__ hm, const float* __restrict__ coords,
+                                                             const float* __restrict__ target, float* __restrict__ dist,
+                                                             float* __restrict__ reg_row, int h, int w, float sigma,
+                                                             float k, int kind) {
+    __shared__ float red[16];
+    const size_t r = blockIdx.x;
+    const float tx = target[2 * r], ty = target[2 * r + 1];
+    if (threadIdx.x == 0) {
+        const float dx = coords[2 * r] - tx, dy = coords[2 * r + 1] - ty;
+        dist[r] = sqrtf(dx * dx + dy * dy);
+    }
+    if (kind < 0) return;
+    const int hw = h * w;
+    Row<VEC, CACHED> row;
+    row.load(hm + r * hw, hw);
+    const Grid2 g(h, w);
+    const RegCtx c = reg_context(row, g, tx, ty, k, kind, red);
+    const float val = reg_value(row, g, c, tx, ty, k, sigma, kind, red);
+    if (threadIdx.x == 0) reg_row[r] = val;
+}
+
+// backward: dL/dp_i = g_dist*((mu-t)/dist . (x_i,y_i)) + g_reg * dreg/dp_i, then softmax backward
+// dz_i = p_i (dL/dp_i - sum_j p_j dL/dp_j).  One read of the saved heat-map, one write.
+template <int VEC, bool CACHED>
+__global__ __launch_bounds__(HB) void head_bwd_kernel(const float* __restrict__ hm, const float* __restrict__ coords,
+                                                       const float* __restrict__ target, const float* __restrict__ dist,
+                                                       const float* __restrict__ g_dist, const float* __restrict__ g_reg,
+                                                       float* __restrict__ g_logits, int h, int w, float sigma, float k,
+                                                       int kind) {
+    __shared__ float red[16];
+    const size_t r = blockIdx.x;
+    const int hw = h * w;
+    Row<VEC, CACHED> row;
+    row.load(hm + r * hw, hw);
+    const Grid2 g(h, w);
+    const float tx = target[2 * r], ty = target[2 * r + 1];
+    const float d = dist[r], gd = g_dist[r];
+    // un-guarded like the reference: dist == 0 with gd != 0 gives NaN
+    const float f = gd / (2.f * d);
+    const float ax = f * (2.f * (coords[2 * r] - tx));
+    const float ay = f * (2.f * (coords[2 * r + 1] - ty));
+    const float gr = (kind >= 0 && g_reg) ? g_reg[r] : 0.f;
+    RegCtx c = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (kind >= 0 && gr != 0.f) c = reg_context(row, g, tx, ty, k, kind, red);
+    auto dLdp = [&](int i, float p) {
+        float x, y; g.xy(i, x, y);
+        float v = ax * x + ay * y;
+        if (kind >= 0 && gr != 0.f) v += gr * reg_grad(p, x, y, c, tx, ty, k, sigma, kind);
+        return v;
+    };
+    float s[1] = {0.f};
+    row.each([&](int i, float p) { s[0] = fmaf(p, dLdp(i, p), s[0]); });
+    block_sum<1>(s, red);
+    float* out = g_logits + r * hw;
+    row.each([&](int i, float p) { out[i] = p * (dLdp(i, p) - s[0]); });
+}
+
+// ------------------------------------------------------------------ host wrappers
+#define ROW_DISPATCH(KERNEL, rows, hw, ptr_ok, ...)                                                   \
+    do {                                                                                               \
+        const bool vec_ = ((hw) % 4 == 0) && (ptr_ok);                                                 \
+        const bool cached_ = (hw) <= 4096;                                                             \
+        hipStream_t st_ = (hipStream_t)stream;                                                         \
+        if (vec_ && cached_) hipLaunchKernelGGL((KERNEL<4, true>), dim3(rows), dim3(HB), 0, st_, __VA_ARGS__);   \
+        else if (cached_) hipLaunchKernelGGL((KERNEL<1, true>), dim3(rows), dim3(HB), 0, st_, __VA_ARGS__);      \
+        else hipLaunchKernelGGL((KERNEL<1, false>), dim3(rows), dim3(HB), 0, st_, __VA_ARGS__);                  \
+    } while (0)
+
+static int check_rows(const char* who, int64_t rows, int h, int w) {
+    DSNT_REQUIRE(rows > 0 && rows < (1LL << 31), DSNT_ERR_SHAPE, "%s: rows=%lld out of range", who, (long long)rows);
+    DSNT_REQUIRE(h > 0 && w > 0 && (long)h * w < (1L << 24), DSNT_ERR_SHAPE, "%s: bad map size %dx%d", who, h, w);
+    return DSNT_OK;
+}
+
+extern "C" int dsnt_preact_fwd(const float* x, float* y, int64_t rows, int hw, int mode, float threshold,
+                               float eps, void* stream) {
+    DSNT_REQUIRE(x && y, DSNT_ERR_ARG, "dsnt_preact_fwd: null tensor");
+    DSNT_REQUIRE(mode >= 0 && mode <= 4, DSNT_ERR_ARG, "dsnt_preact_fwd: unknown mode %d", mode);
+    if (int e = check_rows("dsnt_preact_fwd", rows, 1, hw)) return e;
+    ROW_DISPATCH(preact_fwd_kernel, (int)rows, hw, dsnt_aligned16(x), x, y, hw, mode, threshold, eps);
+    DSNT_CHECK_LAUNCH("dsnt_preact_fwd");
+}
+
+extern "C" int dsnt_preact_bwd(const float* x, const float* y, const float* gy, float* gx, int64_t rows,
+                               int hw, int mode, float threshold, float eps, void* stream) {
+    (void)threshold;
+    DSNT_REQUIRE(y && gy && gx && (mode <= 1 || x), DSNT_ERR_ARG, "dsnt_preact_bwd: null tensor");
+    DSNT_REQUIRE(mode >= 0 && mode <= 4, DSNT_ERR_ARG, "dsnt_preact_bwd: unknown mode %d", mode);
+    if (int e = check_rows("dsnt_preact_bwd", rows, 1, hw)) return e;
+    ROW_DISPATCH(preact_bwd_kernel, (int)rows, hw, dsnt_aligned16(y), x, y, gy, gx, hw, mode, eps);
+    DSNT_CHECK_LAUNCH("dsnt_preact_bwd");
+}
+
+extern "C" int dsnt_expect_fwd(const float* hm, float* coords, int64_t rows, int h, int w, void* stream) {
+    DSNT_REQUIRE(hm && coords, DSNT_ERR_ARG, "dsnt_expect_fwd: null tensor");
+    if (int e = check_rows("dsnt_expect_fwd", rows, h, w)) return e;
+    ROW_DISPATCH(expect_fwd_kernel, (int)rows, h * w, dsnt_aligned16(hm), hm, coords, h, w);
+    DSNT_CHECK_LAUNCH("dsnt_expect_fwd");
+}
+
+extern "C" int dsnt_expect_bwd(const float* gcoords, float* ghm, int64_t rows, int h, int w, void* stream) {
+    DSNT_REQUIRE(gcoords && ghm, DSNT_ERR_ARG, "dsnt_expect_bwd: null tensor");
+    if (int e = check_rows("dsnt_expect_bwd", rows, h, w)) return e;
+    hipLaunchKernelGGL(expect_bwd_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, gcoords, ghm, h, w);
+    DSNT_CHECK_LAUNCH("dsnt_expect_bwd");
+}
+
+extern "C" int dsnt_make_gauss(const float* coords, float* out, int64_t rows, int h, int w, float sigma,
+                               void* stream) {
+    DSNT_REQUIRE(coords && out, DSNT_ERR_ARG, "dsnt_make_gauss: null tensor");
+    DSNT_REQUIRE(sigma > 0.f, DSNT_ERR_ARG, "dsnt_make_gauss: sigma must be positive");
+    if (int e = check_rows("dsnt_make_gauss", rows, h, w)) return e;
+    const float k = (float)(-0.5 * (1.0 / (double)sigma) * (1.0 / (double)sigma));
+    hipLaunchKernelGGL(make_gauss_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, coords, out, h, w, k);
+    DSNT_CHECK_LAUNCH("dsnt_make_gauss");
+}
+
+static inline float gauss_k(float sigma) { return (float)(-0.5 * (1.0 / (double)sigma) * (1.0 / (double)sigma)); }
+
+extern "C" int dsnt_reg_fwd(const float* hm, const float* target, float* per_row, int64_t rows, int h, int w,
+                            float sigma, int kind, void* stream) {
+    DSNT_REQUIRE(hm && per_row && (kind == 3 || target), DSNT_ERR_ARG, "dsnt_reg_fwd: null tensor");
+    DSNT_REQUIRE(kind >= 0 && kind <= 3, DSNT_ERR_ARG, "dsnt_reg_fwd: unknown kind %d", kind);
+    if (int e = check_rows("dsnt_reg_fwd", rows, h, w)) return e;
+    ROW_DISPATCH(reg_fwd_kernel, (int)rows, h * w, dsnt_aligned16(hm), hm, target, per_row, h, w, sigma,
+                 gauss_k(sigma), kind);
+    DSNT_CHECK_LAUNCH("dsnt_reg_fwd");
+}
+
+extern "C" int dsnt_reg_bwd(const float* hm, const float* target, const float* g_row, float* ghm, int64_t rows,
+                            int h, int w, float sigma, int kind, void* stream) {
+    DSNT_REQUIRE(hm && g_row && ghm && (kind == 3 || target), DSNT_ERR_ARG, "dsnt_reg_bwd: null tensor");
+    DSNT_REQUIRE(kind >= 0 && kind <= 3, DSNT_ERR_ARG, "dsnt_reg_bwd: unknown kind %d", kind);
+    if (int e = check_rows("dsnt_reg_bwd", rows, h, w)) return e;
+    ROW_DISPATCH(reg_bwd_kernel, (int)rows, h * w, dsnt_aligned16(hm), hm, target, g_row, ghm, h, w, sigma,
+                 gauss_k(sigma), kind);
+    DSNT_CHECK_LAUNCH("dsnt_reg_bwd");
+}
+
+extern "C" int dsnt_euclid_fwd(const float* actual, const float* target, float* dist, int64_t n, int d,
+                               void* stream) {
+    DSNT_REQUIRE(actual && target && dist && n > 0 && d > 0, DSNT_ERR_ARG, "dsnt_euclid_fwd: bad argument");
+    hipLaunchKernelGGL(euclid_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       actual, target, dist, (long)n, d);
+    DSNT_CHECK_LAUNCH("dsnt_euclid_fwd");
+}
+
+extern "C" int dsnt_euclid_bwd(const float* actual, const float* target, const float* dist, const float* g_dist,
+                               float* g_actual, int64_t n, int d, void* stream) {
+    DSNT_REQUIRE(actual && target && dist && g_dist && g_actual && n > 0 && d > 0, DSNT_ERR_ARG,
+                 "dsnt_euclid_bwd: bad argument");
+    hipLaunchKernelGGL(euclid_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       actual, target, dist, g_dist, g_actual, (long)n, d);
+    DSNT_CHECK_LAUNCH("dsnt_euclid_bwd");
+}
+
+extern "C" int dsnt_masked_avg_fwd(const float* losses, const float* mask, float* out2, int64_t n, void* stream) {
+    DSNT_REQUIRE(losses && out2 && n > 0, DSNT_ERR_ARG, "dsnt_masked_avg_fwd: bad argument");
+    hipLaunchKernelGGL(masked_avg_fwd_kernel, dim3(1), dim3(HB), 0, (hipStream_t)stream, losses, mask, out2, (long)n);
+    DSNT_CHECK_LAUNCH("dsnt_masked_avg_fwd");
+}
+
+extern "C" int dsnt_masked_avg_bwd(const float* g_out, const float* mask, const float* out2, float* g_losses,
+                                   int64_t n, void* stream) {
+    DSNT_REQUIRE(g_out && out2 && g_losses && n > 0, DSNT_ERR_ARG, "dsnt_masked_avg_bwd: bad argument");
+    hipLaunchKernelGGL(masked_avg_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       g_out, mask, out2, g_losses, (long)n);
+    DSNT_CHECK_LAUNCH("dsnt_masked_avg_bwd");
+}
+
+extern "C" int dsnt_head_fwd(const float* logits, float* hm, float* coords, int64_t rows, int h, int w,
+                             void* stream) {
+    DSNT_REQUIRE(logits && hm && coords, DSNT_ERR_ARG, "dsnt_head_fwd: null tensor");
+    if (int e = check_rows("dsnt_head_fwd", rows, h, w)) return e;
+    ROW_DISPATCH(head_fwd_kernel, (int)rows, h * w, dsnt_aligned16(logits) && dsnt_aligned16(hm), logits, hm,
+                 coords, h, w);
+    DSNT_CHECK_LAUNCH("dsnt_head_fwd");
+}
+
+extern "C" int dsnt_head_loss_rows(const float* hm, const float* coords, const float* target, float* dist,
+                                   float* reg_row, int64_t rows, int h, int w, float sigma, int reg_kind,
+                                   void* stream) {
+    DSNT_REQUIRE(hm && coords && target && dist && (reg_kind < 0 || reg_row), DSNT_ERR_ARG,
+                 "dsnt_head_loss_rows: null tensor");
+    DSNT_REQUIRE(reg_kind >= -1 && reg_kind <= 3, DSNT_ERR_ARG, "dsnt_head_loss_rows: unknown regulariser %d", reg_kind);
+    if (int e = check_rows("dsnt_head_loss_rows", rows, h, w)) return e;
+    ROW_DISPATCH(head_loss_rows_kernel, (int)rows, h * w, dsnt_aligned16(hm), hm, coords, target, dist, reg_row,
+                 h, w, sigma, gauss_k(sigma), reg_kind);
+    DSNT_CHECK_LAUNCH("dsnt_head_loss_rows");
+}
+
+extern "C" int dsnt_head_bwd(const float* hm, const float* coords, const float* target, const float* dist,
+                             const float* g_dist, const float* g_reg, float* g_logits, int64_t rows, int h, int w,
+                             float sigma, int reg_kind, void* stream) {
+    DSNT_REQUIRE(hm && coords && target && dist && g_dist && g_logits, DSNT_ERR_ARG, "dsnt_head_bwd: null tensor");
+    DSNT_REQUIRE(reg_kind >= -1 && reg_kind <= 3, DSNT_ERR_ARG, "dsnt_head_bwd: unknown regulariser %d", reg_kind);
+    if (int e = check_rows("dsnt_head_bwd", rows, h, w)) return e;
+    ROW_DISPATCH(head_bwd_kernel, (int)rows, h * w, dsnt_aligned16(hm), hm, coords, target, dist, g_dist, g_reg,
+                 g_logits, h, w, sigma, gauss_k(sigma), reg_kind);
+    DSNT_CHECK_LAUNCH("dsnt_head_bwd");
+}

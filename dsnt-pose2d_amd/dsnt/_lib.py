@@ -1,0 +1,127 @@
+"""ctypes binding of libdsnt_hip.so (the C ABI declared in include/dsnt_hip.h).
+
+There is no CPU fallback: if the library is missing or a tensor is not on a HIP device the
+call raises.  Kernels are enqueued on PyTorch's current stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libdsnt_hip.so')
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_int64
+F = C.c_float
+D = C.c_double
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ('N', 'H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'R', 'S', 'stride', 'pad', 'dil')]
+
+
+GP = C.POINTER(ConvGeom)
+
+# name -> argtypes (the trailing `void* stream` included where the C signature has it)
+SIGNATURES = {
+    'dsnt_preact_fwd': [P, P, L, I, I, F, F, P],
+    'dsnt_preact_bwd': [P, P, P, P, L, I, I, F, F, P],
+    'dsnt_expect_fwd': [P, P, L, I, I, P],
+    'dsnt_expect_bwd': [P, P, L, I, I, P],
+    'dsnt_make_gauss': [P, P, L, I, I, F, P],
+    'dsnt_reg_fwd': [P, P, P, L, I, I, F, I, P],
+    'dsnt_reg_bwd': [P, P, P, P, L, I, I, F, I, P],
+    'dsnt_euclid_fwd': [P, P, P, L, I, P],
+    'dsnt_euclid_bwd': [P, P, P, P, P, L, I, P],
+    'dsnt_masked_avg_fwd': [P, P, P, L, P],
+    'dsnt_masked_avg_bwd': [P, P, P, P, L, P],
+    'dsnt_head_fwd': [P, P, P, L, I, I, P],
+    'dsnt_head_loss_rows': [P, P, P, P, P, L, I, I, F, I, P],
+    'dsnt_head_bwd': [P, P, P, P, P, P, P, L, I, I, F, I, P],
+    'dsnt_conv_fwd': [P, P, P, P, P, P, I, P, P, P, GP, P],
+    'dsnt_conv_pack_dgrad': [P, P, I, I, I, I, P],
+    'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
+    'dsnt_bn_stats': [P, P, L, I, P],
+    'dsnt_bn_finalize': [P, I, L, I, P, P, P, P, F, F, I, P, P, P, P, P],
+    'dsnt_bn_act_fwd': [P, P, P, I, P, L, I, P],
+    'dsnt_bn_act_bwd_reduce': [P, P, P, P, P, P, I, P, L, I, P],
+    'dsnt_bn_bwd_finalize': [P, I, L, I, P, P, I, P, P],
+    'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
+    'dsnt_maxpool2_fwd': [P, P, P, I, I, I, I, P],
+    'dsnt_maxpool2_bwd': [P, P, P, I, I, I, I, I, P],
+    'dsnt_upsample2_add_fwd': [P, P, P, I, I, I, I, P],
+    'dsnt_upsample2_bwd': [P, P, I, I, I, I, I, P],
+    'dsnt_axpy': [P, P, F, I, L, P],
+    'dsnt_nchw_to_nhwc': [P, P, I, I, I, I, P],
+    'dsnt_nhwc_to_nchw': [P, P, I, I, I, I, P],
+    'dsnt_rmsprop_step': [P, P, P, L, F, F, F, F, F, P],
+    'dsnt_sgd_step': [P, P, P, L, F, F, F, F, I, P],
+    'dsnt_pckh': [P, P, P, P, P, P, F, P, P, I, I, P],
+}
+# entry points without the status/stream convention
+PLAIN = {
+    'dsnt_version': (I, []),
+    'dsnt_last_error': (C.c_char_p, []),
+    'dsnt_conv_fwd_bm': (I, [GP]),
+    'dsnt_conv_wgrad_ws_floats': (L, [GP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libdsnt_hip.so not found at %s — build it with `python dsnt-pose2d_amd/build.py` '
+                '(there is no CPU fallback for the dsnt hot path)' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = I
+        for name, (res, argtypes) in PLAIN.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = res
+        _lib = lib
+    return _lib
+
+
+def fn(name):
+    return getattr(load(), name)
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point on the current stream; raise on error."""
+    lib = load()
+    rc = getattr(lib, name)(*args, stream_ptr())
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, lib.dsnt_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses anything not resident on a GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('dsnt: tensor is on %s; the dsnt hot path runs on the HIP device only '
+                           '(no CPU fallback)' % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError('dsnt: tensor must be contiguous')
+    return t.data_ptr()
+
+
+def f32(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError('dsnt: expected float32, got %s (the HIP path computes in fp32)' % t.dtype)
+    return t

@@ -1,0 +1,221 @@
+/*
+ * dsnt_hip.h — C ABI of libdsnt_hip.so: the MI355X (gfx950) device path of the
+ * dsnt-pose2d hot path.
+ *
+ * The reference (anibali/dsnt-pose2d) has NO FFI layer: its device work is whatever
+ * PyTorch 0.3.1 + cuDNN 7 execute underneath pure-Python modules.
+ * Each entry point below therefore cites the reference *call site* whose device
+ * work it replaces (paths relative to /root/reference/src/dsnt/).
+ *
+ * Conventions
+ *  - plain pointers + sizes; every pointer is DEVICE memory owned by the caller
+ *    (PyTorch's allocator); the library allocates nothing and keeps no state
+ *    except a thread-local error string;
+ *  - all arithmetic is fp32; activations are NHWC ([N][H][W][C], C innermost);
+ *    conv weights are OHWI ([Cout][R][S][Cin]); heat-maps for the DSNT head are
+ *    planar rows ([rows = N*J][H*W]);
+ *  - kernels are enqueued on `stream` (a hipStream_t passed as void*) and never
+ *    synchronise, so calls can be captured into a hipGraph;
+ *  - return value 0 = OK, otherwise a dsnt_status; dsnt_last_error() describes it.
+ *    No C++ exception crosses this boundary.
+ */
+#ifndef DSNT_HIP_H
+#define DSNT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    DSNT_OK = 0,
+    DSNT_ERR_SHAPE = 1,       /* unsupported / inconsistent shape */
+    DSNT_ERR_ALIGN = 2,       /* pointer or channel count not 16-byte compatible */
+    DSNT_ERR_ARG = 3,         /* null pointer / bad enum */
+    DSNT_ERR_HIP = 4          /* hipGetLastError() after launch */
+} dsnt_status;
+
+int dsnt_version(void);
+const char* dsnt_last_error(void);
+
+/* ------------------------------------------------------------------ DSNT head
+ * rows = product of leading dims (N*J); each row is one H x W map, contiguous. */
+
+/* model.py:24-45 `_hm_preact`: mode 0 softmax (F.softmax over H*W), 1 thresholded
+ * softmax (nn.py:119-139; threshold, eps), 2 abs, 3 relu, 4 sigmoid (each / (sum+eps)). */
+int dsnt_preact_fwd(const float* x, float* y, int64_t rows, int hw, int mode,
+                    float threshold, float eps, void* stream);
+/* backward of the same (nn.py:131-139 for the softmax forms: y*(g - sum(y*g))). */
+int dsnt_preact_bwd(const float* x, const float* y, const float* gy, float* gx,
+                    int64_t rows, int hw, int mode, float threshold, float eps, void* stream);
+
+/* nn.py:25-78 `generate_xy` + `expectation_2d` + `dsnt`: coords[row] = (E[x], E[y]). */
+int dsnt_expect_fwd(const float* hm, float* coords, int64_t rows, int h, int w, void* stream);
+/* its backward: ghm[row][i] = gcoords.x * X_i + gcoords.y * Y_i. */
+int dsnt_expect_bwd(const float* gcoords, float* ghm, int64_t rows, int h, int w, void* stream);
+
+/* nn.py:168-205 `make_gauss`: out[row] = normalised Gaussian at coords[row], sigma. */
+int dsnt_make_gauss(const float* coords, float* out, int64_t rows, int h, int w, float sigma,
+                    void* stream);
+
+/* nn.py:208-298 regularisers, per-row value before masked_average.
+ * kind: 0 js, 1 kl, 2 mse, 3 var.  target = mu_t [rows][2]. */
+int dsnt_reg_fwd(const float* hm, const float* target, float* per_row, int64_t rows, int h, int w,
+                 float sigma, int kind, void* stream);
+/* ghm[row] = g_row[row] * d(per_row)/d(hm). */
+int dsnt_reg_bwd(const float* hm, const float* target, const float* g_row, float* ghm,
+                 int64_t rows, int h, int w, float sigma, int kind, void* stream);
+
+/* nn.py:97-116 `euclidean_loss` (per-point part): dist[i] = ||a_i - t_i||_2, d dims. */
+int dsnt_euclid_fwd(const float* actual, const float* target, float* dist, int64_t n, int d,
+                    void* stream);
+/* ga = g_dist * (a - t) / dist  (un-guarded at dist == 0, like the reference). */
+int dsnt_euclid_bwd(const float* actual, const float* target, const float* dist,
+                    const float* g_dist, float* g_actual, int64_t n, int d, void* stream);
+
+/* nn.py:81-94 `masked_average`: out[0] = sum(l*m)/clamp(sum m, 1); out[1] = that denominator.
+ * mask may be NULL (plain mean with max(numel,1)). */
+int dsnt_masked_avg_fwd(const float* losses, const float* mask, float* out2, int64_t n,
+                        void* stream);
+/* g_losses[i] = g_out[0] * m_i / denom  (denom read from out2[1]). */
+int dsnt_masked_avg_bwd(const float* g_out, const float* mask, const float* out2,
+                        float* g_losses, int64_t n, void* stream);
+
+/* Fused head, forward: model.py:288-291 (softmax preact + dsnt) in one pass over the logits.
+ * Writes normalised heat-maps and coords. */
+int dsnt_head_fwd(const float* logits, float* hm, float* coords, int64_t rows, int h, int w,
+                  void* stream);
+/* Fused head, loss: model.py:233-246 — per-row Euclidean distance and regulariser value
+ * (reg_kind -1 = none) from the saved heat-maps; reductions by dsnt_masked_avg_fwd. */
+int dsnt_head_loss_rows(const float* hm, const float* coords, const float* target,
+                        float* dist, float* reg_row, int64_t rows, int h, int w, float sigma,
+                        int reg_kind, void* stream);
+/* Fused head, backward: d loss / d logits in one pass, given per-row upstream factors
+ * g_dist[row] (for the Euclidean term) and g_reg[row] (for the regulariser), i.e.
+ * model.py:233-246 + nn.py:66-78 + softmax backward collapsed. */
+int dsnt_head_bwd(const float* hm, const float* coords, const float* target, const float* dist,
+                  const float* g_dist, const float* g_reg, float* g_logits, int64_t rows,
+                  int h, int w, float sigma, int reg_kind, void* stream);
+
+/* --------------------------------------------------------------- convolutions
+ * Implicit-GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replaces nn.Conv2d forward
+ * and its autograd (hourglass.py:20-25,104-105,120-123,135-136,148; model.py:129). */
+typedef struct {
+    int N, H, W, Cin;          /* input  [N][H][W][Cin]   (Cin % 4 == 0) */
+    int Ho, Wo, Cout;          /* output [N][Ho][Wo][Cout] */
+    int R, S;                  /* filter taps */
+    int stride, pad, dil;
+} dsnt_conv_geom;
+
+/* y = conv(act(x)) + bias + res1 + res2,  act(x) = relu?(x*in_scale[c] + in_shift[c]) when
+ * in_scale != NULL (the BatchNorm2d+ReLU that precedes the conv in a pre-activation
+ * Bottleneck, hourglass.py:33-43, folded into the operand load; zero padding is applied
+ * AFTER the activation, as F.conv2d pads the activated tensor).
+ * bias/res1/res2 may be NULL.  res* have y's shape; res1 may alias y (in-place accumulate).
+ * stats_partial (may be NULL): [ceil(M/128)][2][Cout] per-tile column sums and sums of
+ * squares of y — the batch statistics of the next BatchNorm (hourglass.py:19,21,24). */
+int dsnt_conv_fwd(const float* x, const float* w, const float* bias, float* y,
+                  const float* in_scale, const float* in_shift, int in_relu,
+                  const float* res1, const float* res2, float* stats_partial,
+                  const dsnt_conv_geom* g, void* stream);
+
+/* Rows per stats_partial tile that dsnt_conv_fwd uses for this geometry (128 or 32): the
+ * caller sizes stats_partial as [ceil(M/bm)][2][Cout] and hands ceil(M/bm) to dsnt_bn_finalize. */
+int dsnt_conv_fwd_bm(const dsnt_conv_geom* g);
+
+/* Re-pack OHWI weights for the data-gradient pass: wd[Cin][R][S][Cout] with taps flipped,
+ * so that dgrad(dy) == dsnt_conv_fwd(dy, wd) with pad' = dil*(R-1) - pad (stride 1). */
+int dsnt_conv_pack_dgrad(const float* w, float* wd, int Cout, int R, int S, int Cin,
+                         void* stream);
+
+/* Weight / bias gradient: dw[Cout][R][S][Cin] = sum_m act(x)[m, (r,s,c)] * dy[m, cout],
+ * dbias[cout] = sum_m dy.  `ws` is caller workspace of dsnt_conv_wgrad_ws_floats() floats.
+ * accumulate != 0 adds into dw/dbias instead of overwriting. */
+int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g);
+int dsnt_conv_wgrad(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                    const float* dy, float* ws, float* dw, float* dbias, int accumulate,
+                    const dsnt_conv_geom* g, void* stream);
+
+/* ----------------------------------------------------- batch-norm, elementwise
+ * x viewed as [M][C] (M = N*H*W), C % 4 == 0. */
+
+/* Column sums / sums of squares per 128-row tile: partial[ceil(M/128)][2][C]
+ * (same format as dsnt_conv_fwd's stats_partial). */
+int dsnt_bn_stats(const float* x, float* partial, int64_t M, int C, void* stream);
+
+/* nn.BatchNorm2d forward bookkeeping (hourglass.py:19,21,24,106,147; torch defaults):
+ * training: mean/var(biased) from partials -> mean, invstd = rsqrt(var+eps);
+ *           running_mean/var updated with `momentum` (unbiased var);
+ * eval:     mean/invstd from the running statistics.
+ * Always: scale = gamma*invstd, shift = beta - mean*scale. */
+int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int C,
+                     const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps,
+                     int training, float* mean, float* invstd, float* scale, float* shift,
+                     void* stream);
+
+/* y = relu?(x*scale + shift) materialised (stem: hourglass.py:158-159). */
+int dsnt_bn_act_fwd(const float* x, const float* scale, const float* shift, int relu,
+                    float* y, int64_t M, int C, void* stream);
+
+/* Backward of y = relu?(bn(x)) given da = dL/dy, in three steps:
+ *  reduce:   partial[tile][0][c] = sum dz, partial[tile][1][c] = sum dz*xhat,
+ *            dz = da * (y > 0), xhat = (x - mean)*invstd;
+ *  finalize: dgamma (+)= sum dz*xhat, dbeta (+)= sum dz, coef[0][c] = mean(dz),
+ *            coef[1][c] = mean(dz*xhat);
+ *  apply:    dx (+)= gamma*invstd * (dz - coef0 - xhat*coef1). */
+int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const float* scale,
+                           const float* shift, const float* mean, const float* invstd,
+                           int relu, float* partial, int64_t M, int C, void* stream);
+int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M, int C,
+                         float* dgamma, float* dbeta, int accumulate, float* coef,
+                         void* stream);
+int dsnt_bn_act_bwd_apply(const float* da, const float* x, const float* scale,
+                          const float* shift, const float* mean, const float* invstd,
+                          const float* coef, int relu, float* dx, int accumulate,
+                          int64_t M, int C, void* stream);
+
+/* F.max_pool2d(x, 2, stride=2) (hourglass.py:80,111,162): y [N][H/2][W/2][C],
+ * idx = position (0..3) of the first maximum in scan order, for the backward. */
+int dsnt_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C,
+                      void* stream);
+int dsnt_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int accumulate,
+                      int N, int H, int W, int C, void* stream);
+
+/* out = up + nearest_upsample2x(low) (hourglass.py:58,88-89); low [N][H/2][W/2][C]. */
+int dsnt_upsample2_add_fwd(const float* up, const float* low, float* out,
+                           int N, int H, int W, int C, void* stream);
+/* dlow (+)= 2x2 block sums of dout. */
+int dsnt_upsample2_bwd(const float* dout, float* dlow, int accumulate,
+                       int N, int H, int W, int C, void* stream);
+
+/* y (+)= a*x, flat; n % 4 == 0 not required. */
+int dsnt_axpy(const float* x, float* y, float a, int accumulate, int64_t n, void* stream);
+
+/* Layout changes at the model boundary (logical NCHW surface, model.py:229-231,
+ * tests/test_model.py:22-23): src [N][C][HW] -> dst [N][HW][Cpad] (zero-filled pad)
+ * and back (dst [N][C][HW] <- src [N][HW][Cpad]). */
+int dsnt_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int Cpad, void* stream);
+int dsnt_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int Cpad, void* stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * train.py:314-326 — flat multi-tensor updates over the whole parameter arena. */
+int dsnt_rmsprop_step(float* p, const float* g, float* square_avg, int64_t n, float lr,
+                      float alpha, float eps, float weight_decay, float grad_scale, void* stream);
+int dsnt_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr,
+                  float momentum, float weight_decay, float grad_scale, int first_step,
+                  void* stream);
+
+/* ------------------------------------------------------------------ metrics
+ * evaluator.py:66-81 + train.py:243-258: PCKh hits on device.
+ * pred/target [B][J][2] normalised coords; m [B][2][2], b [B][2] back-projection (f64 maths);
+ * mask [B][J]; head [B]; out hits[B][J] (1/0), valid[B][J] (mask == 1). */
+int dsnt_pckh(const float* pred, const float* target, const double* m, const double* b,
+              const float* mask, const double* head, float threshold, float* hits,
+              float* valid, int B, int J, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

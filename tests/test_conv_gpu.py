@@ -1,0 +1,221 @@
+"""HIP implicit-GEMM convolution / BN / pool kernels vs torch CPU ops (the oracle's building
+blocks), called through the C ABI.  fp32 MFMA is an exact-f32 fmaf chain, so forward values are
+held to 2e-5 relative to the output scale (accumulation-order differences only)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dsnt import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _geom(N, H, W, Cin, Cout, R, S, stride, pad, dil):
+    from dsnt._lib import ConvGeom
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    return ConvGeom(N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 16, 16, 128, 128, 3, 1, 1, 1),
+    (2, 16, 16, 256, 128, 1, 1, 0, 1),
+    (2, 16, 16, 128, 256, 1, 1, 0, 1),
+    (3, 8, 8, 256, 16, 1, 1, 0, 1),      # score
+    (3, 8, 8, 16, 256, 1, 1, 0, 1),      # score_
+    (2, 32, 32, 4, 64, 7, 2, 3, 1),      # stem (Cin padded 3 -> 4)
+    (2, 12, 12, 64, 64, 3, 1, 1, 1),
+    (1, 5, 7, 64, 128, 3, 1, 1, 1),      # ragged M (35 rows)
+    (2, 16, 16, 64, 128, 3, 2, 1, 1),    # stride 2 (ResNet)
+    (2, 16, 16, 64, 64, 3, 1, 2, 2),     # dilated (ResNet dilate)
+    (4, 64, 64, 128, 128, 3, 1, 1, 1),   # multi-tile, XCD remap
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('pro', [False, True])
+def test_conv_fwd_wgrad_dgrad(case, pro):
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    dev = torch.device('cuda:0')
+    tag = 'c' + '_'.join(map(str, case))
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=1)
+    w = synthetic.tensor(tag + 'w', (Cout, Cin, k, k), seed=1, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = synthetic.tensor(tag + 'b', (Cout,), seed=1, scale=0.1)
+    sc = synthetic.tensor(tag + 's', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'h', (Cin,), seed=1, scale=0.3)
+    g = _geom(N, H, W, Cin, Cout, k, k, stride, pad, dil)
+    act = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if pro else x
+    act = act.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    br = b.clone().requires_grad_()
+    y_ref = F.conv2d(act, wr, br, stride=stride, padding=pad, dilation=dil)
+    res = synthetic.tensor(tag + 'r', tuple(y_ref.shape), seed=1)
+    y_ref2 = y_ref + res
+    gy = synthetic.tensor(tag + 'g', tuple(y_ref.shape), seed=2)
+    y_ref2.backward(gy)
+
+    xd = _nhwc(x).to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)       # OHWI
+    bd, scd, shd = b.to(dev), sc.to(dev), sh.to(dev)
+    resd = _nhwc(res).to(dev)
+    y = torch.empty(N, g.Ho, g.Wo, Cout, device=dev)
+    M = N * g.Ho * g.Wo
+    bm = _lib.fn('dsnt_conv_fwd_bm')(C.byref(g))
+    tiles = (M + bm - 1) // bm
+    stats = torch.zeros(tiles, 2, Cout, device=dev)
+    call('dsnt_conv_fwd', ptr(xd), ptr(wd), ptr(bd), ptr(y), ptr(scd) if pro else None,
+         ptr(shd) if pro else None, 1, ptr(resd), None, ptr(stats), C.byref(g))
+    got = y.cpu().permute(0, 3, 1, 2)
+    scale = y_ref2.abs().max().item()
+    assert (got - y_ref2.detach()).abs().max().item() <= 2e-5 * scale
+    # fused statistics epilogue == column sums of the output
+    yd = y_ref2.detach().permute(0, 2, 3, 1).reshape(M, Cout).double()
+    s = stats.cpu().double().sum(0)
+    assert (s[0] - yd.sum(0)).abs().max().item() <= 1e-4 * max(1.0, yd.sum(0).abs().max().item())
+    assert (s[1] - (yd * yd).sum(0)).abs().max().item() <= 1e-4 * (yd * yd).sum(0).max().item()
+
+    # weight / bias gradient
+    gyd = _nhwc(gy).to(dev)
+    ws = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev)
+    dw = torch.empty_like(wd)
+    db = torch.empty(Cout, device=dev)
+    call('dsnt_conv_wgrad', ptr(xd), ptr(scd) if pro else None, ptr(shd) if pro else None, 1,
+         ptr(gyd), ptr(ws), ptr(dw), ptr(db), 0, C.byref(g))
+    dw_ref = wr.grad.permute(0, 2, 3, 1)
+    assert (dw.cpu() - dw_ref).abs().max().item() <= 3e-5 * max(1.0, dw_ref.abs().max().item())
+    assert (db.cpu() - br.grad).abs().max().item() <= 3e-5 * max(1.0, br.grad.abs().max().item())
+    call('dsnt_conv_wgrad', ptr(xd), ptr(scd) if pro else None, ptr(shd) if pro else None, 1,
+         ptr(gyd), ptr(ws), ptr(dw), ptr(db), 1, C.byref(g))
+    assert (dw.cpu() - 2 * dw_ref).abs().max().item() <= 6e-5 * max(1.0, dw_ref.abs().max().item())
+
+    # data gradient (stride-1 convs): forward kernel on dy with the re-packed weights
+    if stride == 1:
+        wdg = torch.empty(Cin, k, k, Cout, device=dev)
+        call('dsnt_conv_pack_dgrad', ptr(wd), ptr(wdg), Cout, k, k, Cin)
+        gd = _geom(N, g.Ho, g.Wo, Cout, Cin, k, k, 1, dil * (k - 1) - pad, dil)
+        assert gd.Ho == H and gd.Wo == W
+        if Cout % 4 == 0:
+            da = torch.empty(N, H, W, Cin, device=dev)
+            call('dsnt_conv_fwd', ptr(gyd), ptr(wdg), None, ptr(da), None, None, 0, None, None,
+                 None, C.byref(gd))
+            da_ref = act.grad.permute(0, 2, 3, 1)
+            assert (da.cpu() - da_ref).abs().max().item() <= 2e-5 * da_ref.abs().max().item()
+            # in-place accumulate through res1 == y
+            call('dsnt_conv_fwd', ptr(gyd), ptr(wdg), None, ptr(da), None, None, 0, ptr(da), None,
+                 None, C.byref(gd))
+            assert (da.cpu() - 2 * da_ref).abs().max().item() <= 4e-5 * da_ref.abs().max().item()
+
+
+def test_conv_errors():
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    dev = torch.device('cuda:0')
+    g = _geom(1, 8, 8, 6, 8, 1, 1, 1, 0, 1)   # Cin not a multiple of 4
+    t = torch.zeros(1024, device=dev)
+    with pytest.raises(RuntimeError, match='multiple of 4'):
+        call('dsnt_conv_fwd', ptr(t), ptr(t), None, ptr(t), None, None, 0, None, None, None, C.byref(g))
+    g = _geom(1, 8, 8, 8, 8, 3, 3, 1, 1, 1)
+    g.Ho = 7
+    with pytest.raises(RuntimeError, match='inconsistent'):
+        call('dsnt_conv_fwd', ptr(t), ptr(t), None, ptr(t), None, None, 0, None, None, None, C.byref(g))
+
+
+@pytest.mark.parametrize('M,Cc', [(2 * 16 * 16, 256), (3 * 5 * 7, 64), (2 * 64 * 64, 128), (37, 16)])
+def test_batchnorm_pieces(M, Cc):
+    """stats -> finalize -> act fwd, and reduce -> finalize -> apply bwd vs F.batch_norm+relu."""
+    from dsnt._lib import ptr, call
+    dev = torch.device('cuda:0')
+    x = synthetic.tensor('bnx%d_%d' % (M, Cc), (M, Cc), seed=3) * 1.7 + 0.4
+    gamma = synthetic.tensor('bng', (Cc,), seed=3, kind='uniform') + 1.5
+    beta = synthetic.tensor('bnb', (Cc,), seed=3, scale=0.2)
+    gy = synthetic.tensor('bngy%d_%d' % (M, Cc), (M, Cc), seed=4)
+    xr = x.clone().requires_grad_()
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    y_ref = F.relu(F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5))
+    y_ref.backward(gy)
+
+    xd, gd, bd = x.to(dev), gamma.to(dev), beta.to(dev)
+    tiles = (M + 127) // 128
+    part = torch.empty(tiles, 2, Cc, device=dev)
+    call('dsnt_bn_stats', ptr(xd), ptr(part), M, Cc)
+    mean, invstd, scale, shift = (torch.empty(Cc, device=dev) for _ in range(4))
+    rmd, rvd = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    call('dsnt_bn_finalize', ptr(part), tiles, M, Cc, ptr(gd), ptr(bd), ptr(rmd), ptr(rvd), 0.1, 1e-5,
+         1, ptr(mean), ptr(invstd), ptr(scale), ptr(shift))
+    y = torch.empty(M, Cc, device=dev)
+    call('dsnt_bn_act_fwd', ptr(xd), ptr(scale), ptr(shift), 1, ptr(y), M, Cc)
+    assert (y.cpu() - y_ref.detach()).abs().max().item() <= 1e-5 * max(1, y_ref.abs().max().item())
+    assert (rmd.cpu() - rm).abs().max().item() <= 1e-6 and (rvd.cpu() - rv).abs().max().item() <= 1e-5
+    gyd = gy.to(dev)
+    call('dsnt_bn_act_bwd_reduce', ptr(gyd), ptr(xd), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), 1,
+         ptr(part), M, Cc)
+    dgamma, dbeta = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    coef = torch.empty(2, Cc, device=dev)
+    call('dsnt_bn_bwd_finalize', ptr(part), tiles, M, Cc, ptr(dgamma), ptr(dbeta), 0, ptr(coef))
+    dx = torch.empty(M, Cc, device=dev)
+    call('dsnt_bn_act_bwd_apply', ptr(gyd), ptr(xd), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+         ptr(coef), 1, ptr(dx), 0, M, Cc)
+    tol = 2e-5
+    assert (dx.cpu() - xr.grad).abs().max().item() <= tol * max(1, xr.grad.abs().max().item())
+    assert (dgamma.cpu() - gr.grad).abs().max().item() <= tol * max(1, gr.grad.abs().max().item())
+    assert (dbeta.cpu() - br.grad).abs().max().item() <= tol * max(1, br.grad.abs().max().item())
+    # eval mode: scale/shift from the running statistics
+    call('dsnt_bn_finalize', None, 0, M, Cc, ptr(gd), ptr(bd), ptr(rmd), ptr(rvd), 0.1, 1e-5, 0,
+         ptr(mean), ptr(invstd), ptr(scale), ptr(shift))
+    call('dsnt_bn_act_fwd', ptr(xd), ptr(scale), ptr(shift), 0, ptr(y), M, Cc)
+    y_eval = F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)
+    assert (y.cpu() - y_eval).abs().max().item() <= 1e-5 * max(1, y_eval.abs().max().item())
+
+
+@pytest.mark.parametrize('N,H,W,Cc', [(2, 8, 8, 256), (3, 4, 6, 64), (1, 64, 64, 128)])
+def test_pool_upsample(N, H, W, Cc):
+    from dsnt._lib import ptr, call
+    dev = torch.device('cuda:0')
+    x = synthetic.tensor('px', (N, Cc, H, W), seed=5).requires_grad_()
+    y_ref = F.max_pool2d(x, 2, stride=2)
+    gy = synthetic.tensor('pg', tuple(y_ref.shape), seed=5)
+    y_ref.backward(gy)
+    xd = _nhwc(x.detach()).to(dev)
+    y = torch.empty(N, H // 2, W // 2, Cc, device=dev)
+    idx = torch.empty(N, H // 2, W // 2, Cc, dtype=torch.uint8, device=dev)
+    call('dsnt_maxpool2_fwd', ptr(xd), ptr(y), ptr(idx), N, H, W, Cc)
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), y_ref.detach())
+    dx = torch.empty_like(xd)
+    gyd = _nhwc(gy).to(dev)   # keep device temporaries alive until the kernels have run
+    call('dsnt_maxpool2_bwd', ptr(gyd), ptr(idx), ptr(dx), 0, N, H, W, Cc)
+    assert torch.equal(dx.cpu().permute(0, 3, 1, 2), x.grad)
+    call('dsnt_maxpool2_bwd', ptr(gyd), ptr(idx), ptr(dx), 1, N, H, W, Cc)
+    assert torch.equal(dx.cpu().permute(0, 3, 1, 2), 2 * x.grad)
+
+    up = synthetic.tensor('uu', (N, Cc, H, W), seed=6)
+    low = synthetic.tensor('ul', (N, Cc, H // 2, W // 2), seed=6).requires_grad_()
+    out_ref = up + F.interpolate(low, scale_factor=2, mode='nearest')
+    go = synthetic.tensor('ug', (N, Cc, H, W), seed=6)
+    out_ref.backward(go)
+    out = torch.empty(N, H, W, Cc, device=dev)
+    upd, lowd, god = _nhwc(up).to(dev), _nhwc(low.detach()).to(dev), _nhwc(go).to(dev)
+    call('dsnt_upsample2_add_fwd', ptr(upd), ptr(lowd), ptr(out), N, H, W, Cc)
+    assert torch.equal(out.cpu().permute(0, 3, 1, 2), out_ref.detach())
+    dl = torch.empty(N, H // 2, W // 2, Cc, device=dev)
+    call('dsnt_upsample2_bwd', ptr(god), ptr(dl), 0, N, H, W, Cc)
+    assert (dl.cpu().permute(0, 3, 1, 2) - low.grad).abs().max().item() <= 1e-6
+
+    # layout round trip with channel padding
+    img = synthetic.tensor('im', (N, 3, H, W), seed=7)
+    nhwc = torch.empty(N, H, W, 4, device=dev)
+    imgd = img.to(dev)
+    call('dsnt_nchw_to_nhwc', ptr(imgd), ptr(nhwc), N, 3, H * W, 4)
+    assert torch.equal(nhwc.cpu()[..., :3].permute(0, 3, 1, 2), img) and nhwc[..., 3].abs().max().item() == 0
+    back = torch.empty(N, 3, H, W, device=dev)
+    call('dsnt_nhwc_to_nchw', ptr(nhwc), ptr(back), N, 3, H * W, 4)
+    assert torch.equal(back.cpu(), img)
