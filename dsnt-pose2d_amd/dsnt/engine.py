@@ -1,0 +1,318 @@
+"""Static launch-list engine for the hourglass backbone on MI355X.
+
+The reference runs the backbone as ~300 separate PyTorch modules per pass
+(`/root/reference/src/dsnt/hourglass.py:30-50,78-90,155-177`) and lets autograd record them
+every step.  Here the module tree is traced ONCE per (batch shape, mode) into two flat lists of
+C-ABI kernel launches (forward, backward) over pre-allocated NHWC buffers; a step is a replay
+of those lists on the current HIP stream (no allocation, no Python graph building, capturable
+into a hipGraph).  Fusions decided at trace time:
+
+* BatchNorm+ReLU in front of a conv is folded into the conv's operand load (scale/shift per
+  input channel); its batch statistics come from the *producer's* epilogue (per-tile column
+  sums written by the previous conv), so a pre-activation Bottleneck is 3 conv launches + 3
+  tiny finalise launches instead of 10 elementwise passes;
+* residual / skip adds ride in the conv epilogue (up to two addends);
+* in backward, identity branches donate the incoming gradient buffer instead of copying, and
+  every kernel that produces a gradient can accumulate in place, so fan-in costs no extra pass.
+
+Gradients with respect to parameters are written straight into one flat arena (the same arena
+the fused optimiser and the RCCL all-reduce operate on).
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+from ._lib import ConvGeom
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Act:
+    """An activation on the tape: NHWC buffer + lazily created gradient / batch statistics."""
+    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name')
+
+    def __init__(self, buf, name=''):
+        self.buf = buf
+        self.N, self.H, self.W, self.C = buf.shape
+        self.grad = None        # torch tensor once some backward op has written it
+        self.stats = None       # (partial tensor, ntiles)
+        self.name = name
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+
+class ConvParams:
+    """Views into the parameter / gradient arenas for one convolution (weights are OHWI)."""
+    __slots__ = ('w', 'b', 'gw', 'gb', 'Cout', 'R', 'S', 'Cin', 'stride', 'pad', 'dil')
+
+    def __init__(self, w, b, gw, gb, stride=1, pad=0, dil=1):
+        self.w, self.b, self.gw, self.gb = w, b, gw, gb
+        self.Cout, self.R, self.S, self.Cin = w.shape
+        self.stride, self.pad, self.dil = stride, pad, dil
+
+
+class BnParams:
+    __slots__ = ('gamma', 'beta', 'ggamma', 'gbeta', 'rmean', 'rvar', 'C', 'uses', 'momentum', 'eps')
+
+    def __init__(self, gamma, beta, ggamma, gbeta, rmean, rvar, momentum=BN_MOMENTUM, eps=BN_EPS):
+        self.gamma, self.beta, self.ggamma, self.gbeta = gamma, beta, ggamma, gbeta
+        self.rmean, self.rvar = rmean, rvar
+        self.momentum, self.eps = float(momentum), float(eps)
+        self.C = gamma.numel()
+        self.uses = 0           # backward accumulates dgamma/dbeta from the second use on
+
+
+class Normed:
+    """x seen through a BatchNorm(+ReLU): what a fused conv prologue needs."""
+    __slots__ = ('x', 'bn', 'mean', 'invstd', 'scale', 'shift', 'relu')
+
+
+class Tape:
+    def __init__(self, device, training):
+        self.device = device
+        self.training = training
+        self.fwd = []           # (cfunc, args)
+        self.bwd = []
+        self._bwd_emitters = []
+        self._scratch = {}
+        self._keep = []         # keeps ctypes structs / tensors alive
+        self.lib = _lib.load()
+        self.nbytes = 0
+        self.acts = []          # every activation in creation order (debugging / introspection)
+
+    # ------------------------------------------------------------------ buffers
+    def empty(self, *shape, dtype=torch.float32):
+        t = torch.empty(*shape, device=self.device, dtype=dtype)
+        self.nbytes += t.numel() * t.element_size()
+        self._keep.append(t)
+        return t
+
+    def scratch(self, key, numel):
+        """Shared scratch (valid only within one op's launches on the single stream)."""
+        if os.environ.get('DSNT_NO_SCRATCH'):
+            return self.empty(max(numel, 1))
+        t = self._scratch.get(key)
+        if t is None or t.numel() < numel:
+            if t is not None:
+                self._keep.append(t)   # earlier launches recorded the old pointer
+            t = torch.empty(max(numel, 1), device=self.device, dtype=torch.float32)
+            self.nbytes += t.numel() * 4
+            self._scratch[key] = t
+        return t
+
+    def act(self, N, H, W, Cc, name=''):
+        a = Act(self.empty(N, H, W, Cc), name)
+        self.acts.append(a)
+        return a
+
+    # ------------------------------------------------------------------ emission helpers
+    def _emit(self, lst, name, *args):
+        fn = getattr(self.lib, name)
+        conv = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                conv.append(_lib.ptr(a))
+            elif isinstance(a, ConvGeom):
+                self._keep.append(a)
+                conv.append(C.byref(a))
+            else:
+                conv.append(a)
+        lst.append((fn, tuple(conv), name))
+
+    def f(self, name, *args):
+        self._emit(self.fwd, name, *args)
+
+    def b(self, name, *args):
+        self._emit(self.bwd, name, *args)
+
+    def on_backward(self, fn):
+        self._bwd_emitters.append(fn)
+
+    def finish(self):
+        """Emit the backward list (reverse order of the forward ops)."""
+        for fn in reversed(self._bwd_emitters):
+            fn()
+        self._bwd_emitters = []
+
+    @staticmethod
+    def run(lst):
+        stream = torch.cuda.current_stream().cuda_stream
+        for fn, args, name in lst:
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise RuntimeError('%s failed (%d): %s' % (
+                    name, rc, _lib.load().dsnt_last_error().decode()))
+
+    # ------------------------------------------------------------------ gradient plumbing
+    def grad_target(self, a):
+        """(buffer, accumulate flag) for a kernel about to write a's gradient."""
+        if a.grad is None:
+            a.grad = self.empty(a.N, a.H, a.W, a.C)
+            return a.grad, 0
+        return a.grad, 1
+
+    def grad_identity(self, a, g, donate):
+        """a.grad (+)= g.  With `donate`, g's buffer is handed over when a has no gradient yet
+        (the caller guarantees g is dead after its own launches).  Returns True if donated."""
+        if a.grad is None and donate and not os.environ.get('DSNT_NO_DONATE'):
+            a.grad = g
+            return True
+        buf, acc = self.grad_target(a)
+        self.b('dsnt_axpy', g, buf, 1.0, acc, g.numel())
+        return False
+
+    # ------------------------------------------------------------------ ops
+    def geom(self, x, p):
+        Ho = (x.H + 2 * p.pad - p.dil * (p.R - 1) - 1) // p.stride + 1
+        Wo = (x.W + 2 * p.pad - p.dil * (p.S - 1) - 1) // p.stride + 1
+        assert x.C == p.Cin, (x.C, p.Cin)
+        return ConvGeom(x.N, x.H, x.W, p.Cin, Ho, Wo, p.Cout, p.R, p.S, p.stride, p.pad, p.dil)
+
+    def ensure_stats(self, a):
+        if a.stats is None:
+            tiles = (a.M + 127) // 128
+            part = self.empty(tiles, 2, a.C)
+            self.f('dsnt_bn_stats', a.buf, part, a.M, a.C)
+            a.stats = (part, tiles)
+        return a.stats
+
+    def norm(self, x, bn, relu=True):
+        """BatchNorm bookkeeping for x under `bn`: finalise kernel -> scale/shift vectors."""
+        if os.environ.get('DSNT_DEBUG_NO_RELU'):   # smooth network for exact gradient checks
+            relu = False
+        n = Normed()
+        n.x, n.bn, n.relu = x, bn, relu
+        n.mean, n.invstd, n.scale, n.shift = (self.empty(bn.C) for _ in range(4))
+        if self.training:
+            part, tiles = self.ensure_stats(x)
+            self.f('dsnt_bn_finalize', part, tiles, x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
+                   bn.momentum, bn.eps, 1, n.mean, n.invstd, n.scale, n.shift)
+        else:
+            self.f('dsnt_bn_finalize', None, 0, x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
+                   bn.momentum, bn.eps, 0, n.mean, n.invstd, n.scale, n.shift)
+        return n
+
+    def _norm_backward(self, n, da):
+        """Given da = dL/d relu(bn(x)), accumulate dx into n.x.grad and dgamma/dbeta."""
+        x, bn = n.x, n.bn
+        tiles = (x.M + 127) // 128
+        part = self.scratch('bnpart', tiles * 2 * bn.C).view(-1)
+        coef = self.scratch('bncoef', 2 * bn.C)
+        relu = 1 if n.relu else 0
+        self.b('dsnt_bn_act_bwd_reduce', da, x.buf, n.scale, n.shift, n.mean, n.invstd, relu, part,
+               x.M, bn.C)
+        acc_p = 1 if bn.uses > 0 else 0
+        bn.uses += 1
+        self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef)
+        buf, acc = self.grad_target(x)
+        self.b('dsnt_bn_act_bwd_apply', da, x.buf, n.scale, n.shift, n.mean, n.invstd, coef, relu,
+               buf, acc, x.M, bn.C)
+
+    def conv(self, src, p, res1=None, res2=None, want_stats=False, need_input_grad=True, name=''):
+        """y = conv(src) + bias [+ res1 + res2]; src is an Act (raw) or a Normed (BN+ReLU folded)."""
+        normed = isinstance(src, Normed)
+        x = src.x if normed else src
+        g = self.geom(x, p)
+        y = self.act(x.N, g.Ho, g.Wo, p.Cout, name)
+        sc = src.scale if normed else None
+        sh = src.shift if normed else None
+        relu = 1 if (normed and src.relu) else 0
+        part = None
+        if want_stats and self.training:
+            bm = self.lib.dsnt_conv_fwd_bm(C.byref(g))
+            tiles = (y.M + bm - 1) // bm
+            part = self.empty(tiles, 2, p.Cout)
+            y.stats = (part, tiles)
+        self.f('dsnt_conv_fwd', x.buf, p.w, p.b, y.buf, sc, sh, relu,
+               res1.buf if res1 is not None else None, res2.buf if res2 is not None else None,
+               part, g)
+        if not self.training:
+            return y
+
+        def backward():
+            gy = y.grad
+            assert gy is not None, 'no gradient reached conv output ' + name
+            # parameter gradients (flat arena, overwritten every step)
+            ws = self.scratch('wgrad', self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g)))
+            self.b('dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws, p.gw, p.gb, 0, g)
+            if need_input_grad:
+                assert p.stride == 1, 'data gradient of strided convs is not needed on this path'
+                wd = self.scratch('wdgrad', p.w.numel())
+                self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
+                gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1,
+                              p.dil * (p.R - 1) - p.pad, p.dil)
+                if normed:
+                    da = self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
+                    self.b('dsnt_conv_fwd', gy, wd, None, da, None, None, 0, None, None, None, gd)
+                    self._norm_backward(src, da)
+                else:
+                    buf, acc = self.grad_target(x)
+                    self.b('dsnt_conv_fwd', gy, wd, None, buf, None, None, 0,
+                           buf if acc else None, None, None, gd)
+            # identity branches last: gy is dead after the launches above
+            donated = False
+            for r in (res1, res2):
+                if r is not None:
+                    donated = self.grad_identity(r, gy, donate=not donated) or donated
+
+        self.on_backward(backward)
+        return y
+
+    def bn_act(self, x, bn, relu=True, name=''):
+        """Materialised y = relu?(bn(x)) (the stem: hourglass.py:157-159)."""
+        n = self.norm(x, bn, relu)
+        y = self.act(x.N, x.H, x.W, x.C, name)
+        self.f('dsnt_bn_act_fwd', x.buf, n.scale, n.shift, 1 if n.relu else 0, y.buf, x.M, x.C)
+        if self.training:
+            def backward():
+                self._norm_backward(n, y.grad)
+            self.on_backward(backward)
+        return y
+
+    def maxpool2(self, x, name=''):
+        y = self.act(x.N, x.H // 2, x.W // 2, x.C, name)
+        idx = self.empty(x.N, x.H // 2, x.W // 2, x.C, dtype=torch.uint8)
+        self.f('dsnt_maxpool2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
+        if self.training:
+            def backward():
+                buf, acc = self.grad_target(x)
+                self.b('dsnt_maxpool2_bwd', y.grad, idx, buf, acc, x.N, x.H, x.W, x.C)
+            self.on_backward(backward)
+        return y
+
+    def upsample2_add(self, up, low, name=''):
+        out = self.act(up.N, up.H, up.W, up.C, name)
+        self.f('dsnt_upsample2_add_fwd', up.buf, low.buf, out.buf, up.N, up.H, up.W, up.C)
+        if self.training:
+            def backward():
+                buf, acc = self.grad_target(low)
+                self.b('dsnt_upsample2_bwd', out.grad, buf, acc, up.N, up.H, up.W, up.C)
+                self.grad_identity(up, out.grad, donate=True)
+            self.on_backward(backward)
+        return out
+
+    def to_planar(self, x, C_logical, name=''):
+        """NHWC activation -> logical NCHW tensor [N, C, H, W] (model surface); returns the tensor.
+        In backward the incoming NCHW gradient is transposed into x.grad (first writer)."""
+        out = self.empty(x.N, C_logical, x.H, x.W)
+        gin = self.empty(x.N, C_logical, x.H, x.W) if self.training else None
+        self.f('dsnt_nhwc_to_nchw', x.buf, out, x.N, C_logical, x.H * x.W, x.C)
+        if self.training:
+            def backward():
+                assert x.grad is None, 'planar output must be the first gradient writer'
+                buf, _ = self.grad_target(x)
+                self.b('dsnt_nchw_to_nhwc', gin, buf, x.N, C_logical, x.H * x.W, x.C)
+            self.on_backward(backward)
+        return out, gin
+
+    def from_planar(self, src_nchw, Cpad, name=''):
+        """Logical NCHW input [N, C, H, W] -> NHWC Act with channels zero-padded to Cpad."""
+        N, Cc, H, W = src_nchw.shape
+        a = self.act(N, H, W, Cpad, name)
+        self.f('dsnt_nchw_to_nhwc', src_nchw, a.buf, N, Cc, H * W, Cpad)
+        return a

@@ -1,0 +1,410 @@
+"""Stacked-Hourglass backbone on the MI355X launch-list engine.
+
+Same constructor signatures, attribute names and `state_dict()` keys as
+`/root/reference/src/dsnt/hourglass.py` (`Bottleneck` :14-50, `Hourglass` :53-93,
+`HourglassNet` :96-177), so checkpoints and callers (`build_mpii_pose_model`,
+`convert_hg_model.py`) are interchangeable.  The `torch.nn` sub-modules here are parameter
+holders only (they give the reference's initialisation, shapes and key names); `forward` never
+calls them.  Instead the module tree is traced into forward/backward kernel launch lists
+(`engine.Tape`) over NHWC buffers, parameters live OHWI-packed in one flat arena (the
+`nn.Parameter`s become strided views of it with their logical OIHW shapes), and gradients land
+in a matching flat arena that the fused optimiser and the RCCL all-reduce consume directly.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib
+from .engine import Tape, ConvParams, BnParams
+
+EXPANSION = 2
+
+
+def _ceil4(n):
+    return (n + 3) // 4 * 4
+
+
+# ====================================================================== parameter arena
+class Arena:
+    """Flat fp32 storage for every parameter of a module tree (+ a same-shaped gradient arena).
+
+    Conv weights are stored OHWI with Cin padded to a multiple of 4 (only the 3-channel stem
+    needs padding); each `nn.Parameter.data` is re-pointed to a strided view with the logical
+    OIHW shape, so `state_dict()`, `load_state_dict()` and stock optimisers keep working.
+    """
+
+    def __init__(self, module, device):
+        self.device = device
+        slots, off = [], 0
+        for name, p in module.named_parameters():
+            if p.dim() == 4:
+                O, I, R, S = p.shape
+                n = O * R * S * _ceil4(I)
+            else:
+                n = p.numel()
+            slots.append((name, p, off, n))
+            off += _ceil4(n)
+        self.numel = off
+        self.params = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grads = torch.zeros(off, device=device, dtype=torch.float32)   # what p.grad views
+        self.fresh = torch.zeros(off, device=device, dtype=torch.float32)   # what backward writes
+        self.slots = slots
+        self.pviews, self.gviews, self.packed, self.packed_fresh = {}, {}, {}, {}
+        with torch.no_grad():
+            for name, p, o, n in slots:
+                src = p.detach().to(device=device, dtype=torch.float32)
+                if p.dim() == 4:
+                    O, I, R, S = p.shape
+                    Ip = _ceil4(I)
+                    store = self.params[o:o + n].view(O, R, S, Ip)
+                    store[..., :I].copy_(src.permute(0, 2, 3, 1))
+                    self.packed[name] = store
+                    self.packed_fresh[name] = self.fresh[o:o + n].view(O, R, S, Ip)
+                    pv = store.permute(0, 3, 1, 2)[:, :I]
+                    gv = self.grads[o:o + n].view(O, R, S, Ip).permute(0, 3, 1, 2)[:, :I]
+                else:
+                    store = self.params[o:o + n].view(p.shape)
+                    store.copy_(src)
+                    self.packed[name] = store
+                    self.packed_fresh[name] = self.fresh[o:o + n].view(p.shape)
+                    pv, gv = store, self.grads[o:o + n].view(p.shape)
+                p.data = pv
+                self.pviews[name], self.gviews[name] = pv, gv
+        # running statistics: plain contiguous float buffers on the device
+        for name, b in module.named_buffers():
+            if b.dtype.is_floating_point and (b.device != device or b.dtype != torch.float32
+                                              or not b.is_contiguous()):
+                b.data = b.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.ptr_check = [(p, p.data_ptr()) for _, p, _, _ in slots[:1] + slots[-1:]]
+
+    def valid(self):
+        return all(p.data_ptr() == ptr and p.device == self.device for p, ptr in self.ptr_check)
+
+    def publish_grads(self, params):
+        """Make p.grad reflect this backward (torch semantics: accumulate unless p.grad is None)."""
+        state = [p.grad is None for p in params]
+        if all(state):
+            self.grads.copy_(self.fresh)
+            for (name, p, _, _) in self.slots:
+                p.grad = self.gviews[name]
+        elif not any(state) and all(p.grad.data_ptr() == self.gviews[name].data_ptr()
+                                    for (name, p, _, _) in self.slots):
+            _lib.call('dsnt_axpy', _lib.ptr(self.fresh), _lib.ptr(self.grads), 1.0, 1, self.numel)
+        else:
+            for (name, p, o, n) in self.slots:
+                fresh = self.fresh[o:o + n]
+                if p.dim() == 4:
+                    O, I, R, S = p.shape
+                    fresh = fresh.view(O, R, S, _ceil4(I)).permute(0, 3, 1, 2)[:, :I]
+                else:
+                    fresh = fresh.view(p.shape)
+                if p.grad is None:
+                    self.gviews[name].copy_(fresh)
+                    p.grad = self.gviews[name]
+                else:
+                    p.grad.add_(fresh)
+
+
+# ====================================================================== traced programs
+class Program:
+    """Forward/backward launch lists for one (input shape, training mode)."""
+
+    def __init__(self, root, arena, in_shape, training, input_grad):
+        self.training = training
+        self.token = 0
+        dev = arena.device
+        tape = Tape(dev, training)
+        self.tape = tape
+        names = {id(m): n for n, m in root.named_modules()}
+
+        def key(m, leaf):
+            prefix = names[id(m)]
+            return (prefix + '.' if prefix else '') + leaf
+
+        class P:   # parameter lookup handed to the trace functions
+            @staticmethod
+            def conv(m):
+                w = arena.packed[key(m, 'weight')]
+                gw = arena.packed_fresh[key(m, 'weight')]
+                b = arena.packed[key(m, 'bias')] if m.bias is not None else None
+                gb = arena.packed_fresh[key(m, 'bias')] if m.bias is not None else None
+                return ConvParams(w, b, gw, gb, m.stride[0], m.padding[0], m.dilation[0])
+
+            _bn = {}
+
+            @staticmethod
+            def bn(m):
+                if id(m) not in P._bn:
+                    P._bn[id(m)] = BnParams(arena.packed[key(m, 'weight')], arena.packed[key(m, 'bias')],
+                                            arena.packed_fresh[key(m, 'weight')],
+                                            arena.packed_fresh[key(m, 'bias')],
+                                            m.running_mean, m.running_var,
+                                            0.1 if m.momentum is None else m.momentum, m.eps)
+                return P._bn[id(m)]
+        P._bn = {}
+
+        N, Cc, H, W = in_shape
+        self.in_nchw = tape.empty(N, Cc, H, W)
+        x = tape.from_planar(self.in_nchw, _ceil4(Cc), 'input')
+        self.in_act = x
+        outs = root.trace(tape, x, P)
+        single = not isinstance(outs, (list, tuple))
+        self.single = single
+        outs = [outs] if single else list(outs)
+        self.out_channels = root.out_channels
+        self.outs, self.gins = [], []
+        for o in outs:
+            t, g = tape.to_planar(o, self.out_channels)
+            self.outs.append(t)
+            self.gins.append(g)
+        self.input_grad = input_grad and training
+        if training:
+            tape.finish()
+            if self.input_grad:
+                self.gx = tape.empty(N, Cc, H, W)
+                if x.grad is None:
+                    raise RuntimeError('input gradient requested but nothing produced it')
+                tape.b('dsnt_nhwc_to_nchw', x.grad, self.gx, N, Cc, H * W, x.C)
+        self.n_fwd, self.n_bwd = len(tape.fwd), len(tape.bwd)
+
+
+class _Run(Function):
+    @staticmethod
+    def forward(ctx, runner, prog, x, *params):
+        prog.in_nchw.copy_(x)
+        prog.token += 1
+        Tape.run(prog.tape.fwd)
+        ctx.runner, ctx.prog, ctx.token, ctx.nparams = runner, prog, prog.token, len(params)
+        return tuple(o.clone() for o in prog.outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        prog, runner = ctx.prog, ctx.runner
+        if not prog.training:
+            raise RuntimeError('dsnt: backward through an eval-mode forward is not supported; '
+                               'call model.train() before the forward pass')
+        if prog.token != ctx.token:
+            raise RuntimeError('dsnt: the saved activations of this forward were overwritten by a '
+                               'later forward of the same shape; run backward before forwarding again')
+        for g, gin in zip(gouts, prog.gins):
+            if g is None:
+                gin.zero_()
+            else:
+                gin.copy_(g)
+        Tape.run(prog.tape.bwd)
+        runner.arena.publish_grads(runner.params)
+        runner.after_backward()
+        gx = prog.gx.clone() if prog.input_grad else None
+        return (None, None, gx) + (None,) * ctx.nparams
+
+
+class Runner:
+    """Owns the arena and the traced programs of one root module."""
+
+    def __init__(self, root):
+        self.root = root
+        self.arena = None
+        self.programs = {}
+        self.params = []
+        self.grad_hooks = []
+
+    def ensure(self, device):
+        if self.arena is None or not self.arena.valid() or self.arena.device != device:
+            self.arena = Arena(self.root, device)
+            self.programs = {}
+            self.params = [p for _, p, _, _ in self.arena.slots]
+
+    def _bn_signature(self):
+        # momentum / eps are baked into the launch lists; re-trace if a caller changes them
+        return tuple((m.momentum, m.eps) for m in self.root.modules()
+                     if isinstance(m, nn.BatchNorm2d))[:4]
+
+    def after_backward(self):
+        for h in self.grad_hooks:
+            h(self.arena)
+
+    def __call__(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('dsnt: input is on %s; the backbone runs on the HIP device only '
+                               '(no CPU fallback) — move the model and input with .cuda()' % x.device)
+        if x.dtype != torch.float32:
+            raise RuntimeError('dsnt: expected a float32 input, got %s' % x.dtype)
+        self.ensure(x.device)
+        training = self.root.training
+        grad_mode = torch.is_grad_enabled()
+        key = (tuple(x.shape), training, bool(x.requires_grad), self._bn_signature())
+        prog = self.programs.get(key)
+        if prog is None:
+            if x.requires_grad and not self.root.supports_input_grad:
+                raise NotImplementedError('dsnt: gradient with respect to the input image is not '
+                                          'on the hot path (stride-2 stem data-gradient)')
+            prog = Program(self.root, self.arena, tuple(x.shape), training, bool(x.requires_grad))
+            self.programs[key] = prog
+        if training and grad_mode:
+            outs = _Run.apply(self, prog, x, *self.params)
+        else:
+            with torch.no_grad():
+                prog.in_nchw.copy_(x)
+                prog.token += 1
+                Tape.run(prog.tape.fwd)
+                outs = tuple(o.clone() for o in prog.outs)
+        return outs[0] if prog.single else list(outs)
+
+
+class TapeModule(nn.Module):
+    """Mixin: `forward` = traced launch lists; `.cuda()`/`.to()` invalidate the arena."""
+    supports_input_grad = True
+
+    def _runner(self):
+        r = self.__dict__.get('_tape_runner')
+        if r is None:
+            r = Runner(self)
+            self.__dict__['_tape_runner'] = r
+        return r
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        r = self.__dict__.get('_tape_runner')
+        if r is not None:
+            r.arena = None
+            r.programs = {}
+        return out
+
+    def forward(self, x):
+        return self._runner()(x)
+
+    @property
+    def arena(self):
+        return self._runner().arena
+
+
+# ====================================================================== the modules
+class Bottleneck(TapeModule):
+    """Pre-activation residual unit (reference hourglass.py:14-50)."""
+    expansion = EXPANSION
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(inplanes)
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=True)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=True)
+        self.bn3 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 2, kernel_size=1, bias=True)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self.out_channels = planes * 2
+
+    def trace(self, t, x, P):
+        skip = x
+        if self.downsample is not None:
+            skip = t.conv(x, P.conv(self.downsample[0]), name='ds')
+        y = t.conv(t.norm(x, P.bn(self.bn1)), P.conv(self.conv1), want_stats=True, name='c1')
+        y = t.conv(t.norm(y, P.bn(self.bn2)), P.conv(self.conv2), want_stats=True, name='c2')
+        return t.conv(t.norm(y, P.bn(self.bn3)), P.conv(self.conv3), res1=skip, want_stats=True,
+                      name='c3')
+
+
+def _trace_seq(seq, t, x, P):
+    for m in seq:
+        x = m.trace(t, x, P)
+    return x
+
+
+class Hourglass(TapeModule):
+    """Depth-`depth` recursive hourglass (reference hourglass.py:53-93)."""
+
+    def __init__(self, block, num_blocks, planes, depth):
+        super().__init__()
+        self.depth = depth
+        self.block = block
+        self.upsample = nn.Upsample(scale_factor=2, mode='nearest')
+        levels = []
+        for i in range(depth):
+            groups = [nn.Sequential(*[block(planes * block.expansion, planes) for _ in range(num_blocks)])
+                      for _ in range(4 if i == 0 else 3)]
+            levels.append(nn.ModuleList(groups))
+        self.hg = nn.ModuleList(levels)
+        self.out_channels = planes * block.expansion
+
+    def _level(self, n, t, x, P):
+        g = self.hg[n - 1]
+        up1 = _trace_seq(g[0], t, x, P)
+        low = _trace_seq(g[1], t, t.maxpool2(x), P)
+        low = self._level(n - 1, t, low, P) if n > 1 else _trace_seq(g[3], t, low, P)
+        low = _trace_seq(g[2], t, low, P)
+        return t.upsample2_add(up1, low)
+
+    def trace(self, t, x, P):
+        return self._level(self.depth, t, x, P)
+
+
+class HourglassNet(TapeModule):
+    """Hourglass model from Newell et al. ECCV 2016 (reference hourglass.py:96-177)."""
+    supports_input_grad = False
+
+    def __init__(self, block, num_stacks=2, num_blocks=4, num_classes=16):
+        super().__init__()
+        self.inplanes = 64
+        self.num_feats = 128
+        self.num_stacks = num_stacks
+        self.num_classes = num_classes
+        self.conv1 = nn.Conv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=True)
+        self.bn1 = nn.BatchNorm2d(self.inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.layer1 = self._make_residual(block, self.inplanes, 1)
+        self.layer2 = self._make_residual(block, self.inplanes, 1)
+        self.layer3 = self._make_residual(block, self.num_feats, 1)
+        self.maxpool = nn.MaxPool2d(2, stride=2)
+        ch = self.num_feats * block.expansion
+        hg, res, fc, score, fc_, score_ = [], [], [], [], [], []
+        for i in range(num_stacks):
+            hg.append(Hourglass(block, num_blocks, self.num_feats, 4))
+            res.append(self._make_residual(block, self.num_feats, num_blocks))
+            fc.append(nn.Sequential(nn.Conv2d(ch, ch, kernel_size=1, bias=True),
+                                    nn.BatchNorm2d(ch), self.relu))
+            score.append(nn.Conv2d(ch, num_classes, kernel_size=1, bias=True))
+            if i < num_stacks - 1:
+                fc_.append(nn.Conv2d(ch, ch, kernel_size=1, bias=True))
+                score_.append(nn.Conv2d(num_classes, ch, kernel_size=1, bias=True))
+        self.hg = nn.ModuleList(hg)
+        self.res = nn.ModuleList(res)
+        self.fc = nn.ModuleList(fc)
+        self.score = nn.ModuleList(score)
+        self.fc_ = nn.ModuleList(fc_)
+        self.score_ = nn.ModuleList(score_)
+        self.out_channels = num_classes
+
+    def _make_residual(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion,
+                                                 kernel_size=1, stride=stride, bias=True))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def trace(self, t, x, P):
+        if x.H % 64 != 0 or x.W % 64 != 0:
+            raise RuntimeError('dsnt: hourglass input must be a multiple of 64 pixels '
+                               '(stem /4, four 2x2 poolings), got %dx%d' % (x.H, x.W))
+        x = t.conv(x, P.conv(self.conv1), want_stats=True, need_input_grad=False, name='stem')
+        x = t.bn_act(x, P.bn(self.bn1), relu=True, name='stem_act')
+        x = _trace_seq(self.layer1, t, x, P)
+        x = t.maxpool2(x)
+        x = _trace_seq(self.layer3, t, _trace_seq(self.layer2, t, x, P), P)
+        outs = []
+        for i in range(self.num_stacks):
+            y = self.hg[i].trace(t, x, P)
+            y = _trace_seq(self.res[i], t, y, P)
+            y = t.conv(y, P.conv(self.fc[i][0]), want_stats=True, name='fc')
+            yn = t.norm(y, P.bn(self.fc[i][1]), relu=True)        # one BN, two consumers
+            score = t.conv(yn, P.conv(self.score[i]), name='score')
+            if i < self.num_stacks - 1:
+                f = t.conv(yn, P.conv(self.fc_[i]), name='fc_')
+                x = t.conv(score, P.conv(self.score_[i]), res1=x, res2=f, want_stats=True, name='score_')
+            outs.append(score)
+        return outs

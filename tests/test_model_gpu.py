@@ -1,0 +1,257 @@
+"""HIP backbone + head vs the oracle and the golden vectors (made from the reference).
+
+Bars (BASELINE.json north_star): joint coordinates within 1e-4 of the CPU path on identical
+inputs; losses to 1e-4 relative; every parameter gradient to a few 1e-3 of its own max-norm
+scale (fp32 accumulation-order differences through ~100 layers with batch-norm).
+"""
+import numpy as np
+import pytest
+import torch
+
+from dsnt import synthetic
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rel_l2(got, want, floor=0.0):
+    return (got.double() - want.double()).norm().item() / max(want.double().norm().item(), floor, 1e-30)
+
+
+def _grads_close(m, o, tol, what):
+    """Every parameter gradient: relative L2 error <= tol (floor = 1e-3 of the largest gradient
+    norm: conv biases that feed a batch-norm have an exactly-zero true gradient, only noise)."""
+    floor = 1e-3 * max(q.grad.double().norm().item() for q in o.parameters() if q.grad is not None)
+    worst = (0.0, None)
+    for (n, p), (_, q) in zip(m.named_parameters(), o.named_parameters()):
+        assert p.grad is not None and p.grad.shape == q.grad.shape, n
+        e = _rel_l2(p.grad.cpu(), q.grad, floor)
+        worst = max(worst, (e, n))
+        assert e <= tol, (what, n, e)
+    return worst
+
+
+class _NoRelu:
+    """Context: run BOTH implementations without ReLU.  Two fp32 implementations of the same
+    network can place a pre-activation that is within ~1e-7 of zero on opposite sides of the ReLU
+    kink; that flips one mask element and moves gradients by O(1e-2) at the tiny batch sizes the
+    CPU oracle can afford, although every kernel is exact.  The smooth network has no such kinks,
+    so there the gradients must agree tightly — this is the proof that the backward kernels,
+    accumulation and buffer-donation logic are right.  The ReLU network is then checked with a
+    flip-tolerant bound."""
+
+    def __enter__(self):
+        import os
+        import torch.nn.functional as F
+        from dsnt_oracle import hourglass as ohg
+        os.environ['DSNT_DEBUG_NO_RELU'] = '1'
+        self.ohg, self.saved = ohg, ohg.F
+
+        class Shim:
+            relu = staticmethod(lambda t: t)
+            max_pool2d = staticmethod(F.max_pool2d)
+            interpolate = staticmethod(F.interpolate)
+        ohg.F = Shim
+        return self
+
+    def __exit__(self, *a):
+        import os
+        os.environ.pop('DSNT_DEBUG_NO_RELU', None)
+        self.ohg.F = self.saved
+
+    @staticmethod
+    def strip(oracle_model):
+        import torch.nn as nn
+        for seq in oracle_model.hg.fc:
+            seq[2] = nn.Identity()
+
+
+@pytest.mark.parametrize('kind', ['bottleneck', 'hourglass'])
+@pytest.mark.parametrize('smooth', [True, False])
+def test_blocks_vs_golden_and_oracle(kind, smooth):
+    from dsnt import hourglass as dhg
+    from dsnt_oracle import hourglass as ohg
+    import contextlib
+    g = gu.load(kind)
+    hw = 16 if kind == 'bottleneck' else 32
+    mk = (lambda mod: mod.Bottleneck(256, 128)) if kind == 'bottleneck' else \
+        (lambda mod: mod.Hourglass(mod.Bottleneck, 1, 128, 4))
+    with (_NoRelu() if smooth else contextlib.nullcontext()):
+        m, o = mk(dhg), mk(ohg)
+        synthetic.fill_state_dict(m, seed=5)
+        synthetic.fill_state_dict(o, seed=5)
+        assert list(m.state_dict().keys()) == list(o.state_dict().keys())
+        m.cuda().train()
+        o.train()
+        x = synthetic.tensor(kind + '.x', (2, 256, hw, hw), seed=5)
+        gy = synthetic.tensor(kind + '.gy', (2, 256, hw, hw), seed=5)
+        xd = x.to(DEV).requires_grad_()
+        y = m(xd)
+        y.backward(gy.to(DEV))
+        xo = x.clone().requires_grad_()
+        yo = o(xo)
+        yo.backward(gy)
+    assert _rel_l2(y.detach().cpu(), yo.detach()) <= 1e-5
+    tol = 2e-4 if smooth else 3e-2
+    assert _rel_l2(xd.grad.cpu(), xo.grad) <= tol
+    _grads_close(m, o, tol, kind)
+    if not smooth:      # golden vectors come from the (ReLU) reference
+        gu.check_summary(g, 'y', y, 2e-5)
+        for n, p in m.named_parameters():
+            want = float(g['gradnorm.' + n])
+            assert abs(p.grad.double().norm().item() - want) <= 3e-2 * max(1.0, want), n
+    for (n, b), (_, c) in zip(m.named_buffers(), o.named_buffers()):
+        if 'running' in n:
+            s_ = max(1.0, c.abs().max().item())
+            assert (b.cpu() - c).abs().max().item() <= 1e-5 * s_, n
+            if not smooth:
+                assert np.abs(b.cpu().double().numpy() - g['buf.' + n]).max() <= 1e-5 * s_, n
+
+
+@pytest.mark.parametrize('base,size,reg,tag', [('hg1', 128, 'none', 'hg1_128'),
+                                               ('hg2', 128, 'js', 'hg2_128'),
+                                               ('hg2', 256, 'js', 'hg2_256')])
+def test_end_to_end_vs_golden(base, size, reg, tag):
+    """Golden vectors made from the reference: coords (bar 1e-4), loss, heat-maps, running
+    statistics, eval-mode coords; gradient norms flip-tolerantly (see _NoRelu)."""
+    from dsnt.model import build_mpii_pose_model
+    g = gu.load(tag)
+    m = build_mpii_pose_model(base=base, output_strat='dsnt', reg=reg)
+    synthetic.fill_state_dict(m, seed=0)
+    m.cuda().train()
+    x, target, mask = synthetic.batch(2, size=size, seed=1, mask_p=0.9)
+    x, target, mask = x.to(DEV), target.to(DEV), mask.to(DEV)
+    outs = m(x)
+    loss = m.forward_loss(outs, target, mask)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-4 * max(1.0, abs(float(g['loss'])))
+    for i, o in enumerate(outs):
+        err = np.abs(o.detach().cpu().numpy() - g['coords%d' % i]).max()
+        assert err <= 1e-4, ('coords', i, err)          # the north-star bar
+        gu.check_summary(g, 'heatmaps%d' % i, m.heatmaps_array[i], 1e-4)
+    coords = m.compute_coords(outs)
+    assert coords.device.type == 'cpu' and coords.dtype == torch.float32 and coords.shape == (2, 16, 2)
+    assert m.heatmaps is m.heatmaps_array[0] and m.heatmaps.shape == (2, 16, size // 4, size // 4)
+    norms = {k[9:]: float(g[k]) for k in g.files if k.startswith('gradnorm.')}
+    fl = 1e-3 * max(norms.values())
+    bad = [(n, p.grad.double().norm().item(), norms[n]) for n, p in m.named_parameters()
+           if abs(p.grad.double().norm().item() - norms[n]) > 0.15 * max(fl, norms[n])]
+    assert not bad, bad[:5]
+    tot_got = np.sqrt(sum(p.grad.double().norm().item() ** 2 for p in m.parameters()))
+    tot_want = np.sqrt(sum(v * v for v in norms.values()))
+    assert abs(tot_got - tot_want) <= 2e-2 * tot_want
+    for n, b in m.named_buffers():
+        if 'running' in n:
+            want = float(g['bufsum.' + n])
+            assert abs(b.double().sum().item() - want) <= 1e-4 * max(1.0, abs(want)), n
+    for mod in m.modules():                               # see tests/golden/make_golden.py
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 1.0
+    with torch.no_grad():
+        m(x)
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)[-1].cpu().numpy()
+    assert np.abs(ev - g['eval_coords']).max() <= 1e-4
+
+
+@pytest.mark.parametrize('smooth', [True, False])
+def test_hg2_every_gradient_vs_oracle(smooth):
+    """All 396 parameter gradients of hg2 + DSNT + JS against the CPU oracle (batch 4, 128 px)."""
+    import contextlib
+    from dsnt.model import build_mpii_pose_model
+    from dsnt_oracle import model as omodel
+    with (_NoRelu() if smooth else contextlib.nullcontext()):
+        m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+        o = omodel.build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+        if smooth:
+            _NoRelu.strip(o)
+        synthetic.fill_state_dict(m, seed=3)
+        synthetic.fill_state_dict(o, seed=3)
+        m.cuda().train()
+        o.train()
+        x, target, mask = synthetic.batch(4, size=128, seed=2, mask_p=0.8)
+        outs = m(x.to(DEV))
+        loss = m.forward_loss(outs, target.to(DEV), mask.to(DEV))
+        loss.backward()
+        outs_o = o(x)
+        loss_o = o.forward_loss(outs_o, target, mask)
+        loss_o.backward()
+    for a, b in zip(outs, outs_o):
+        assert (a.detach().cpu() - b.detach()).abs().max().item() <= 1e-4
+    assert abs(loss.item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
+    pm, po = dict(m.named_parameters()), dict(o.named_parameters())
+    assert list(pm) == list(po) and len(pm) == 396
+    worst = _grads_close(m, o, 1e-3 if smooth else 0.2, 'hg2')
+    flat_m = torch.cat([p.grad.cpu().reshape(-1) for p in pm.values()]).double()
+    flat_o = torch.cat([p.grad.reshape(-1) for p in po.values()]).double()
+    cos = (flat_m @ flat_o / (flat_m.norm() * flat_o.norm())).item()
+    assert cos >= (1 - 1e-7 if smooth else 0.999), (cos, worst)
+    if smooth:
+        return
+    # mask_var=None path (tests/test_model.py:56) and torch's gradient accumulation semantics
+    m.zero_grad()
+    l2 = m.forward_loss(m(x.to(DEV)), target.to(DEV), None)
+    l2.backward()
+    g1 = {n: p.grad.clone() for n, p in pm.items()}
+    l3 = m.forward_loss(m(x.to(DEV)), target.to(DEV), None)
+    l3.backward()                                        # no zero_grad: torch accumulates
+    for n, p in pm.items():
+        assert _rel_l2(p.grad, 2 * g1[n], 1e-3 * g1[n].norm().item() + 1e-12) <= 1e-5, n
+
+
+def test_optimizer_kernels():
+    """Flat RMSprop / SGD-momentum kernels vs torch.optim on identical gradients (train.py:314-326)."""
+    from dsnt._lib import ptr, call
+    n = 100003
+    p0 = synthetic.tensor('op', (n,), seed=8)
+    grads = [synthetic.tensor('og%d' % i, (n,), seed=8) * (0.1 + i) for i in range(3)]
+    for kind in ('rmsprop', 'sgd'):
+        pt = p0.clone().requires_grad_()
+        opt = torch.optim.RMSprop([pt], lr=2.5e-4) if kind == 'rmsprop' else \
+            torch.optim.SGD([pt], lr=0.2, momentum=0.9)
+        pd = p0.to(DEV).clone()
+        state = torch.zeros(n, device=DEV)
+        for i, g_ in enumerate(grads):
+            pt.grad = g_.clone()
+            opt.step()
+            gd = g_.to(DEV)
+            if kind == 'rmsprop':
+                call('dsnt_rmsprop_step', ptr(pd), ptr(gd), ptr(state), n, 2.5e-4, 0.99, 1e-8, 0.0, 1.0)
+            else:
+                call('dsnt_sgd_step', ptr(pd), ptr(gd), ptr(state), n, 0.2, 0.9, 0.0, 1.0, 1 if i == 0 else 0)
+        assert (pd.cpu() - pt.detach()).abs().max().item() <= 2e-6, kind
+
+
+def test_surface_and_errors():
+    from dsnt.model import build_mpii_pose_model
+    m = build_mpii_pose_model(base='hg', dilate=2, truncate=1)       # resnet kwargs filtered out
+    assert m.output_strat == 'gauss' and m.hg.num_stacks == 2 and m.heatmap_size == 64
+    assert m.image_specs.size == 256 and m.image_specs.subtract_mean
+    assert build_mpii_pose_model(base='hg8', output_strat='dsnt').hg.num_stacks == 8
+    for bad in ('vgg', 'hgx'):
+        with pytest.raises(Exception, match='unsupported base model type'):
+            build_mpii_pose_model(base=bad)
+    m = build_mpii_pose_model(base='hg1', output_strat='dsnt')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.zeros(2, 3, 64, 64))
+    m.cuda()
+    with pytest.raises(RuntimeError, match='multiple of 64'):
+        m(torch.zeros(2, 3, 96, 96, device=DEV))
+    # inference.py:33-48: forward_part1 -> last stack -> forward_part2 on a bare 4-D tensor
+    m.eval()
+    with torch.no_grad():
+        hm = m.forward_part1(torch.rand(2, 3, 64, 64, device=DEV))
+        assert isinstance(hm, list) and hm[-1].shape == (2, 16, 16, 16)
+        out = m.forward_part2(hm[-1][:1])
+        assert len(out) == 1 and out[0].shape == (1, 16, 2)
+    sd = m.state_dict()
+    assert sd['hg.conv1.weight'].shape == (64, 3, 7, 7)
+    assert sd['hg.layer1.0.conv2.weight'].shape == (64, 64, 3, 3)
+    m2 = build_mpii_pose_model(base='hg1', output_strat='dsnt')
+    m2.load_state_dict(sd)
+    m2.cuda().eval()
+    x = torch.rand(2, 3, 64, 64, device=DEV)
+    with torch.no_grad():
+        assert torch.equal(m(x)[0], m2(x)[0])
