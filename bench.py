@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Benchmark of the dsnt-pose2d hot path on MI355X: images/sec of one TRAIN STEP.
+
+A step is the reference's `bin/train.py:355-384` minus data loading, telemetry and PCKh:
+forward -> forward_loss -> zero_grad -> backward (-> gradient all-reduce) -> optimiser step,
+on synthetic 256x256x3 crops already resident in HBM, 16 joints, 64x64 heat-maps.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg2_js|hg1|hg8_js] [--batch B]
+
+For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.  Scaling is weak: the per-GPU batch is
+fixed (32; hg8: 16) as N grows.  Besides the whole-job throughput the line carries
+  roofline     — the dominant kernel (3x3 128->128 implicit-GEMM conv at 64x64, the shape that
+                 holds ~half of the backbone FLOPs) timed live with HIP events on its stream:
+                 algorithmic FLOPs / launch time vs the 157.3 TFLOP/s fp32-MFMA peak;
+  cpu_baseline — the CPU oracle (plain PyTorch ops, proven equal to the reference) timed on this
+                 node's host cores on a bounded sample of the same workload (rank 0, N = 1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, 'dsnt-pose2d_amd')]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (base, reg, per-GPU batch, train GFLOP per image [BASELINE.md])
+    'hg2_js': ('hg2', 'js', 32, 53.6),
+    'hg1': ('hg1', 'none', 32, 34.5),
+    'hg8_js': ('hg8', 'js', 16, 168.3),
+}
+PEAK_F32_MFMA = 157.3  # TFLOP/s, MI355X_MICROARCH.md
+
+
+def dominant_kernel_roofline(batch, iters=20):
+    """3x3 128->128 conv with fused BN+ReLU prologue and stats epilogue at [B,64,64,128]."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, ConvGeom
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = ConvGeom(batch, 64, 64, 128, 64, 64, 128, 3, 3, 1, 1, 1)
+    x = torch.randn(batch, 64, 64, 128, device=dev)
+    w = torch.randn(128, 3, 3, 128, device=dev) * 0.03
+    b = torch.zeros(128, device=dev)
+    sc = torch.rand(128, device=dev) + 0.5
+    sh = torch.randn(128, device=dev) * 0.1
+    y = torch.empty(batch, 64, 64, 128, device=dev)
+    M = batch * 64 * 64
+    stats = torch.empty((M + 127) // 128, 2, 128, device=dev)
+    fn = _lib.fn('dsnt_conv_fwd')
+    args = (ptr(x), ptr(w), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g))
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        assert fn(*args, stream) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn(*args, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * (3 * 3 * 128) * 128
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {
+        'bound': 'mfma', 'kernel': 'conv_fwd_kernel<2,2,2,2,true> 3x3 128->128 @64x64 B=%d' % batch,
+        'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
+        'frac': round(achieved / PEAK_F32_MFMA, 4), 'traffic': None,
+        'flops_per_launch': flops, 'us_per_launch': round(ms * 1e3, 1),
+    }
+
+
+def cpu_baseline(base, reg, batch=8, steps=2):
+    """The CPU oracle on the same workload at a bounded batch (images/sec on the host cores)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    from dsnt_oracle import model as omodel
+    from dsnt import synthetic
+    cores = torch.get_num_threads()
+    m = omodel.build_mpii_pose_model(base=base, output_strat='dsnt', reg=reg)
+    synthetic.fill_state_dict(m, seed=0)
+    m.train()
+    opt = torch.optim.RMSprop(m.parameters(), lr=2.5e-4)
+    x, t, k = synthetic.batch(batch, size=256, seed=1)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        out = m(x)
+        loss = m.forward_loss(out, t, k)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    best = sorted(times[1:])[len(times[1:]) // 2]
+    return {'value': round(batch / best, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%s+dsnt reg=%s, batch %d, 256x256, %d timed steps after 1 warm-up (median), '
+                      'torch %s CPU ops' % (base, reg, batch, steps, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='hg2_js', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', type=int, default=int(os.environ.get('DSNT_BENCH_GRAPH', '0')))
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                             '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...'
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from dsnt.model import build_mpii_pose_model
+    from dsnt import synthetic, optim, parallel
+
+    base, reg, batch, gflop = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    model = build_mpii_pose_model(base=base, output_strat='dsnt', reg=reg)
+    synthetic.fill_state_dict(model, seed=0)          # identical weights on every rank
+    model.cuda().train()
+    x, target, mask = synthetic.batch(batch, size=256, seed=1 + rank, mask_p=1.0)
+    x, target, mask = x.to(dev), target.to(dev), mask.to(dev)
+
+    model.hg._runner().ensure(dev)
+    opt = optim.RMSprop(model, lr=2.5e-4)             # train.py:88-99 defaults for rmsprop
+    if world > 1:
+        parallel.DataParallel(model, opt)
+
+    def step():
+        out = model(x)
+        loss = model.forward_loss(out, target, mask)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss.item())
+
+    out = None
+    if rank == 0:
+        ips = world * batch * args.steps / elapsed
+        prog = [p for p in model.hg._runner().programs.values() if p.training][0]
+        out = {
+            'metric': 'images/sec (train step, 256x256, 16 joints)',
+            'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s + DSNT%s, 256x256 -> 64x64x16, batch %d per GPU, RMSprop lr 2.5e-4, '
+                                   'train step fwd+loss+bwd%s+optim'
+                                   % (base, '' if reg == 'none' else ' + %s reg' % reg.upper(), batch,
+                                      '+RCCL all-reduce' if world > 1 else ''),
+                       'global_batch': world * batch, 'parallelism': 'dp%d' % world,
+                       'launches_fwd': prog.n_fwd, 'launches_bwd': prog.n_bwd},
+            'final_loss': final_loss,
+            'step_mfma_frac': round(ips / world * gflop * 1e9 / (PEAK_F32_MFMA * 1e12), 4),
+        }
+        out['roofline'] = dominant_kernel_roofline(batch)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(base, reg)
+            out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -139,10 +139,20 @@ class Tape:
             fn()
         self._bwd_emitters = []
 
+    def mark_bucket(self, k):
+        """Forward position where parameter bucket k starts being used: in the (reversed) backward
+        list the marker lands right after the last launch that writes bucket k's gradients."""
+        if self.training:
+            self.on_backward(lambda: self.bwd.append((None, k, 'bucket')))
+
     @staticmethod
-    def run(lst):
+    def run(lst, bucket_hook=None):
         stream = torch.cuda.current_stream().cuda_stream
         for fn, args, name in lst:
+            if fn is None:
+                if bucket_hook is not None:
+                    bucket_hook(args)
+                continue
             rc = fn(*args, stream)
             if rc != 0:
                 raise RuntimeError('%s failed (%d): %s' % (

@@ -35,16 +35,32 @@ class Arena:
 
     def __init__(self, module, device):
         self.device = device
+        self.publish_scale = 1.0    # 1/world_size under data parallelism
         slots, off = [], 0
-        for name, p in module.named_parameters():
+        named = list(module.named_parameters())
+        bucket_of = getattr(module, 'param_bucket', lambda name: 0)
+        order = sorted(range(len(named)), key=lambda i: (bucket_of(named[i][0]), i))
+        nb = 1 + max([bucket_of(n) for n, _ in named] + [0])
+        starts = [None] * nb
+        for i in order:
+            name, p = named[i]
             if p.dim() == 4:
                 O, I, R, S = p.shape
                 n = O * R * S * _ceil4(I)
             else:
                 n = p.numel()
+            b = bucket_of(name)
+            if starts[b] is None:
+                starts[b] = off
             slots.append((name, p, off, n))
             off += _ceil4(n)
         self.numel = off
+        # contiguous element range of every gradient bucket (for the overlapped all-reduce)
+        self.bucket_bounds = []
+        for b in range(nb):
+            s_ = starts[b] if starts[b] is not None else off
+            nxt = [x for x in starts[b + 1:] if x is not None]
+            self.bucket_bounds.append((s_, nxt[0] if nxt else off))
         self.params = torch.zeros(off, device=device, dtype=torch.float32)
         self.grads = torch.zeros(off, device=device, dtype=torch.float32)   # what p.grad views
         self.fresh = torch.zeros(off, device=device, dtype=torch.float32)   # what backward writes
@@ -83,16 +99,17 @@ class Arena:
     def publish_grads(self, params):
         """Make p.grad reflect this backward (torch semantics: accumulate unless p.grad is None)."""
         state = [p.grad is None for p in params]
+        a = float(self.publish_scale)
         if all(state):
-            self.grads.copy_(self.fresh)
+            _lib.call('dsnt_axpy', _lib.ptr(self.fresh), _lib.ptr(self.grads), a, 0, self.numel)
             for (name, p, _, _) in self.slots:
                 p.grad = self.gviews[name]
         elif not any(state) and all(p.grad.data_ptr() == self.gviews[name].data_ptr()
                                     for (name, p, _, _) in self.slots):
-            _lib.call('dsnt_axpy', _lib.ptr(self.fresh), _lib.ptr(self.grads), 1.0, 1, self.numel)
+            _lib.call('dsnt_axpy', _lib.ptr(self.fresh), _lib.ptr(self.grads), a, 1, self.numel)
         else:
             for (name, p, o, n) in self.slots:
-                fresh = self.fresh[o:o + n]
+                fresh = self.fresh[o:o + n] * a
                 if p.dim() == 4:
                     O, I, R, S = p.shape
                     fresh = fresh.view(O, R, S, _ceil4(I)).permute(0, 3, 1, 2)[:, :I]
@@ -191,9 +208,10 @@ class _Run(Function):
                 gin.zero_()
             else:
                 gin.copy_(g)
-        Tape.run(prog.tape.bwd)
+        Tape.run(prog.tape.bwd, runner.bucket_hook)
+        if runner.before_publish is not None:
+            runner.before_publish()
         runner.arena.publish_grads(runner.params)
-        runner.after_backward()
         gx = prog.gx.clone() if prog.input_grad else None
         return (None, None, gx) + (None,) * ctx.nparams
 
@@ -206,7 +224,8 @@ class Runner:
         self.arena = None
         self.programs = {}
         self.params = []
-        self.grad_hooks = []
+        self.bucket_hook = None       # called with k when gradient bucket k is complete (DP)
+        self.before_publish = None    # called after the backward list (DP: wait for all-reduce)
 
     def ensure(self, device):
         if self.arena is None or not self.arena.valid() or self.arena.device != device:
@@ -218,10 +237,6 @@ class Runner:
         # momentum / eps are baked into the launch lists; re-trace if a caller changes them
         return tuple((m.momentum, m.eps) for m in self.root.modules()
                      if isinstance(m, nn.BatchNorm2d))[:4]
-
-    def after_backward(self):
-        for h in self.grad_hooks:
-            h(self.arena)
 
     def __call__(self, x):
         if not x.is_cuda:
@@ -387,10 +402,18 @@ class HourglassNet(TapeModule):
             layers.append(block(self.inplanes, planes))
         return nn.Sequential(*layers)
 
+    def param_bucket(self, name):
+        """Gradient bucket of a parameter: 0 = stem, 1 + i = hourglass stack i."""
+        parts = name.split('.')
+        if parts[0] in ('hg', 'res', 'fc', 'score', 'fc_', 'score_'):
+            return 1 + int(parts[1])
+        return 0
+
     def trace(self, t, x, P):
         if x.H % 64 != 0 or x.W % 64 != 0:
             raise RuntimeError('dsnt: hourglass input must be a multiple of 64 pixels '
                                '(stem /4, four 2x2 poolings), got %dx%d' % (x.H, x.W))
+        t.mark_bucket(0)
         x = t.conv(x, P.conv(self.conv1), want_stats=True, need_input_grad=False, name='stem')
         x = t.bn_act(x, P.bn(self.bn1), relu=True, name='stem_act')
         x = _trace_seq(self.layer1, t, x, P)
@@ -398,6 +421,7 @@ class HourglassNet(TapeModule):
         x = _trace_seq(self.layer3, t, _trace_seq(self.layer2, t, x, P), P)
         outs = []
         for i in range(self.num_stacks):
+            t.mark_bucket(1 + i)
             y = self.hg[i].trace(t, x, P)
             y = _trace_seq(self.res[i], t, y, P)
             y = t.conv(y, P.conv(self.fc[i][0]), want_stats=True, name='fc')
