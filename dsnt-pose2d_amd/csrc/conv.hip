@@ -77,52 +77,61 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) bn_[j] = ntile * BN + lrow + 32 * j;
 
+    // Staging registers.  gload() only ISSUES the global loads (unconditional, clamped addresses,
+    // so they go out back-to-back and stay in flight during the MFMAs of the current step);
+    // the BN+ReLU / zero-padding transform happens in lstore(), after the MFMAs.
     float4 ra[APASS], rb[BPASS];
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned okmask = 0;
     auto gload = [&](int step) {
         const int k0 = step * BK + kc * 4;
         const bool vk = k0 < p.K;
         const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
         const int r = tap / p.S, s = tap - r * p.S;
         const int dh = r * p.dil, dw = s * p.dil;
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRO && vk) {
-            sc = *reinterpret_cast<const float4*>(p.in_scale + c);
-            sh = *reinterpret_cast<const float4*>(p.in_shift + c);
+        if (PRO) {
+            const int cc = vk ? c : 0;
+            sc = *reinterpret_cast<const float4*>(p.in_scale + cc);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + cc);
         }
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int ih = aih0[i] + dh, iw = aiw0[i] + dw;
             const bool ok = vk && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(p.x + (size_t)abase[i] +
-                                                     (size_t)(ih * p.W + iw) * p.Cin + c);
-                if (PRO) {
-                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                    v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-                    if (p.in_relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                }
-            }
-            ra[i] = v;
+            const size_t off = ok ? (size_t)abase[i] + (size_t)(ih * p.W + iw) * p.Cin + c : 0;
+            ra[i] = *reinterpret_cast<const float4*>(p.x + off);
+            okmask |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (vk && bn_[j] < p.Cout)
-                v = *reinterpret_cast<const float4*>(p.w + (size_t)bn_[j] * p.K + k0);
-            rb[j] = v;
+            const bool ok = vk && bn_[j] < p.Cout;
+            const size_t off = ok ? (size_t)bn_[j] * p.K + k0 : 0;
+            rb[j] = *reinterpret_cast<const float4*>(p.w + off);
+            okmask |= (ok ? 1u : 0u) << (8 + j);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < APASS; ++i)
-            *reinterpret_cast<float4*>(As + (buf * BM + lrow + 32 * i) * PITCH + kc * 4) = ra[i];
+        for (int i = 0; i < APASS; ++i) {
+            float4 v = ra[i];
+            if (PRO) {
+                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                if (p.in_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            if (!((okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(As + (buf * BM + lrow + 32 * i) * PITCH + kc * 4) = v;
+        }
 #pragma unroll
-        for (int j = 0; j < BPASS; ++j)
-            *reinterpret_cast<float4*>(Bs + (buf * BN + lrow + 32 * j) * PITCH + kc * 4) = rb[j];
+        for (int j = 0; j < BPASS; ++j) {
+            float4 v = rb[j];
+            if (!((okmask >> (8 + j)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Bs + (buf * BN + lrow + 32 * j) * PITCH + kc * 4) = v;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -161,59 +170,74 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
                 }
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the vmcnt wait + transform behind the MFMAs
         if (s + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float s1[TN], s2[TN];
+    // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) +
+    // 4*(lane>>5)) are transposed through LDS into row-major [BM][BN] so that bias / residual /
+    // store run as 16-byte row-contiguous accesses, all loads issued before the first use.
+    constexpr int CP = BN + 4;                 // C-tile pitch (floats)
+    float* Cs = smem;                          // [BM][CP]; the main loop ended with a barrier
 #pragma unroll
-    for (int b = 0; b < TN; ++b) { s1[b] = 0.f; s2[b] = 0.f; }
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int n = ntile * BN + (wn * TN + b) * 32 + lr;
-        const bool vn = n < p.Cout;
-        const float bias = (p.bias && vn) ? p.bias[n] : 0.f;
+        for (int b = 0; b < TN; ++b) {
+            const int col = (wn * TN + b) * 32 + lr;
+            const int row0 = (wm * TM + a) * 32 + 4 * lh;
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const int mrow0 = mtile * BM + (wm * TM + a) * 32 + 4 * lh;
+            for (int e = 0; e < 16; ++e)
+                Cs[(row0 + (e & 3) + 8 * (e >> 2)) * CP + col] = acc[a][b][e];
+        }
+    __syncthreads();
+    constexpr int CH = BN / 4;                 // float4 chunks per row
+    constexpr int RPP = 256 / CH;              // rows per pass
+    constexpr int NP = BM / RPP;               // passes
+    const int ch = tid % CH, r0 = tid / CH;
+    const int n0 = ntile * BN + ch * 4;
+    const bool vn = n0 < p.Cout;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && vn) bias4 = *reinterpret_cast<const float4*>(p.bias + n0);
+    float4 r1[NP], r2[NP];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mrow0 + (e & 3) + 8 * (e >> 2);
-                if (vn && m < p.M) {
-                    const size_t o = (size_t)m * p.Cout + n;
-                    float v = acc[a][b][e] + bias;
-                    if (p.res1) v += p.res1[o];
-                    if (p.res2) v += p.res2[o];
-                    p.y[o] = v;
-                    s1[b] += v;
-                    s2[b] = fmaf(v, v, s2[b]);
-                }
-            }
+    for (int j = 0; j < NP; ++j) {
+        const int m = mtile * BM + r0 + RPP * j;
+        const bool ok = vn && m < p.M;
+        const size_t o = ok ? (size_t)m * p.Cout + n0 : 0;
+        r1[j] = p.res1 ? *reinterpret_cast<const float4*>(p.res1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r2[j] = p.res2 ? *reinterpret_cast<const float4*>(p.res2 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int row = r0 + RPP * j;
+        const int m = mtile * BM + row;
+        if (vn && m < p.M) {
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + ch * 4);
+            v.x += bias4.x + r1[j].x + r2[j].x; v.y += bias4.y + r1[j].y + r2[j].y;
+            v.z += bias4.z + r1[j].z + r2[j].z; v.w += bias4.w + r1[j].w + r2[j].w;
+            *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n0) = v;
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+            s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
         }
     }
     if (p.stats) {
-        // lanes l and l+32 hold different rows of the same column; then combine the WM waves
-        float* red = smem;  // [WM][BN][2]; all LDS reads of the main loop are behind a barrier
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            s1[b] += __shfl_xor(s1[b], 32, 64);
-            s2[b] += __shfl_xor(s2[b], 32, 64);
-            if (lh == 0) {
-                const int col = (wn * TN + b) * 32 + lr;
-                red[(wm * BN + col) * 2 + 0] = s1[b];
-                red[(wm * BN + col) * 2 + 1] = s2[b];
-            }
-        }
+        __syncthreads();                       // every thread has read its part of Cs
+        float* red = smem;                     // [RPP][BN][2]
+        float* mine = red + ((size_t)r0 * BN + ch * 4) * 2;
+        mine[0] = s1.x; mine[1] = s2.x; mine[2] = s1.y; mine[3] = s2.y;
+        mine[4] = s1.z; mine[5] = s2.z; mine[6] = s1.w; mine[7] = s2.w;
         __syncthreads();
         if (tid < BN) {
             const int n = ntile * BN + tid;
             if (n < p.Cout) {
                 float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-                for (int w = 0; w < WM; ++w) {
-                    a0 += red[(w * BN + tid) * 2 + 0];
-                    a1 += red[(w * BN + tid) * 2 + 1];
+                for (int w = 0; w < RPP; ++w) {
+                    a0 += red[((size_t)w * BN + tid) * 2 + 0];
+                    a1 += red[((size_t)w * BN + tid) * 2 + 1];
                 }
                 p.stats[((size_t)mtile * 2 + 0) * p.Cout + n] = a0;
                 p.stats[((size_t)mtile * 2 + 1) * p.Cout + n] = a1;
@@ -267,6 +291,7 @@ static int check_geom(const dsnt_conv_geom* g, const char* who) {
                  g->S > 0 && g->stride > 0 && g->dil > 0 && g->pad >= 0, DSNT_ERR_SHAPE,
                  "%s: non-positive dimension", who);
     DSNT_REQUIRE(g->Cin % 4 == 0, DSNT_ERR_ALIGN, "%s: Cin=%d must be a multiple of 4", who, g->Cin);
+    DSNT_REQUIRE(g->Cout % 4 == 0, DSNT_ERR_ALIGN, "%s: Cout=%d must be a multiple of 4", who, g->Cout);
     const int ho = (g->H + 2 * g->pad - g->dil * (g->R - 1) - 1) / g->stride + 1;
     const int wo = (g->W + 2 * g->pad - g->dil * (g->S - 1) - 1) / g->stride + 1;
     DSNT_REQUIRE(ho == g->Ho && wo == g->Wo, DSNT_ERR_SHAPE,
@@ -381,41 +406,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     const int HoWo = p.Ho * p.Wo;
 
     float4 ra[4], rg[4];
+    unsigned okmask = 0;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // issue-only loads (clamped addresses); transform / masking in lstore after the MFMAs
     auto gload = [&](int step) {
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m_begin + step * 32 + lrow + 8 * i;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vg = va;
-            if (m < m_end) {
-                if (vk) {
-                    const int n = m / HoWo, rem = m - n * HoWo;
-                    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-                    const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
-                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-                        va = *reinterpret_cast<const float4*>(
-                            p.x + ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + c);
-                        if (PRO) {
-                            va.x = fmaf(va.x, sc.x, sh.x); va.y = fmaf(va.y, sc.y, sh.y);
-                            va.z = fmaf(va.z, sc.z, sh.z); va.w = fmaf(va.w, sc.w, sh.w);
-                            if (p.in_relu) {
-                                va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f);
-                                va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
-                            }
-                        }
-                    }
-                }
-                if (vn) vg = *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.Cout + n0);
-            }
-            ra[i] = va; rg[i] = vg;
+            const bool vm = m < m_end;
+            const int mc = vm ? m : 0;
+            const int n = mc / HoWo, rem = mc - n * HoWo;
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
+            const bool oka = vm && vk && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const size_t offa = oka ? ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + c : 0;
+            ra[i] = *reinterpret_cast<const float4*>(p.x + offa);
+            const bool okg = vm && vn;
+            const size_t offg = okg ? (size_t)m * p.Cout + n0 : 0;
+            rg[i] = *reinterpret_cast<const float4*>(p.dy + offg);
+            okmask |= ((oka ? 1u : 0u) << i) | ((okg ? 1u : 0u) << (8 + i));
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = ra[i];
-            *reinterpret_cast<float4*>(&Gs[buf][lrow + 8 * i][cc * 4]) = rg[i];
-            bsum.x += rg[i].x; bsum.y += rg[i].y; bsum.z += rg[i].z; bsum.w += rg[i].w;
+            float4 va = ra[i], vg = rg[i];
+            if (PRO) {
+                va.x = fmaf(va.x, sc.x, sh.x); va.y = fmaf(va.y, sc.y, sh.y);
+                va.z = fmaf(va.z, sc.z, sh.z); va.w = fmaf(va.w, sc.w, sh.w);
+                if (p.in_relu) {
+                    va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f);
+                    va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                }
+            }
+            if (!((okmask >> i) & 1u)) va = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!((okmask >> (8 + i)) & 1u)) vg = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = va;
+            *reinterpret_cast<float4*>(&Gs[buf][lrow + 8 * i][cc * 4]) = vg;
+            bsum.x += vg.x; bsum.y += vg.y; bsum.z += vg.z; bsum.w += vg.w;
         }
     };
 
@@ -449,6 +478,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (st + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
@@ -497,7 +527,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total4) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < splits; ++s) {
+        int s = 0;
+        for (; s + 8 <= splits; s += 8) {       // 8 independent 16-byte loads in flight
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = *reinterpret_cast<const float4*>(ws + (size_t)(s + u) * CK + (size_t)i * 4);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; s < splits; ++s) {
             const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)s * CK + (size_t)i * 4);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
@@ -518,7 +557,7 @@ static void wgrad_plan(const dsnt_conv_geom* g, int& ktiles, int& ntiles, int& s
     const int K = g->R * g->S * g->Cin;
     ktiles = (K + 127) / 128;
     ntiles = (g->Cout + 127) / 128;
-    long want = 1024 / (ktiles * ntiles);
+    long want = 512 / (ktiles * ntiles);      // ~2 workgroups per CU; more only inflates the slabs
     if (want < 1) want = 1;
     long max_splits = (M + 255) / 256;         // at least 8 steps of 32 rows per split
     if (max_splits < 1) max_splits = 1;

@@ -101,28 +101,37 @@ extern "C" int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const flo
     DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_reduce");
 }
 
-// Combine tile partials: 16 channels x 16 tile-lanes per block, fp64 accumulation.
+// Combine tile partials: 16 channels x 64 tile-lanes per 1024-thread block (the kernel is pure
+// latency: many independent loads in flight matter, not bandwidth), fp64 accumulation.
 // MODE 0: forward statistics.  MODE 1: backward sums.
+#define FIN_T 1024
+#define FIN_P (FIN_T / 16)
 template <int MODE>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+__global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
     const float* __restrict__ partial, int ntiles, double invM, double unbias, int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, float momentum, float eps, int training, float* o0, float* o1, float* o2,
     float* o3, int accumulate) {
-    __shared__ double r0[256], r1[256];
+    __shared__ double r0[FIN_T], r1[FIN_T];
     const int tid = threadIdx.x, cl = tid & 15, part = tid >> 4;
     const int c = blockIdx.x * 16 + cl;
     double a0 = 0.0, a1 = 0.0;
     if (c < C && (MODE == 1 || training)) {
-        for (int t = part; t < ntiles; t += 16) {
+#pragma unroll 4
+        for (int t = part; t < ntiles; t += FIN_P) {
             a0 += (double)partial[((size_t)t * 2 + 0) * C + c];
             a1 += (double)partial[((size_t)t * 2 + 1) * C + c];
         }
     }
     r0[tid] = a0; r1[tid] = a1;
     __syncthreads();
+    // tree over the 64 tile-lanes (fixed order: deterministic)
+    for (int h = FIN_P / 2; h >= 1; h >>= 1) {
+        if (part < h) { r0[tid] += r0[tid + h * 16]; r1[tid] += r1[tid + h * 16]; }
+        __syncthreads();
+    }
     if (part == 0 && c < C) {
-        for (int j = 1; j < 16; ++j) { a0 += r0[j * 16 + cl]; a1 += r1[j * 16 + cl]; }
+        a0 = r0[tid]; a1 = r1[tid];
         if (MODE == 0) {
             double mean, var;
             if (training) {
@@ -165,7 +174,7 @@ extern "C" int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int
     DSNT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DSNT_ERR_ARG,
                  "dsnt_bn_finalize: running_mean/var must be given together");
     const double unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
                        partial, ntiles, 1.0 / (double)M, unbias, C, gamma, beta, running_mean,
                        running_var, momentum, eps, training, mean, invstd, scale, shift, 0);
     DSNT_CHECK_LAUNCH("dsnt_bn_finalize");
@@ -176,7 +185,7 @@ extern "C" int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M,
                                     void* stream) {
     DSNT_REQUIRE(partial && coef && ntiles > 0 && C > 0 && M > 0, DSNT_ERR_ARG,
                  "dsnt_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
                        partial, ntiles, 1.0 / (double)M, 1.0, C, nullptr, nullptr, nullptr, nullptr,
                        0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate);
     DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize");
