@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdsnt_hip.so')
-SOURCES = ['api.cpp', 'conv.hip', 'elementwise.hip', 'head.hip']
+SOURCES = ['api.cpp', 'conv.hip', 'elementwise.hip', 'head.hip', 'debug.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result']
 

@@ -32,6 +32,21 @@ struct ConvP {
     int M, K, mtiles, ntiles;
 };
 
+// Debug timeline (normally null): when set through dsnt_debug_set_timeline, lane 0 of every wave
+// of workgroup `g_dbg_block` stamps s_memtime at chosen points: dbg[wave*128 + slot].
+__device__ long long* g_dbg = nullptr;
+__device__ int g_dbg_block = 0;
+#define DBG_STAMP(slot)                                                                      \
+    do {                                                                                     \
+        if (dbg && (slot) < 128) dbg[wave * 128 + (slot)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+
+extern "C" int dsnt_debug_set_timeline(long long* buf, int block) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &buf, sizeof(buf)) != hipSuccess) return DSNT_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_block), &block, sizeof(block)) != hipSuccess) return DSNT_ERR_HIP;
+    return DSNT_OK;
+}
+
 __device__ __forceinline__ void xcd_remap(int bid, int nwg, int& out) {
     // Blocks are dealt round-robin over the 8 XCDs; give every XCD a contiguous run of
     // tiles so neighbouring tiles (shared halo rows, shared A rows across n-tiles) meet in
@@ -40,8 +55,18 @@ __device__ __forceinline__ void xcd_remap(int bid, int nwg, int& out) {
     out = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
-template <int WM, int WN, int TM, int TN, bool PRO>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP p) {
+// Wave-specialised: a workgroup is 8 waves — waves 0..3 only read fragments from LDS and issue
+// MFMAs (one per SIMD, 64 MFMAs = 4096 matrix-pipe cycles per K-step), waves 4..7 only move data
+// (global loads two K-steps ahead, BN+ReLU / zero-padding transform, LDS stores).  The two roles
+// meet at one barrier per K-step, so the matrix pipe never waits on address arithmetic, memory
+// latency or the transform.  Two workgroups per CU (LDS-limited) give each SIMD two MFMA waves.
+// FAST (Cin % 32 == 0, R*S*APASS <= 64, tensors < 4 GiB): the filter tap of a K-step is
+// wave-uniform, so loader addresses are a per-thread constant plus a scalar — range-checked buffer
+// loads need one v_add per 16-byte load and no clamping, and zero padding comes from a validity
+// bit-mask computed once per thread.  This matters because on gfx950 the fp32 MFMA executes at the
+// vector-FP32 rate and loader VALU instructions measurably take matrix-pipe time.
+template <int WM, int WN, int TM, int TN, bool PRO, bool FAST>
+__global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int APASS = BM / 32, BPASS = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -52,87 +77,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP p) {
     xcd_remap(blockIdx.x, p.mtiles * p.ntiles, tile);
     const int ntile = tile % p.ntiles, mtile = tile / p.ntiles;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsteps = (p.K + BK - 1) / BK;
     const int lr = lane & 31, lh = lane >> 5;
-    const int lrow = tid >> 3, kc = tid & 7;
-
-    // per-thread A rows: image base and top-left input coordinate
-    int abase[APASS], aih0[APASS], aiw0[APASS];
-    const int HoWo = p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-        const int m = mtile * BM + lrow + 32 * i;
-        if (m < p.M) {
-            const int n = m / HoWo, rem = m - n * HoWo;
-            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-            abase[i] = n * p.H * p.W * p.Cin;
-            aih0[i] = oh * p.stride - p.pad;
-            aiw0[i] = ow * p.stride - p.pad;
-        } else {
-            abase[i] = 0; aih0[i] = -(1 << 28); aiw0[i] = 0;
-        }
-    }
-    int bn_[BPASS];
-#pragma unroll
-    for (int j = 0; j < BPASS; ++j) bn_[j] = ntile * BN + lrow + 32 * j;
-
-    // Staging registers.  gload() only ISSUES the global loads (unconditional, clamped addresses,
-    // so they go out back-to-back and stay in flight during the MFMAs of the current step);
-    // the BN+ReLU / zero-padding transform happens in lstore(), after the MFMAs.
-    float4 ra[APASS], rb[BPASS];
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned okmask = 0;
-    auto gload = [&](int step) {
-        const int k0 = step * BK + kc * 4;
-        const bool vk = k0 < p.K;
-        const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
-        const int r = tap / p.S, s = tap - r * p.S;
-        const int dh = r * p.dil, dw = s * p.dil;
-        if (PRO) {
-            const int cc = vk ? c : 0;
-            sc = *reinterpret_cast<const float4*>(p.in_scale + cc);
-            sh = *reinterpret_cast<const float4*>(p.in_shift + cc);
-        }
-        okmask = 0;
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) {
-            const int ih = aih0[i] + dh, iw = aiw0[i] + dw;
-            const bool ok = vk && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            const size_t off = ok ? (size_t)abase[i] + (size_t)(ih * p.W + iw) * p.Cin + c : 0;
-            ra[i] = *reinterpret_cast<const float4*>(p.x + off);
-            okmask |= (ok ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int j = 0; j < BPASS; ++j) {
-            const bool ok = vk && bn_[j] < p.Cout;
-            const size_t off = ok ? (size_t)bn_[j] * p.K + k0 : 0;
-            rb[j] = *reinterpret_cast<const float4*>(p.w + off);
-            okmask |= (ok ? 1u : 0u) << (8 + j);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < APASS; ++i) {
-            float4 v = ra[i];
-            if (PRO) {
-                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-                if (p.in_relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-            }
-            if (!((okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(As + (buf * BM + lrow + 32 * i) * PITCH + kc * 4) = v;
-        }
-#pragma unroll
-        for (int j = 0; j < BPASS; ++j) {
-            float4 v = rb[j];
-            if (!((okmask >> (8 + j)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(Bs + (buf * BN + lrow + 32 * j) * PITCH + kc * 4) = v;
-        }
-    };
+    const int cw = wave & 3;
+    const int wm = cw / WN, wn = cw % WN;
+    long long* dbg = (g_dbg && (int)blockIdx.x == g_dbg_block && lane == 0) ? g_dbg : nullptr;
+    DBG_STAMP(0);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -142,57 +94,302 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    const int nsteps = (p.K + BK - 1) / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nsteps) gload(s + 1);
-        const float* Ab = As + (buf * BM + (wm * TM) * 32 + lr) * PITCH + 4 * lh;
-        const float* Bb = Bs + (buf * BN + (wn * TN) * 32 + lr) * PITCH + 4 * lh;
+    if (FAST && wave >= 4) {
+        // ------------------------------------------------------------------ loader waves (fast)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int ltid = tid - 256;
+        const int lrow = ltid >> 3, kc = ltid & 7;
+        const int HoWo = p.Ho * p.Wo;
+        const int RS = p.R * p.S;
+        // per-thread constants: byte offset of (row i, tap (0,0), channel 4*kc) and tap validity
+        unsigned apix[APASS];
+        unsigned long long vmask = 0ull;            // bit tap*APASS + i
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float4 fa[TM], fb[TN];
+        for (int i = 0; i < APASS; ++i) {
+            const int m = mtile * BM + lrow + 32 * i;
+            const bool vm = m < p.M;
+            const int mm = vm ? m : 0;
+            const int n = mm / HoWo, rem = mm - n * HoWo;
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            apix[i] = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.Cin + kc * 4) * 4u;
+            for (int t = 0; t < RS; ++t) {
+                const int r = t / p.S, s_ = t - r * p.S;
+                const int ih = ih0 + r * p.dil, iw = iw0 + s_ * p.dil;
+                if (vm && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                    vmask |= 1ull << (t * APASS + i);
+            }
+        }
+        unsigned bpix[BPASS];
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
-                fa[a] = *reinterpret_cast<const float4*>(Ab + a * 32 * PITCH + ks * 8);
+        for (int j = 0; j < BPASS; ++j) {
+            const int n = ntile * BN + lrow + 32 * j;
+            bpix[j] = n < p.Cout ? (unsigned)(n * p.K + kc * 4) * 4u : 0xF0000000u;   // OOB -> 0
+        }
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.w), 0, (int)((size_t)p.Cout * p.K * 4u), 0x00020000);
+        struct Stage {
+            u32x4 ra[APASS], rb[BPASS];
+            float4 sc, sh;
+            unsigned ok;       // APASS validity bits of this step's tap
+        };
+        Stage S0, S1;
+        auto gload = [&](Stage& st, int step) {
+            // all scalar: tap, channel base, byte offset of the tap relative to tap (0,0)
+            const int kb = step * BK;
+            const int tap = kb / p.Cin, cb = kb - tap * p.Cin;
+            const int r = tap / p.S, s_ = tap - r * p.S;
+            const unsigned toff = (unsigned)(((r * p.dil) * p.W + s_ * p.dil) * p.Cin + cb) * 4u;
+            if (PRO) {
+                st.sc = *reinterpret_cast<const float4*>(p.in_scale + cb + kc * 4);
+                st.sh = *reinterpret_cast<const float4*>(p.in_shift + cb + kc * 4);
+            }
+            st.ok = (unsigned)(vmask >> (tap * APASS));
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
-                fb[b] = *reinterpret_cast<const float4*>(Bb + b * 32 * PITCH + ks * 8);
+            for (int i = 0; i < APASS; ++i)
+                st.ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, apix[i] + toff, 0, 0);
+            const unsigned koff = (unsigned)kb * 4u;
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j)
+                st.rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bpix[j] + koff, 0, 0);
+        };
+        auto lstore = [&](const Stage& st, int buf) {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                float4 v = make_float4(__uint_as_float(st.ra[i].x), __uint_as_float(st.ra[i].y),
+                                       __uint_as_float(st.ra[i].z), __uint_as_float(st.ra[i].w));
+                float* dst = As + (buf * BM + lrow + 32 * i) * PITCH + kc * 4;
+                if ((st.ok >> i) & 1u) {
+                    if (PRO) {
+                        v.x = fmaf(v.x, st.sc.x, st.sh.x); v.y = fmaf(v.y, st.sc.y, st.sh.y);
+                        v.z = fmaf(v.z, st.sc.z, st.sh.z); v.w = fmaf(v.w, st.sc.w, st.sh.w);
+                        if (p.in_relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                    }
+                    *reinterpret_cast<float4*>(dst) = v;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j)
+                *reinterpret_cast<u32x4*>(Bs + (buf * BN + lrow + 32 * j) * PITCH + kc * 4) = st.rb[j];
+        };
+        gload(S0, 0);
+        if (nsteps > 1) gload(S1, 1);
+        lstore(S0, 0);
+        if (nsteps > 2) gload(S0, 2);
+        DBG_STAMP(1);
+        __syncthreads();
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            DBG_STAMP(2 + 3 * s);
+            lstore(S1, 1);
+            DBG_STAMP(3 + 3 * s);
+            if (s + 3 < nsteps) gload(S1, s + 3);
+            DBG_STAMP(4 + 3 * s);
+            __syncthreads();
+            DBG_STAMP(5 + 3 * s);
+            if (s + 2 < nsteps) {
+                lstore(S0, 0);
+                DBG_STAMP(6 + 3 * s);
+                if (s + 4 < nsteps) gload(S0, s + 4);
+                DBG_STAMP(7 + 3 * s);
+            }
+            __syncthreads();
+        }
+        if (s < nsteps) __syncthreads();
+    } else if (wave >= 4) {
+        // ------------------------------------------------------------------ loader waves (general)
+        const int ltid = tid - 256;
+        const int lrow = ltid >> 3, kc = ltid & 7;
+        int abase[APASS], aih0[APASS], aiw0[APASS];
+        const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int m = mtile * BM + lrow + 32 * i;
+            if (m < p.M) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                abase[i] = n * p.H * p.W * p.Cin;
+                aih0[i] = oh * p.stride - p.pad;
+                aiw0[i] = ow * p.stride - p.pad;
+            } else {
+                abase[i] = 0; aih0[i] = -(1 << 28); aiw0[i] = 0;
+            }
+        }
+        int boff[BPASS];
+        bool bok[BPASS];
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const int n = ntile * BN + lrow + 32 * j;
+            bok[j] = n < p.Cout;
+            boff[j] = bok[j] ? n * p.K : 0;
+        }
+        // Two register sets: the loads of K-step s+2 and s+3 are in flight while s+1 is stored,
+        // i.e. every global load has two full K-steps (>= 8k matrix-pipe cycles) to land.
+        struct Stage {
+            float4 ra[APASS], rb[BPASS];
+            float4 sc, sh;
+            unsigned okmask;
+        };
+        Stage S0, S1;
+        // issue-only: unconditional loads from clamped addresses, nothing consumed here
+        auto gload = [&](Stage& st, int step) {
+            const int k0 = step * BK + kc * 4;
+            const bool vk = k0 < p.K;
+            const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
+            const int r = tap / p.S, s = tap - r * p.S;
+            const int dh = r * p.dil, dw = s * p.dil;
+            if (PRO) {
+                const int cc = vk ? c : 0;
+                st.sc = *reinterpret_cast<const float4*>(p.in_scale + cc);
+                st.sh = *reinterpret_cast<const float4*>(p.in_shift + cc);
+            }
+            st.okmask = 0;
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const int ih = aih0[i] + dh, iw = aiw0[i] + dw;
+                const bool ok = vk && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                const int off = ok ? abase[i] + (ih * p.W + iw) * p.Cin + c : 0;
+                st.ra[i] = *reinterpret_cast<const float4*>(p.x + off);
+                st.okmask |= (ok ? 1u : 0u) << i;
+            }
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) {
+                const bool ok = vk && bok[j];
+                st.rb[j] = *reinterpret_cast<const float4*>(p.w + (ok ? boff[j] + k0 : 0));
+                st.okmask |= (ok ? 1u : 0u) << (8 + j);
+            }
+        };
+        auto lstore = [&](const Stage& st, int buf) {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                float4 v = st.ra[i];
+                if (PRO) {
+                    v.x = fmaf(v.x, st.sc.x, st.sh.x); v.y = fmaf(v.y, st.sc.y, st.sh.y);
+                    v.z = fmaf(v.z, st.sc.z, st.sh.z); v.w = fmaf(v.w, st.sc.w, st.sh.w);
+                    if (p.in_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+                if (!((st.okmask >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(As + (buf * BM + lrow + 32 * i) * PITCH + kc * 4) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) {
+                float4 v = st.rb[j];
+                if (!((st.okmask >> (8 + j)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(Bs + (buf * BN + lrow + 32 * j) * PITCH + kc * 4) = v;
+            }
+        };
+        gload(S0, 0);
+        if (nsteps > 1) gload(S1, 1);
+        lstore(S0, 0);
+        if (nsteps > 2) gload(S0, 2);
+        DBG_STAMP(1);
+        __syncthreads();
+        // iteration s stores K-step s+1 (held in S1 for even s, S0 for odd s) into the buffer the
+        // MFMA waves left in iteration s-1, then refills that register set with K-step s+3
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            DBG_STAMP(2 + 3 * s);
+            lstore(S1, 1);
+            DBG_STAMP(3 + 3 * s);
+            if (s + 3 < nsteps) gload(S1, s + 3);
+            DBG_STAMP(4 + 3 * s);
+            __syncthreads();
+            DBG_STAMP(5 + 3 * s);
+            if (s + 2 < nsteps) {
+                lstore(S0, 0);
+                DBG_STAMP(6 + 3 * s);
+                if (s + 4 < nsteps) gload(S0, s + 4);
+                DBG_STAMP(7 + 3 * s);
+            }
+            __syncthreads();
+        }
+        if (s < nsteps) __syncthreads();     // odd step count: the last iteration only synchronises
+    } else {
+        // ------------------------------------------------------------------ MFMA waves
+        __builtin_amdgcn_s_setprio(1);
+        // Software-pipelined fragment reads: the ds_reads of k-group g+1 are issued before the 16
+        // MFMAs of group g (two fragment register sets), and the barrier of a K-step sits in front
+        // of its LAST group, so the first reads of the next step are already in flight while that
+        // group's MFMAs run.  The matrix pipe then only idles for the barrier skew.
+        struct Frag { float4 a[TM], b[TN]; };
+        Frag F0, F1;
+        auto rd = [&](Frag& f, int buf, int ks) {
+            const float* Ab = As + (buf * BM + (wm * TM) * 32 + lr) * PITCH + 4 * lh + ks * 8;
+            const float* Bb = Bs + (buf * BN + (wn * TN) * 32 + lr) * PITCH + 4 * lh + ks * 8;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) f.a[a] = *reinterpret_cast<const float4*>(Ab + a * 32 * PITCH);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) f.b[b] = *reinterpret_cast<const float4*>(Bb + b * 32 * PITCH);
+        };
+        auto mm = [&](const Frag& f) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[a].x, f.b[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[a].y, f.b[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[a].z, f.b[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[a].w, f.b[b].w, acc[a][b], 0, 0, 0);
                 }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the vmcnt wait + transform behind the MFMAs
-        if (s + 1 < nsteps) lstore(buf ^ 1);
+        };
         __syncthreads();
+        rd(F0, 0, 0);
+        for (int s = 0; s < nsteps; ++s) {
+            const int buf = s & 1;
+            DBG_STAMP(1 + 2 * s);
+            rd(F1, buf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(F0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(F0, buf, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(F1);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(F1, buf, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(F0);
+            __builtin_amdgcn_sched_barrier(0);
+            DBG_STAMP(2 + 2 * s);
+            __syncthreads();                       // all of this step's LDS reads have landed
+            if (s + 1 < nsteps) rd(F0, buf ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(F1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
     }
+    DBG_STAMP(120);
 
     // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) +
     // 4*(lane>>5)) are transposed through LDS into row-major [BM][BN] so that bias / residual /
     // store run as 16-byte row-contiguous accesses, all loads issued before the first use.
     constexpr int CP = BN + 4;                 // C-tile pitch (floats)
     float* Cs = smem;                          // [BM][CP]; the main loop ended with a barrier
+    if (wave < 4) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int col = (wn * TN + b) * 32 + lr;
-            const int row0 = (wm * TM + a) * 32 + 4 * lh;
+            for (int b = 0; b < TN; ++b) {
+                const int col = (wn * TN + b) * 32 + lr;
+                const int row0 = (wm * TM + a) * 32 + 4 * lh;
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                Cs[(row0 + (e & 3) + 8 * (e >> 2)) * CP + col] = acc[a][b][e];
-        }
+                for (int e = 0; e < 16; ++e)
+                    Cs[(row0 + (e & 3) + 8 * (e >> 2)) * CP + col] = acc[a][b][e];
+            }
+    }
     __syncthreads();
     constexpr int CH = BN / 4;                 // float4 chunks per row
-    constexpr int RPP = 256 / CH;              // rows per pass
+    constexpr int RPP = 512 / CH;              // rows per pass
     constexpr int NP = BM / RPP;               // passes
     const int ch = tid % CH, r0 = tid / CH;
     const int n0 = ntile * BN + ch * 4;
@@ -244,6 +441,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvP p) {
             }
         }
     }
+    DBG_STAMP(121);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -272,16 +470,24 @@ static int launch_fwd(const ConvP& p, bool pro, hipStream_t st) {
     // one-time opt-in to > 64 KiB of dynamic LDS (not a stream operation; safe under capture)
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {
-        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, true>,
+        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, true, true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, false>,
+        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, false, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, true, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, false, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (pro)
-        hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, true>), dim3(grid), dim3(256), lds, st, p);
-    else
-        hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, false>), dim3(grid), dim3(256), lds, st, p);
+    const bool fast = (p.Cin % BK == 0) && (p.R * p.S * (BM / 32) <= 64) &&
+                      ((size_t)p.N * p.H * p.W * p.Cin * 4u < (1ull << 31)) &&
+                      ((size_t)p.Cout * p.K * 4u < (1ull << 31));
+    dim3 gr(grid), bl(512);
+    if (pro && fast) hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, true, true>), gr, bl, lds, st, p);
+    else if (pro) hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, true, false>), gr, bl, lds, st, p);
+    else if (fast) hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, false, true>), gr, bl, lds, st, p);
+    else hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, false, false>), gr, bl, lds, st, p);
     return 0;
 }
 

@@ -60,6 +60,8 @@ SIGNATURES = {
     'dsnt_rmsprop_step': [P, P, P, L, F, F, F, F, F, P],
     'dsnt_sgd_step': [P, P, P, L, F, F, F, F, I, P],
     'dsnt_pckh': [P, P, P, P, P, P, F, P, P, I, I, P],
+    'dsnt_debug_mfma_peak': [P, I, I, I, I, P],
+    'dsnt_debug_coexec': [P, I, I, I, P],
 }
 # entry points without the status/stream convention
 PLAIN = {
@@ -67,6 +69,7 @@ PLAIN = {
     'dsnt_last_error': (C.c_char_p, []),
     'dsnt_conv_fwd_bm': (I, [GP]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
+    'dsnt_debug_set_timeline': (I, [P, I]),
 }
 
 _lib = None

@@ -215,6 +215,16 @@ int dsnt_pckh(const float* pred, const float* target, const double* m, const dou
               const float* mask, const double* head, float threshold, float* hits,
               float* valid, int B, int J, void* stream);
 
+/* ------------------------------------------------------------------ calibration
+ * Not on the product path: sustained v_mfma_f32_32x32x2_f32 rate of this device
+ * (blocks x threads, `iters` x 16 MFMAs per wave; dep = 1 independent / 4 dependent chains). */
+int dsnt_debug_mfma_peak(float* out, int blocks, int threads, int iters, int dep, void* stream);
+/* Debug timeline of the conv kernel: lane 0 of every wave of workgroup `block` stamps s_memtime
+ * into buf[wave*128 + slot] (buf = 8*128 int64 on the device; NULL switches it off). */
+int dsnt_debug_set_timeline(long long* buf, int block);
+/* MFMA / VALU co-execution probe (512-thread blocks: 4 MFMA waves + 4 v_fma waves). */
+int dsnt_debug_coexec(float* out, int blocks, int mfma_iters, int valu_iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,24 @@
+"""Run only the dominant conv kernel a few times (for rocprofv3 --pmc)."""
+import ctypes as C, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'dsnt-pose2d_amd')]
+from dsnt import _lib
+from dsnt._lib import ptr, ConvGeom
+dev = torch.device('cuda:0')
+B, H, Cin, Cout, k = 32, 64, 128, 128, 3
+which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
+g = ConvGeom(B, H, H, Cin, H, H, Cout, k, k, 1, k // 2, 1)
+x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
+b = torch.zeros(Cout, device=dev); sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
+y = torch.empty(B, H, H, Cout, device=dev); gy = torch.randn(B, H, H, Cout, device=dev)
+M = B * H * H
+stats = torch.empty((M + 127) // 128, 2, Cout, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+ws = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev); dw = torch.empty_like(w); db = torch.empty(Cout, device=dev)
+for _ in range(5):
+    if which == 'fwd':
+        _lib.fn('dsnt_conv_fwd')(ptr(x), ptr(w), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
+    else:
+        _lib.fn('dsnt_conv_wgrad')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), ptr(dw), ptr(db), 0, C.byref(g), st)
+torch.cuda.synchronize()
