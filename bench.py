@@ -66,10 +66,14 @@ def dominant_kernel_roofline(batch, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * (3 * 3 * 128) * 128
     achieved = flops / (ms * 1e-3) / 1e12
+    traffic = None
+    tj = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if batch == 32 and os.path.exists(tj):      # PMC passes of this exact launch (profiles/)
+        traffic = json.load(open(tj))['traffic_bytes_per_launch']
     return {
         'bound': 'mfma', 'kernel': 'conv_fwd_kernel<2,2,2,2,true> 3x3 128->128 @64x64 B=%d' % batch,
         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_F32_MFMA, 4), 'traffic': None,
+        'frac': round(achieved / PEAK_F32_MFMA, 4), 'traffic': traffic,
         'flops_per_launch': flops, 'us_per_launch': round(ms * 1e3, 1),
     }
 
