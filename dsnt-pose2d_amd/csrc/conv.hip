@@ -578,8 +578,13 @@ struct WgradP {
 
 #define WPITCH 132
 
+// VALU diet (fp32 MFMA and VALU are serialised on gfx950): each thread's filter tap / channel
+// chunk is fixed for the whole kernel, rows advance by 32 per step with incremental (n, oh, ow)
+// carries instead of divisions, loads are range-checked buffer loads (invalid rows / padded taps
+// point out of range and come back as zeros), two register sets keep two steps of loads in flight.
 template <bool PRO>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float As[2][32][WPITCH];
     __shared__ __attribute__((aligned(16))) float Gs[2][32][WPITCH];
 
@@ -593,7 +598,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     const int li = lane & 31, lm = lane >> 5;
     const int lrow = tid >> 5, cc = tid & 31;  // loader: row lrow + 8i, float4 column cc
 
-    // A loader: this thread's k (4 consecutive) is fixed for the whole kernel
     const int k0 = ktile * 128 + cc * 4;
     const bool vk = k0 < p.K;
     const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
@@ -605,50 +609,77 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         sh = *reinterpret_cast<const float4*>(p.in_shift + c);
     }
     const int n0 = ntile * 128 + cc * 4;
-    const bool vn = n0 < p.Cout;   // Cout % 4 == 0 is required by the host wrapper
+    const bool vn = n0 < p.Cout;
 
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
     const int HoWo = p.Ho * p.Wo;
+    const int adv_h = 32 / p.Wo, adv_w = 32 - adv_h * p.Wo;     // scalars: 32 rows = adv_h rows + adv_w cols
 
-    float4 ra[4], rg[4];
-    unsigned okmask = 0;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy), 0, (int)((size_t)p.M * p.Cout * 4u), 0x00020000);
+    const unsigned OOB = 0xF0000000u;
+
+    // per-row state of this thread's four rows
+    int rn[4], roh[4], row_[4], rm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m_begin + lrow + 8 * i;
+        rm[i] = m;
+        const int mm = m < p.M ? m : 0;
+        rn[i] = mm / HoWo;
+        const int rem = mm - rn[i] * HoWo;
+        roh[i] = rem / p.Wo;
+        row_[i] = rem - roh[i] * p.Wo;
+    }
+    struct Stage { u32x4 a[4], g[4]; unsigned ok; };
+    Stage S0, S1;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    // issue-only loads (clamped addresses); transform / masking in lstore after the MFMAs
-    auto gload = [&](int step) {
-        okmask = 0;
+    // issue the loads of the current rows, then advance the rows by 32
+    auto gload = [&](Stage& st) {
+        st.ok = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m_begin + step * 32 + lrow + 8 * i;
-            const bool vm = m < m_end;
-            const int mc = vm ? m : 0;
-            const int n = mc / HoWo, rem = mc - n * HoWo;
-            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-            const int ih = oh * p.stride + dh, iw = ow * p.stride + dw;
+            const bool vm = rm[i] < m_end;
+            const int ih = roh[i] * p.stride + dh, iw = row_[i] * p.stride + dw;
             const bool oka = vm && vk && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            const size_t offa = oka ? ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + c : 0;
-            ra[i] = *reinterpret_cast<const float4*>(p.x + offa);
-            const bool okg = vm && vn;
-            const size_t offg = okg ? (size_t)m * p.Cout + n0 : 0;
-            rg[i] = *reinterpret_cast<const float4*>(p.dy + offg);
-            okmask |= ((oka ? 1u : 0u) << i) | ((okg ? 1u : 0u) << (8 + i));
+            const unsigned offa = oka ? (unsigned)(((rn[i] * p.H + ih) * p.W + iw) * p.Cin + c) * 4u : OOB;
+            st.a[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, offa, 0, 0);
+            const unsigned offg = (vm && vn) ? (unsigned)(rm[i] * p.Cout + n0) * 4u : OOB;
+            st.g[i] = __builtin_amdgcn_raw_buffer_load_b128(gr, offg, 0, 0);
+            st.ok |= (oka ? 1u : 0u) << i;
+            // advance
+            rm[i] += 32;
+            row_[i] += adv_w;
+            roh[i] += adv_h;
+            if (row_[i] >= p.Wo) { row_[i] -= p.Wo; roh[i] += 1; }
+            while (roh[i] >= p.Ho) { roh[i] -= p.Ho; rn[i] += 1; }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const Stage& st, int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float4 va = ra[i], vg = rg[i];
+            float4 va = make_float4(__uint_as_float(st.a[i].x), __uint_as_float(st.a[i].y),
+                                    __uint_as_float(st.a[i].z), __uint_as_float(st.a[i].w));
+            const float4 vg = make_float4(__uint_as_float(st.g[i].x), __uint_as_float(st.g[i].y),
+                                          __uint_as_float(st.g[i].z), __uint_as_float(st.g[i].w));
             if (PRO) {
-                va.x = fmaf(va.x, sc.x, sh.x); va.y = fmaf(va.y, sc.y, sh.y);
-                va.z = fmaf(va.z, sc.z, sh.z); va.w = fmaf(va.w, sc.w, sh.w);
-                if (p.in_relu) {
-                    va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f);
-                    va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                if ((st.ok >> i) & 1u) {
+                    va.x = fmaf(va.x, sc.x, sh.x); va.y = fmaf(va.y, sc.y, sh.y);
+                    va.z = fmaf(va.z, sc.z, sh.z); va.w = fmaf(va.w, sc.w, sh.w);
+                    if (p.in_relu) {
+                        va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f);
+                        va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = va;
+                } else {
+                    *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+            } else {
+                *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = va;   // OOB loads are zeros
             }
-            if (!((okmask >> i) & 1u)) va = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!((okmask >> (8 + i)) & 1u)) vg = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = va;
             *reinterpret_cast<float4*>(&Gs[buf][lrow + 8 * i][cc * 4]) = vg;
             bsum.x += vg.x; bsum.y += vg.y; bsum.z += vg.z; bsum.w += vg.w;
         }
@@ -662,15 +693,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    const int nsteps = (m_end - m_begin + 31) / 32;
-    if (nsteps > 0) {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nsteps) gload(st + 1);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             float fa[2], fb[2];
@@ -684,10 +707,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
                 for (int b = 0; b < 2; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
+    };
+
+    const int nsteps = (m_end - m_begin + 31) / 32;
+    // S0 holds step 0 (then 2, 4, ...), S1 holds step 1 (3, 5, ...): two steps of loads in flight
+    if (nsteps > 0) gload(S0);
+    if (nsteps > 1) gload(S1);
+    if (nsteps > 0) lstore(S0, 0);
+    if (nsteps > 2) gload(S0);
+    __syncthreads();
+    int st = 0;
+    for (; st + 1 < nsteps; st += 2) {
+        compute(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (st + 1 < nsteps) lstore(buf ^ 1);
+        lstore(S1, 1);
+        if (st + 3 < nsteps) gload(S1);
+        __syncthreads();
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < nsteps) {
+            lstore(S0, 0);
+            if (st + 4 < nsteps) gload(S0);
+        }
         __syncthreads();
     }
+    if (st < nsteps) compute(0);
 
     // slab store: ws[split][n][k], D row = k (regs, 4 consecutive), D col = n (lane)
     float* slab = p.ws + (size_t)split * p.Cout * p.K;
@@ -726,35 +770,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                    float* __restrict__ dbias, int splits, int CK, int Cout,
-                                    int accumulate) {
+// Slab reduction: 64 float4 columns x 4 split-lanes per block, 8 loads in flight per thread.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                            float* __restrict__ dbias, int splits, int CK, int Cout,
+                                                            int accumulate) {
+    __shared__ float4 red[256];
     const int total4 = CK / 4;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < total4) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        int s = 0;
-        for (; s + 8 <= splits; s += 8) {       // 8 independent 16-byte loads in flight
+        int s = sl;
+        for (; s + 28 < splits; s += 32) {      // 8 independent 16-byte loads in flight
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[u] = *reinterpret_cast<const float4*>(ws + (size_t)(s + u) * CK + (size_t)i * 4);
+                v[u] = *reinterpret_cast<const float4*>(ws + (size_t)(s + 4 * u) * CK + (size_t)i * 4);
 #pragma unroll
             for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
         }
-        for (; s < splits; ++s) {
+        for (; s < splits; s += 4) {
             const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)s * CK + (size_t)i * 4);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        float4* o = reinterpret_cast<float4*>(dw) + i;
-        if (accumulate) { const float4 c = *o; a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; }
-        *o = a;
-    } else if (dbias && i - total4 < Cout) {
-        const int n = i - total4;
+    } else if (dbias && i - total4 < (Cout + 3) / 4) {
+        // bias partials live behind the slabs: [splits][Cout]
+        const int n0 = (i - total4) * 4;
         const float* b = ws + (size_t)splits * CK;
-        float a = 0.f;
-        for (int s = 0; s < splits; ++s) a += b[(size_t)s * Cout + n];
-        dbias[n] = accumulate ? dbias[n] + a : a;
+        for (int s = sl; s < splits; s += 4) {
+            const float* q = b + (size_t)s * Cout + n0;
+            a.x += q[0]; if (n0 + 1 < Cout) a.y += q[1]; if (n0 + 2 < Cout) a.z += q[2]; if (n0 + 3 < Cout) a.w += q[3];
+        }
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (sl == 0) {
+        for (int j = 1; j < 4; ++j) {
+            const float4 v = red[j * 64 + col];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (i < total4) {
+            float4* o = reinterpret_cast<float4*>(dw) + i;
+            if (accumulate) { const float4 c = *o; a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; }
+            *o = a;
+        } else if (dbias && i - total4 < (Cout + 3) / 4) {
+            const int n0 = (i - total4) * 4;
+            const float v4[4] = {a.x, a.y, a.z, a.w};
+            for (int e = 0; e < 4 && n0 + e < Cout; ++e)
+                dbias[n0 + e] = accumulate ? dbias[n0 + e] + v4[e] : v4[e];
+        }
     }
 }
 
@@ -806,8 +870,8 @@ extern "C" int dsnt_conv_wgrad(const float* x, const float* in_scale, const floa
     else
         hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(grid), dim3(256), 0, st, p);
     const int CK = p.Cout * p.K;
-    const int total = CK / 4 + p.Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws, dw, dbias,
+    const int total = CK / 4 + (p.Cout + 3) / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias,
                        p.splits, CK, p.Cout, accumulate);
     DSNT_CHECK_LAUNCH("dsnt_conv_wgrad");
 }

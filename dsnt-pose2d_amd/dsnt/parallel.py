@@ -55,8 +55,8 @@ def broadcast_flat(flat, src=0, group=None):
 
 class DataParallel:
     """Attach to a built, on-device dsnt model: replicates rank 0's weights and arranges the
-    overlapped gradient all-reduce.  The optimiser then divides by the world size
-    (`optimizer.grad_scale = 1/world`, set here when an optimiser from dsnt.optim is given)."""
+    overlapped gradient all-reduce; the 1/world averaging is folded into the kernel that
+    publishes the gradients, so stock and dsnt.optim optimisers both see the mean gradient."""
 
     def __init__(self, model, optimizer=None, group=None):
         from .optim import _find_arena
@@ -71,8 +71,8 @@ class DataParallel:
         self.reducer = GradientAllReducer(arena.fresh, arena.bucket_bounds, group)
         self.runner.bucket_hook = self.reducer.bucket_ready
         self.runner.before_publish = self.reducer.wait
-        if optimizer is not None:
-            optimizer.grad_scale = 1.0 / self.world
+        # gradients are published as the MEAN over ranks (works with any optimiser)
+        arena.publish_scale = 1.0 / self.world
 
     def shard(self, *tensors):
         """This rank's contiguous slice of a global batch (dim 0)."""
