@@ -27,6 +27,8 @@ struct ConvP {
     const float* x; const float* w; const float* bias; float* y;
     const float* in_scale; const float* in_shift;
     const float* res1; const float* res2; float* stats;
+    const unsigned short* wq;      // bf16x6 path: plane 0 of the weights; planes are `wq_stride` elements apart
+    long wq_stride;
     int in_relu;
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil;
     int M, K, mtiles, ntiles;
@@ -53,6 +55,87 @@ __device__ __forceinline__ void xcd_remap(int bid, int nwg, int& out) {
     // one L2.  Bijective for any nwg (cdna guide §5, "XCD swizzle must be bijective").
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
     out = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+// Shared epilogue of the forward / data-gradient kernels (fp32 and bf16x6 variants).
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* smem, int mtile,
+                                              int ntile, int tid, int wave, int lane) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int cw = wave & 3;
+    const int wm = cw / WN, wn = cw % WN;
+    // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) +
+    // 4*(lane>>5)) are transposed through LDS into row-major [BM][BN] so that bias / residual /
+    // store run as 16-byte row-contiguous accesses, all loads issued before the first use.
+    constexpr int CP = BN + 4;                 // C-tile pitch (floats)
+    float* Cs = smem;                          // [BM][CP]; the main loop ended with a barrier
+    if (wave < 4) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = (wn * TN + b) * 32 + lr;
+                const int row0 = (wm * TM + a) * 32 + 4 * lh;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    Cs[(row0 + (e & 3) + 8 * (e >> 2)) * CP + col] = acc[a][b][e];
+            }
+    }
+    __syncthreads();
+    constexpr int CH = BN / 4;                 // float4 chunks per row
+    constexpr int RPP = 512 / CH;              // rows per pass
+    constexpr int NP = BM / RPP;               // passes
+    const int ch = tid % CH, r0 = tid / CH;
+    const int n0 = ntile * BN + ch * 4;
+    const bool vn = n0 < p.Cout;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && vn) bias4 = *reinterpret_cast<const float4*>(p.bias + n0);
+    float4 r1[NP], r2[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int m = mtile * BM + r0 + RPP * j;
+        const bool ok = vn && m < p.M;
+        const size_t o = ok ? (size_t)m * p.Cout + n0 : 0;
+        r1[j] = p.res1 ? *reinterpret_cast<const float4*>(p.res1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r2[j] = p.res2 ? *reinterpret_cast<const float4*>(p.res2 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int row = r0 + RPP * j;
+        const int m = mtile * BM + row;
+        if (vn && m < p.M) {
+            float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + ch * 4);
+            v.x += bias4.x + r1[j].x + r2[j].x; v.y += bias4.y + r1[j].y + r2[j].y;
+            v.z += bias4.z + r1[j].z + r2[j].z; v.w += bias4.w + r1[j].w + r2[j].w;
+            *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n0) = v;
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+            s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+        }
+    }
+    if (p.stats) {
+        __syncthreads();                       // every thread has read its part of Cs
+        float* red = smem;                     // [RPP][BN][2]
+        float* mine = red + ((size_t)r0 * BN + ch * 4) * 2;
+        mine[0] = s1.x; mine[1] = s2.x; mine[2] = s1.y; mine[3] = s2.y;
+        mine[4] = s1.z; mine[5] = s2.z; mine[6] = s1.w; mine[7] = s2.w;
+        __syncthreads();
+        if (tid < BN) {
+            const int n = ntile * BN + tid;
+            if (n < p.Cout) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int w = 0; w < RPP; ++w) {
+                    a0 += red[((size_t)w * BN + tid) * 2 + 0];
+                    a1 += red[((size_t)w * BN + tid) * 2 + 1];
+                }
+                p.stats[((size_t)mtile * 2 + 0) * p.Cout + n] = a0;
+                p.stats[((size_t)mtile * 2 + 1) * p.Cout + n] = a1;
+            }
+        }
+    }
 }
 
 // Wave-specialised: a workgroup is 8 waves — waves 0..3 only read fragments from LDS and issue
@@ -370,78 +453,236 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
     }
     DBG_STAMP(120);
 
-    // ---- epilogue.  The accumulators (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) +
-    // 4*(lane>>5)) are transposed through LDS into row-major [BM][BN] so that bias / residual /
-    // store run as 16-byte row-contiguous accesses, all loads issued before the first use.
-    constexpr int CP = BN + 4;                 // C-tile pitch (floats)
-    float* Cs = smem;                          // [BM][CP]; the main loop ended with a barrier
-    if (wave < 4) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int col = (wn * TN + b) * 32 + lr;
-                const int row0 = (wm * TM + a) * 32 + 4 * lh;
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    Cs[(row0 + (e & 3) + 8 * (e >> 2)) * CP + col] = acc[a][b][e];
-            }
-    }
-    __syncthreads();
-    constexpr int CH = BN / 4;                 // float4 chunks per row
-    constexpr int RPP = 512 / CH;              // rows per pass
-    constexpr int NP = BM / RPP;               // passes
-    const int ch = tid % CH, r0 = tid / CH;
-    const int n0 = ntile * BN + ch * 4;
-    const bool vn = n0 < p.Cout;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && vn) bias4 = *reinterpret_cast<const float4*>(p.bias + n0);
-    float4 r1[NP], r2[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int m = mtile * BM + r0 + RPP * j;
-        const bool ok = vn && m < p.M;
-        const size_t o = ok ? (size_t)m * p.Cout + n0 : 0;
-        r1[j] = p.res1 ? *reinterpret_cast<const float4*>(p.res1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-        r2[j] = p.res2 ? *reinterpret_cast<const float4*>(p.res2 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int row = r0 + RPP * j;
-        const int m = mtile * BM + row;
-        if (vn && m < p.M) {
-            float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + ch * 4);
-            v.x += bias4.x + r1[j].x + r2[j].x; v.y += bias4.y + r1[j].y + r2[j].y;
-            v.z += bias4.z + r1[j].z + r2[j].z; v.w += bias4.w + r1[j].w + r2[j].w;
-            *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n0) = v;
-            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-            s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
-            s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
-        }
-    }
-    if (p.stats) {
-        __syncthreads();                       // every thread has read its part of Cs
-        float* red = smem;                     // [RPP][BN][2]
-        float* mine = red + ((size_t)r0 * BN + ch * 4) * 2;
-        mine[0] = s1.x; mine[1] = s2.x; mine[2] = s1.y; mine[3] = s2.y;
-        mine[4] = s1.z; mine[5] = s2.z; mine[6] = s1.w; mine[7] = s2.w;
-        __syncthreads();
-        if (tid < BN) {
-            const int n = ntile * BN + tid;
-            if (n < p.Cout) {
-                float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-                for (int w = 0; w < RPP; ++w) {
-                    a0 += red[((size_t)w * BN + tid) * 2 + 0];
-                    a1 += red[((size_t)w * BN + tid) * 2 + 1];
-                }
-                p.stats[((size_t)mtile * 2 + 0) * p.Cout + n] = a0;
-                p.stats[((size_t)mtile * 2 + 1) * p.Cout + n] = a1;
-            }
-        }
-    }
+    conv_epilogue<WM, WN, TM, TN>(p, acc, smem, mtile, ntile, tid, wave, lane);
     DBG_STAMP(121);
+}
+
+// ==========================================================================================
+// bf16x6: fp32-accurate convolution on the bf16 matrix cores.
+// Every fp32 operand is split exactly into three bf16 planes x = x1 + x2 + x3 (8 + 8 + 8 mantissa
+// bits); the product keeps the six terms of order <= 2^-16 (x1y1, x1y2, x2y1, x1y3, x2y2, x3y1),
+// accumulated in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  The dropped terms are
+// <= 2^-23 |xy| — below one fp32 rounding — so results match the fp32 kernel to fp32 accuracy
+// (measured 2.4e-7 vs 5.4e-7 for a plain fp32 GEMM, K = 1152), at 6/16 of the fp32-MFMA cost.
+// Weights are pre-split once per step (dsnt_split_bf16x3); activations are transformed
+// (BN + ReLU, zero padding) and split by the loader waves while staging.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define BK6 16
+#define PITCH6 24        // bf16 per LDS row: 16 data + 8 pad = 48 B -> conflict-free ds_read_b128
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// 4 floats -> three planes of 4 bf16 (2 dwords each): exact 3-way split
+__device__ __forceinline__ void split4(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
+    p1.x = pk_bf16(v.x, v.y); p1.y = pk_bf16(v.z, v.w);
+    float4 r;
+    r.x = v.x - __uint_as_float(p1.x << 16); r.y = v.y - __uint_as_float(p1.x & 0xffff0000u);
+    r.z = v.z - __uint_as_float(p1.y << 16); r.w = v.w - __uint_as_float(p1.y & 0xffff0000u);
+    p2.x = pk_bf16(r.x, r.y); p2.y = pk_bf16(r.z, r.w);
+    r.x -= __uint_as_float(p2.x << 16); r.y -= __uint_as_float(p2.x & 0xffff0000u);
+    r.z -= __uint_as_float(p2.y << 16); r.w -= __uint_as_float(p2.y & 0xffff0000u);
+    p3.x = pk_bf16(r.x, r.y); p3.y = pk_bf16(r.z, r.w);
+}
+
+__global__ void split_bf16x3_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        uint2 a, b, c;
+        split4(src[i], a, b, c);
+        dst[i] = a; dst[n4 + i] = b; dst[2 * n4 + i] = c;
+    }
+}
+
+extern "C" int dsnt_split_bf16x3(const float* src, void* dst, int64_t n, void* stream) {
+    DSNT_REQUIRE(src && dst && n > 0 && n % 4 == 0, DSNT_ERR_ARG, "dsnt_split_bf16x3: n must be a positive multiple of 4");
+    DSNT_REQUIRE(dsnt_aligned16(src) && (((uintptr_t)dst) & 7u) == 0, DSNT_ERR_ALIGN, "dsnt_split_bf16x3: alignment");
+    const long n4 = n / 4;
+    long g = (n4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)src, (uint2*)dst, n4);
+    DSNT_CHECK_LAUNCH("dsnt_split_bf16x3");
+}
+
+template <int WM, int WN, int TM, int TN, bool PRO>
+__global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int APASS = BM / 64;             // loader: 64 rows x 4 float4 chunks per pass
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* A6 = reinterpret_cast<__bf16*>(smem);          // [2][3][BM][PITCH6]
+    __bf16* B6 = A6 + 2 * 3 * BM * PITCH6;                 // [2][3][BN][PITCH6]
+
+    int tile;
+    xcd_remap(blockIdx.x, p.mtiles * p.ntiles, tile);
+    const int ntile = tile % p.ntiles, mtile = tile / p.ntiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsteps = p.K / BK6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int cw = wave & 3;
+    const int wm = cw / WN, wn = cw % WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int ltid = tid - 256;
+        const int lrow = ltid >> 2, kc = ltid & 3;
+        const int HoWo = p.Ho * p.Wo;
+        const int RS = p.R * p.S;
+        unsigned apix[APASS];
+        unsigned vmask = 0;                          // bit tap*APASS + i
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int m = mtile * BM + lrow + 64 * i;
+            const bool vm = m < p.M;
+            const int mm = vm ? m : 0;
+            const int n = mm / HoWo, rem = mm - n * HoWo;
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            apix[i] = (unsigned)(((n * p.H + ih0) * p.W + iw0) * p.Cin + kc * 4) * 4u;
+            for (int t = 0; t < RS; ++t) {
+                const int r = t / p.S, s_ = t - r * p.S;
+                const int ih = ih0 + r * p.dil, iw = iw0 + s_ * p.dil;
+                if (vm && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) vmask |= 1u << (t * APASS + i);
+            }
+        }
+        // weights: 16-byte chunk `ltid` of each plane's [BN][16] slice: row = ltid>>1, half = ltid&1
+        const int brow = ltid >> 1, bhalf = ltid & 1;
+        const int bn = ntile * BN + brow;
+        const bool bvalid = brow < BN && bn < p.Cout;
+        unsigned bpix[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            bpix[j] = bvalid ? (unsigned)((size_t)j * p.wq_stride + (size_t)bn * p.K + bhalf * 8) * 2u : 0xF0000000u;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)2 * p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
+        struct Stage {
+            u32x4 ra[APASS], rb[3];
+            float4 sc, sh;
+            unsigned ok;
+        };
+        Stage S0, S1;
+        auto gload = [&](Stage& st, int step) {
+            const int kb = step * BK6;
+            const int tap = kb / p.Cin, cb = kb - tap * p.Cin;
+            const int r = tap / p.S, s_ = tap - r * p.S;
+            const unsigned toff = (unsigned)(((r * p.dil) * p.W + s_ * p.dil) * p.Cin + cb) * 4u;
+            if (PRO) {
+                st.sc = *reinterpret_cast<const float4*>(p.in_scale + cb + kc * 4);
+                st.sh = *reinterpret_cast<const float4*>(p.in_shift + cb + kc * 4);
+            }
+            st.ok = vmask >> (tap * APASS);
+#pragma unroll
+            for (int i = 0; i < APASS; ++i)
+                st.ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, apix[i] + toff, 0, 0);
+            const unsigned koff = (unsigned)kb * 2u;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                st.rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bpix[j] + koff, 0, 0);
+        };
+        auto lstore = [&](const Stage& st, int buf) {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                float4 v = make_float4(__uint_as_float(st.ra[i].x), __uint_as_float(st.ra[i].y),
+                                       __uint_as_float(st.ra[i].z), __uint_as_float(st.ra[i].w));
+                uint2 q1 = make_uint2(0u, 0u), q2 = q1, q3 = q1;
+                if ((st.ok >> i) & 1u) {
+                    if (PRO) {
+                        v.x = fmaf(v.x, st.sc.x, st.sh.x); v.y = fmaf(v.y, st.sc.y, st.sh.y);
+                        v.z = fmaf(v.z, st.sc.z, st.sh.z); v.w = fmaf(v.w, st.sc.w, st.sh.w);
+                        if (p.in_relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                    }
+                    split4(v, q1, q2, q3);
+                }
+                __bf16* dst = A6 + ((size_t)(buf * 3) * BM + lrow + 64 * i) * PITCH6 + kc * 4;
+                *reinterpret_cast<uint2*>(dst) = q1;
+                *reinterpret_cast<uint2*>(dst + BM * PITCH6) = q2;
+                *reinterpret_cast<uint2*>(dst + 2 * BM * PITCH6) = q3;
+            }
+            if (brow < BN) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    *reinterpret_cast<u32x4*>(B6 + ((size_t)(buf * 3 + j) * BN + brow) * PITCH6 + bhalf * 8) = st.rb[j];
+            }
+        };
+        gload(S0, 0);
+        if (nsteps > 1) gload(S1, 1);
+        lstore(S0, 0);
+        if (nsteps > 2) gload(S0, 2);
+        __syncthreads();
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            lstore(S1, 1);
+            if (s + 3 < nsteps) gload(S1, s + 3);
+            __syncthreads();
+            if (s + 2 < nsteps) {
+                lstore(S0, 0);
+                if (s + 4 < nsteps) gload(S0, s + 4);
+            }
+            __syncthreads();
+        }
+        if (s < nsteps) __syncthreads();
+    } else {
+        // ------------------------------------------------------------------ MFMA waves
+        struct Frag { bf16x8 a[TM][3], b[TN][3]; };
+        Frag F;
+        auto rd = [&](Frag& f, int buf) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+                    f.a[a][pl] = *reinterpret_cast<const bf16x8*>(
+                        A6 + ((size_t)(buf * 3 + pl) * BM + (wm * TM + a) * 32 + lr) * PITCH6 + 8 * lh);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    f.b[b][pl] = *reinterpret_cast<const bf16x8*>(
+                        B6 + ((size_t)(buf * 3 + pl) * BN + (wn * TN + b) * 32 + lr) * PITCH6 + 8 * lh);
+            }
+        };
+        auto mm = [&](const Frag& f) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    // smallest terms first
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][2], f.b[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][0], f.b[b][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][1], f.b[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][1], f.b[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][0], f.b[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][0], f.b[b][0], acc[a][b], 0, 0, 0);
+                }
+        };
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            rd(F, s & 1);
+            mm(F);
+            __syncthreads();
+        }
+    }
+    conv_epilogue<WM, WN, TM, TN>(p, acc, smem, mtile, ntile, tid, wave, lane);
+}
+
+extern "C" int dsnt_conv_bf16x6_ok(const dsnt_conv_geom* g) {
+    if (!g) return 0;
+    return g->Cin % BK6 == 0 && g->Cout % 4 == 0 && g->R * g->S * 2 <= 32 &&
+           (size_t)g->N * g->H * g->W * g->Cin * 4u < (1ull << 31) &&
+           (size_t)3 * g->Cout * g->R * g->S * g->Cin * 2u < (1ull << 31);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -522,7 +763,7 @@ extern "C" int dsnt_conv_fwd(const float* x, const float* w, const float* bias, 
                  "dsnt_conv_fwd: x/w/scale/shift must be 16-byte aligned");
     ConvP p;
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift;
-    p.res1 = res1; p.res2 = res2; p.stats = stats_partial; p.in_relu = in_relu;
+    p.res1 = res1; p.res2 = res2; p.stats = stats_partial; p.in_relu = in_relu; p.wq = nullptr; p.wq_stride = 0;
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
@@ -536,6 +777,55 @@ extern "C" int dsnt_conv_fwd(const float* x, const float* w, const float* bias, 
     else if (BM == 128 && BN == 32) launch_fwd<4, 1, 1, 1>(p, pro, st);
     else launch_fwd<1, 4, 1, 1>(p, pro, st);
     DSNT_CHECK_LAUNCH("dsnt_conv_fwd");
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    size_t lds = (size_t)2 * 3 * (BM + BN) * PITCH6 * 2;
+    const size_t epi = (size_t)BM * (BN + 4) * 4;          // the epilogue's C tile lives in the same LDS
+    if (epi > lds) lds = epi;
+    static bool attr_done = false;
+    if (!attr_done && lds > 65536) {
+        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 gr(p.mtiles * p.ntiles), bl(512);
+    if (pro) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true>), gr, bl, lds, st, p);
+    else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false>), gr, bl, lds, st, p);
+}
+
+extern "C" int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_t plane_stride, const float* bias, float* y,
+                                    const float* in_scale, const float* in_shift, int in_relu,
+                                    const float* res1, const float* res2, float* stats_partial,
+                                    const dsnt_conv_geom* g, void* stream) {
+    if (int e = check_geom(g, "dsnt_conv_fwd_bf16x6")) return e;
+    DSNT_REQUIRE(x && w_planes && y, DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6: null tensor");
+    DSNT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DSNT_ERR_ARG,
+                 "dsnt_conv_fwd_bf16x6: in_scale/in_shift must be given together");
+    DSNT_REQUIRE(dsnt_conv_bf16x6_ok(g), DSNT_ERR_SHAPE,
+                 "dsnt_conv_fwd_bf16x6: geometry not supported (need Cin %% 16 == 0, <= 16 taps, < 2 GiB)");
+    DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(w_planes) && (!in_scale || dsnt_aligned16(in_scale)) &&
+                 (!in_shift || dsnt_aligned16(in_shift)), DSNT_ERR_ALIGN, "dsnt_conv_fwd_bf16x6: alignment");
+    ConvP p;
+    DSNT_REQUIRE(plane_stride >= (int64_t)g->Cout * g->R * g->S * g->Cin && plane_stride % 8 == 0 &&
+                 (2 * plane_stride + (int64_t)g->Cout * g->R * g->S * g->Cin) * 2 < (1LL << 31), DSNT_ERR_SHAPE,
+                 "dsnt_conv_fwd_bf16x6: bad plane stride %lld", (long long)plane_stride);
+    p.x = x; p.w = nullptr; p.wq = (const unsigned short*)w_planes; p.wq_stride = plane_stride; p.bias = bias; p.y = y;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.res1 = res1; p.res2 = res2; p.stats = stats_partial;
+    p.in_relu = in_relu;
+    p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
+    p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
+    p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
+    const int BN = g->Cout <= 64 ? 64 : 128;
+    p.mtiles = (p.M + 127) / 128; p.ntiles = (p.Cout + BN - 1) / BN;
+    hipStream_t st = (hipStream_t)stream;
+    if (BN == 128) launch_fwd6<2, 2, 2, 2>(p, in_scale != nullptr, st);
+    else launch_fwd6<2, 2, 2, 1>(p, in_scale != nullptr, st);
+    DSNT_CHECK_LAUNCH("dsnt_conv_fwd_bf16x6");
 }
 
 // wd[ci][R-1-r][S-1-s][co] = w[co][r][s][ci]

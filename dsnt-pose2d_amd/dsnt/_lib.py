@@ -43,6 +43,8 @@ SIGNATURES = {
     'dsnt_head_bwd': [P, P, P, P, P, P, P, L, I, I, F, I, P],
     'dsnt_conv_fwd': [P, P, P, P, P, P, I, P, P, P, GP, P],
     'dsnt_conv_pack_dgrad': [P, P, I, I, I, I, P],
+    'dsnt_conv_fwd_bf16x6': [P, P, L, P, P, P, P, I, P, P, P, GP, P],
+    'dsnt_split_bf16x3': [P, P, L, P],
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_bn_stats': [P, P, L, I, P],
     'dsnt_bn_finalize': [P, I, L, I, P, P, P, P, F, F, I, P, P, P, P, P],
@@ -62,12 +64,14 @@ SIGNATURES = {
     'dsnt_pckh': [P, P, P, P, P, P, F, P, P, I, I, P],
     'dsnt_debug_mfma_peak': [P, I, I, I, I, P],
     'dsnt_debug_coexec': [P, I, I, I, P],
+    'dsnt_debug_bf16_peak': [P, I, I, I, I, P],
 }
 # entry points without the status/stream convention
 PLAIN = {
     'dsnt_version': (I, []),
     'dsnt_last_error': (C.c_char_p, []),
     'dsnt_conv_fwd_bm': (I, [GP]),
+    'dsnt_conv_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
     'dsnt_debug_set_timeline': (I, [P, I]),
 }

@@ -48,10 +48,11 @@ class Act:
 
 class ConvParams:
     """Views into the parameter / gradient arenas for one convolution (weights are OHWI)."""
-    __slots__ = ('w', 'b', 'gw', 'gb', 'Cout', 'R', 'S', 'Cin', 'stride', 'pad', 'dil')
+    __slots__ = ('w', 'b', 'gw', 'gb', 'Cout', 'R', 'S', 'Cin', 'stride', 'pad', 'dil', 'wq', 'wq_stride')
 
     def __init__(self, w, b, gw, gb, stride=1, pad=0, dil=1):
         self.w, self.b, self.gw, self.gb = w, b, gw, gb
+        self.wq, self.wq_stride = None, 0      # bf16x6 planes of w (plane 0 view, plane stride)
         self.Cout, self.R, self.S, self.Cin = w.shape
         self.stride, self.pad, self.dil = stride, pad, dil
 
@@ -83,6 +84,9 @@ class Tape:
         self._keep = []         # keeps ctypes structs / tensors alive
         self.lib = _lib.load()
         self.nbytes = 0
+        # fp32-accurate split-bf16 matrix-core path for the large convolutions (DSNT_MFMA=f32 disables)
+        self.use_bf16x6 = os.environ.get('DSNT_MFMA', 'bf16x6') != 'f32'
+        self.bf16x6_min_rows = int(os.environ.get('DSNT_BF16X6_MIN_ROWS', '16384'))
         self.acts = []          # every activation in creation order (debugging / introspection)
 
     # ------------------------------------------------------------------ buffers
@@ -104,6 +108,20 @@ class Tape:
             self.nbytes += t.numel() * 4
             self._scratch[key] = t
         return t
+
+    def scratch_bf16(self, key, numel):
+        t = self._scratch.get(key)
+        if t is None or t.numel() < numel:
+            if t is not None:
+                self._keep.append(t)
+            t = torch.empty(max(numel, 8), device=self.device, dtype=torch.bfloat16)
+            self.nbytes += t.numel() * 2
+            self._scratch[key] = t
+        return t
+
+    def _use6(self, g):
+        return (self.use_bf16x6 and g.N * g.Ho * g.Wo >= self.bf16x6_min_rows and
+                bool(self.lib.dsnt_conv_bf16x6_ok(C.byref(g))))
 
     def act(self, N, H, W, Cc, name=''):
         a = Act(self.empty(N, H, W, Cc), name)
@@ -233,14 +251,18 @@ class Tape:
         sh = src.shift if normed else None
         relu = 1 if (normed and src.relu) else 0
         part = None
+        use6 = self._use6(g) and p.wq is not None
         if want_stats and self.training:
-            bm = self.lib.dsnt_conv_fwd_bm(C.byref(g))
+            bm = 128 if use6 else self.lib.dsnt_conv_fwd_bm(C.byref(g))
             tiles = (y.M + bm - 1) // bm
             part = self.empty(tiles, 2, p.Cout)
             y.stats = (part, tiles)
-        self.f('dsnt_conv_fwd', x.buf, p.w, p.b, y.buf, sc, sh, relu,
-               res1.buf if res1 is not None else None, res2.buf if res2 is not None else None,
-               part, g)
+        r1 = res1.buf if res1 is not None else None
+        r2 = res2.buf if res2 is not None else None
+        if use6:
+            self.f('dsnt_conv_fwd_bf16x6', x.buf, p.wq, p.wq_stride, p.b, y.buf, sc, sh, relu, r1, r2, part, g)
+        else:
+            self.f('dsnt_conv_fwd', x.buf, p.w, p.b, y.buf, sc, sh, relu, r1, r2, part, g)
         if not self.training:
             return y
 
@@ -252,18 +274,28 @@ class Tape:
             self.b('dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws, p.gw, p.gb, 0, g)
             if need_input_grad:
                 assert p.stride == 1, 'data gradient of strided convs is not needed on this path'
-                wd = self.scratch('wdgrad', p.w.numel())
+                nw = p.w.numel()
+                wd = self.scratch('wdgrad', nw)
                 self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
                 gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1,
                               p.dil * (p.R - 1) - p.pad, p.dil)
+                d6 = self._use6(gd) and nw % 8 == 0
+                if d6:
+                    wq = self.scratch_bf16('wdgrad6', 3 * nw)
+                    self.b('dsnt_split_bf16x3', wd, wq, nw)
+
+                def dgrad(out, res):
+                    if d6:
+                        self.b('dsnt_conv_fwd_bf16x6', gy, wq, nw, None, out, None, None, 0, res, None, None, gd)
+                    else:
+                        self.b('dsnt_conv_fwd', gy, wd, None, out, None, None, 0, res, None, None, gd)
                 if normed:
                     da = self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
-                    self.b('dsnt_conv_fwd', gy, wd, None, da, None, None, 0, None, None, None, gd)
+                    dgrad(da, None)
                     self._norm_backward(src, da)
                 else:
                     buf, acc = self.grad_target(x)
-                    self.b('dsnt_conv_fwd', gy, wd, None, buf, None, None, 0,
-                           buf if acc else None, None, None, gd)
+                    dgrad(buf, buf if acc else None)
             # identity branches last: gy is dead after the launches above
             donated = False
             for r in (res1, res2):

@@ -64,6 +64,9 @@ class Arena:
         self.params = torch.zeros(off, device=device, dtype=torch.float32)
         self.grads = torch.zeros(off, device=device, dtype=torch.float32)   # what p.grad views
         self.fresh = torch.zeros(off, device=device, dtype=torch.float32)   # what backward writes
+        # bf16x6 path: the arena split into three bf16 planes, refreshed by ONE launch per step
+        self.planes = torch.zeros(3 * off, device=device, dtype=torch.bfloat16)
+        self.packed_planes = {}
         self.slots = slots
         self.pviews, self.gviews, self.packed, self.packed_fresh = {}, {}, {}, {}
         with torch.no_grad():
@@ -75,6 +78,7 @@ class Arena:
                     store = self.params[o:o + n].view(O, R, S, Ip)
                     store[..., :I].copy_(src.permute(0, 2, 3, 1))
                     self.packed[name] = store
+                    self.packed_planes[name] = self.planes[o:o + n]
                     self.packed_fresh[name] = self.fresh[o:o + n].view(O, R, S, Ip)
                     pv = store.permute(0, 3, 1, 2)[:, :I]
                     gv = self.grads[o:o + n].view(O, R, S, Ip).permute(0, 3, 1, 2)[:, :I]
@@ -145,7 +149,9 @@ class Program:
                 gw = arena.packed_fresh[key(m, 'weight')]
                 b = arena.packed[key(m, 'bias')] if m.bias is not None else None
                 gb = arena.packed_fresh[key(m, 'bias')] if m.bias is not None else None
-                return ConvParams(w, b, gw, gb, m.stride[0], m.padding[0], m.dilation[0])
+                cp = ConvParams(w, b, gw, gb, m.stride[0], m.padding[0], m.dilation[0])
+                cp.wq, cp.wq_stride = arena.packed_planes[key(m, 'weight')], arena.numel
+                return cp
 
             _bn = {}
 
@@ -161,6 +167,8 @@ class Program:
         P._bn = {}
 
         N, Cc, H, W = in_shape
+        if tape.use_bf16x6:
+            tape.f('dsnt_split_bf16x3', arena.params, arena.planes, arena.numel)
         self.in_nchw = tape.empty(N, Cc, H, W)
         x = tape.from_planar(self.in_nchw, _ceil4(Cc), 'input')
         self.in_act = x

@@ -124,6 +124,19 @@ int dsnt_conv_fwd(const float* x, const float* w, const float* bias, float* y,
  * caller sizes stats_partial as [ceil(M/bm)][2][Cout] and hands ceil(M/bm) to dsnt_bn_finalize. */
 int dsnt_conv_fwd_bm(const dsnt_conv_geom* g);
 
+/* bf16x6 variant: fp32-accurate convolution on the bf16 matrix cores.  Operands are split exactly
+ * into three bf16 planes and the six product terms >= 2^-16 are accumulated in fp32 (error below
+ * one fp32 rounding; 6/16 of the fp32-MFMA cost).  `w_planes` points at plane 0 of the OHWI weights
+ * inside a dsnt_split_bf16x3 output; planes are `plane_stride` bf16 elements apart (a multiple of 8;
+ * the whole parameter arena is split with one launch).  Every other argument as dsnt_conv_fwd.  Uses 128-row statistics
+ * tiles.  dsnt_conv_bf16x6_ok(g) != 0 tells whether the geometry is supported. */
+int dsnt_conv_bf16x6_ok(const dsnt_conv_geom* g);
+int dsnt_split_bf16x3(const float* src, void* dst_planes, int64_t n, void* stream);
+int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_t plane_stride, const float* bias, float* y,
+                         const float* in_scale, const float* in_shift, int in_relu,
+                         const float* res1, const float* res2, float* stats_partial,
+                         const dsnt_conv_geom* g, void* stream);
+
 /* Re-pack OHWI weights for the data-gradient pass: wd[Cin][R][S][Cout] with taps flipped,
  * so that dgrad(dy) == dsnt_conv_fwd(dy, wd) with pad' = dil*(R-1) - pad (stride 1). */
 int dsnt_conv_pack_dgrad(const float* w, float* wd, int Cout, int R, int S, int Cin,
@@ -224,6 +237,8 @@ int dsnt_debug_mfma_peak(float* out, int blocks, int threads, int iters, int dep
 int dsnt_debug_set_timeline(long long* buf, int block);
 /* MFMA / VALU co-execution probe (512-thread blocks: 4 MFMA waves + 4 v_fma waves). */
 int dsnt_debug_coexec(float* out, int blocks, int mfma_iters, int valu_iters, void* stream);
+/* bf16 MFMA rate (v_mfma_f32_32x32x16_bf16) and its co-execution with VALU (threads 256 or 512). */
+int dsnt_debug_bf16_peak(float* out, int blocks, int threads, int mfma_iters, int valu_iters, void* stream);
 
 #ifdef __cplusplus
 }

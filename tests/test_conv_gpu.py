@@ -219,3 +219,50 @@ def test_pool_upsample(N, H, W, Cc):
     back = torch.empty(N, 3, H, W, device=dev)
     call('dsnt_nhwc_to_nchw', ptr(nhwc), ptr(back), N, 3, H * W, 4)
     assert torch.equal(back.cpu(), img)
+
+
+BF16X6_CASES = [c for c in CASES if c[3] % 16 == 0 and c[4] % 4 == 0]
+
+
+@pytest.mark.parametrize('case', BF16X6_CASES)
+@pytest.mark.parametrize('pro', [False, True])
+def test_conv_bf16x6_matches_fp32_accuracy(case, pro):
+    """bf16x6 split-precision kernel: same bar as the fp32-MFMA kernel (2e-5 of the output scale vs
+    torch fp32 on the CPU) and an fp64 check that its error is of fp32 size."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    dev = torch.device('cuda:0')
+    tag = 'c' + '_'.join(map(str, case))
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=1)
+    w = synthetic.tensor(tag + 'w', (Cout, Cin, k, k), seed=1, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = synthetic.tensor(tag + 'b', (Cout,), seed=1, scale=0.1)
+    sc = synthetic.tensor(tag + 's', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'h', (Cin,), seed=1, scale=0.3)
+    g = _geom(N, H, W, Cin, Cout, k, k, stride, pad, dil)
+    assert _lib.fn('dsnt_conv_bf16x6_ok')(C.byref(g))
+    act = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if pro else x
+    y32 = F.conv2d(act, w, b, stride=stride, padding=pad, dilation=dil)
+    y64 = F.conv2d(act.double(), w.double(), b.double(), stride=stride, padding=pad, dilation=dil)
+    res = synthetic.tensor(tag + 'r', tuple(y32.shape), seed=1)
+    xd = _nhwc(x).to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    planes = torch.empty(3 * wd.numel(), dtype=torch.bfloat16, device=dev)
+    call('dsnt_split_bf16x3', ptr(wd), ptr(planes), wd.numel())
+    # the split is exact: the three planes add up to the fp32 weights
+    assert torch.equal(planes.view(3, -1).float().sum(0), wd.reshape(-1))
+    bd, scd, shd, resd = b.to(dev), sc.to(dev), sh.to(dev), _nhwc(res).to(dev)
+    y = torch.empty(N, g.Ho, g.Wo, Cout, device=dev)
+    M = N * g.Ho * g.Wo
+    stats = torch.zeros((M + 127) // 128, 2, Cout, device=dev)
+    call('dsnt_conv_fwd_bf16x6', ptr(xd), ptr(planes), wd.numel(), ptr(bd), ptr(y), ptr(scd) if pro else None,
+         ptr(shd) if pro else None, 1, ptr(resd), None, ptr(stats), C.byref(g))
+    got = y.cpu().permute(0, 3, 1, 2)
+    scale = y32.abs().max().item()
+    assert (got - (y32 + res)).abs().max().item() <= 2e-5 * scale
+    err6 = (got.double() - (y64 + res.double())).abs().max().item()
+    err32 = ((y32 + res).double() - (y64 + res.double())).abs().max().item()
+    assert err6 <= max(4 * err32, 2e-6 * scale), (err6, err32)
+    yd = (y32 + res).permute(0, 2, 3, 1).reshape(M, Cout).double()
+    s = stats.cpu().double().sum(0)
+    assert (s[0] - yd.sum(0)).abs().max().item() <= 1e-4 * max(1.0, yd.sum(0).abs().max().item())

@@ -15,6 +15,24 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+@pytest.fixture(params=['f32', 'bf16x6'], autouse=True)
+def mfma_path(request, monkeypatch):
+    """Every model-level parity test runs twice: convolutions on the fp32 MFMA, and on the
+    split-bf16 (bf16x6) matrix-core path forced on for ALL eligible convolutions (in production
+    it is used from 16384 output rows up, which the small oracle-sized batches never reach)."""
+    if request.param == 'f32':
+        monkeypatch.setenv('DSNT_MFMA', 'f32')
+    else:
+        monkeypatch.setenv('DSNT_MFMA', 'bf16x6')
+        monkeypatch.setenv('DSNT_BF16X6_MIN_ROWS', '0')
+    return request.param
+
+
+def _count_launches(module, name):
+    progs = module._runner().programs.values()
+    return sum(1 for p in progs for (_, _, n) in p.tape.fwd + p.tape.bwd if n == name)
+
+
 def _rel_l2(got, want, floor=0.0):
     return (got.double() - want.double()).norm().item() / max(want.double().norm().item(), floor, 1e-30)
 
@@ -112,7 +130,7 @@ def test_blocks_vs_golden_and_oracle(kind, smooth):
 @pytest.mark.parametrize('base,size,reg,tag', [('hg1', 128, 'none', 'hg1_128'),
                                                ('hg2', 128, 'js', 'hg2_128'),
                                                ('hg2', 256, 'js', 'hg2_256')])
-def test_end_to_end_vs_golden(base, size, reg, tag):
+def test_end_to_end_vs_golden(base, size, reg, tag, mfma_path):
     """Golden vectors made from the reference: coords (bar 1e-4), loss, heat-maps, running
     statistics, eval-mode coords; gradient norms flip-tolerantly (see _NoRelu)."""
     from dsnt.model import build_mpii_pose_model
@@ -154,6 +172,8 @@ def test_end_to_end_vs_golden(base, size, reg, tag):
     with torch.no_grad():
         ev = m(x)[-1].cpu().numpy()
     assert np.abs(ev - g['eval_coords']).max() <= 1e-4
+    n6 = _count_launches(m.hg, 'dsnt_conv_fwd_bf16x6')
+    assert (n6 > 100) if mfma_path == 'bf16x6' else (n6 == 0)
 
 
 @pytest.mark.parametrize('smooth', [True, False])
