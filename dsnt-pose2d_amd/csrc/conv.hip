@@ -853,6 +853,43 @@ extern "C" int dsnt_conv_pack_dgrad(const float* w, float* wd, int Cout, int R, 
     DSNT_CHECK_LAUNCH("dsnt_conv_pack_dgrad");
 }
 
+// All data-gradient weight packs of a backward pass in ONE launch: for conv c (table row c =
+// {src offset, dst offset, Cout, R, S, Cin}) write wd[ci][R-1-r][S-1-s][co] = w[co][r][s][ci] as fp32
+// and as three bf16 planes (plane stride = `total` elements).
+__global__ void pack_dgrad_all_kernel(const int* __restrict__ table, const float* __restrict__ params,
+                                      float* __restrict__ out, unsigned short* __restrict__ planes, long total) {
+    const int* t = table + blockIdx.y * 6;
+    const int src = t[0], dst = t[1], Cout = t[2], R = t[3], S = t[4], Cin = t[5];
+    const int n = Cout * R * S * Cin;
+    const float* w = params + src;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int co = i % Cout;
+        int q = i / Cout;
+        const int s_ = q % S; q /= S;
+        const int r = q % R;
+        const int ci = q / R;
+        const float v = w[((co * R + (R - 1 - r)) * S + (S - 1 - s_)) * Cin + ci];
+        out[dst + i] = v;
+        // exact 3-way bf16 split (round-to-nearest-even by hand: one scalar at a time)
+        float rem = v;
+        for (int pl = 0; pl < 3; ++pl) {
+            unsigned u = __float_as_uint(rem);
+            unsigned rb = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+            planes[(long)pl * total + dst + i] = (unsigned short)(rb >> 16);
+            rem -= __uint_as_float(rb);
+        }
+    }
+}
+
+extern "C" int dsnt_conv_pack_dgrad_all(const int* table, int nconv, const float* params, float* out,
+                                        void* planes, int64_t total, void* stream) {
+    DSNT_REQUIRE(table && params && out && planes && nconv > 0 && total > 0, DSNT_ERR_ARG,
+                 "dsnt_conv_pack_dgrad_all: bad argument");
+    hipLaunchKernelGGL(pack_dgrad_all_kernel, dim3(64, nconv), dim3(256), 0, (hipStream_t)stream, table, params,
+                       out, (unsigned short*)planes, (long)total);
+    DSNT_CHECK_LAUNCH("dsnt_conv_pack_dgrad_all");
+}
+
 // ------------------------------------------------------------------------------------------
 // Weight gradient.  GEMM view: D[k][n] = sum_m A[m][k] * G[m][n], tile 128(k) x 128(n),
 // m consumed 32 rows per step.  Both LDS tiles are [32 m][128] row-major; the MFMA operands are
@@ -1060,6 +1097,215 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
+// bf16x6 weight gradient: D[k][n] = sum_m A[m][k] G[m][n] on the bf16 matrix cores (see the
+// forward bf16x6 kernel for the numerics).  The reduction index of the MFMA is m, so both LDS tiles
+// are stored transposed ([k][m] and [n][m], m contiguous): a loader thread owns a 4(m) x 4(k or n)
+// block, loads four rows, applies BN+ReLU / zero padding (A only), splits and packs pairs of ROWS with
+// v_cvt_pk_bf16_f32, i.e. the transpose costs no extra instruction.  128 threads stage A, 128 stage G;
+// waves 0..3 run the MFMAs (64 x 64 of the 128 x 128 tile each), one barrier per 16 rows of m.
+template <bool PRO>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* At = reinterpret_cast<__bf16*>(smem);            // [2][3][128][PITCH6]
+    __bf16* Gt = At + 2 * 3 * 128 * PITCH6;                  // [2][3][128][PITCH6]
+
+    int bid = blockIdx.x;
+    const int ktile = bid % p.ktiles; bid /= p.ktiles;
+    const int ntile = bid % p.ntiles;
+    const int split = bid / p.ntiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nsteps = (m_end - m_begin + 15) / 16;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int ltid = tid - 256;
+        const bool isA = ltid < 128;
+        const int q = ltid & 31, mb = (ltid >> 5) & 3;       // 4-wide column chunk, 4-row block
+        const unsigned OOB = 0xF0000000u;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.dy), 0, (int)((size_t)p.M * p.Cout * 4u), 0x00020000);
+        // A side: fixed tap / channel chunk
+        const int k0 = ktile * 128 + q * 4;
+        const bool vk = k0 < p.K;
+        const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
+        const int r = tap / p.S, s_ = tap - r * p.S;
+        const int dh = r * p.dil - p.pad, dw = s_ * p.dil - p.pad;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRO && isA && vk) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + c);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + c);
+        }
+        // G side
+        const int n0 = ntile * 128 + q * 4;
+        const bool vn = n0 < p.Cout;
+        // first row of this thread's 4-row block (Wo % 4 == 0: the 4 rows share n and oh)
+        const int HoWo = p.Ho * p.Wo;
+        int rm = m_begin + mb * 4;
+        const int mm0 = rm < p.M ? rm : 0;
+        int rn = mm0 / HoWo;
+        int roh = (mm0 - rn * HoWo) / p.Wo;
+        int row_ = mm0 - rn * HoWo - roh * p.Wo;
+        const int adv_h = 16 / p.Wo, adv_w = 16 - adv_h * p.Wo;
+        struct Stage { u32x4 v[4]; unsigned ok; };
+        Stage S0, S1;
+        auto gload = [&](Stage& st) {
+            st.ok = 0;
+            if (isA) {
+                const int ih = roh * p.stride + dh;
+                const bool vrow = vk && ih >= 0 && ih < p.H;
+                const int base = ((rn * p.H + ih) * p.W) * p.Cin + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int iw = (row_ + j) * p.stride + dw;
+                    const bool ok = vrow && (rm + j) < m_end && iw >= 0 && iw < p.W;
+                    st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)(base + iw * p.Cin) * 4u : OOB, 0, 0);
+                    st.ok |= (ok ? 1u : 0u) << j;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = vn && (rm + j) < m_end;
+                    st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(gr, ok ? (unsigned)((rm + j) * p.Cout + n0) * 4u : OOB, 0, 0);
+                }
+            }
+            rm += 16;
+            row_ += adv_w; roh += adv_h;
+            if (row_ >= p.Wo) { row_ -= p.Wo; roh += 1; }
+            while (roh >= p.Ho) { roh -= p.Ho; rn += 1; }
+        };
+        auto lstore = [&](const Stage& st, int buf) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = make_float4(__uint_as_float(st.v[j].x), __uint_as_float(st.v[j].y),
+                                   __uint_as_float(st.v[j].z), __uint_as_float(st.v[j].w));
+                if (isA) {
+                    if (PRO) {
+                        v[j].x = fmaf(v[j].x, sc.x, sh.x); v[j].y = fmaf(v[j].y, sc.y, sh.y);
+                        v[j].z = fmaf(v[j].z, sc.z, sh.z); v[j].w = fmaf(v[j].w, sc.w, sh.w);
+                        if (p.in_relu) {
+                            v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f);
+                            v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
+                        }
+                        if (!((st.ok >> j) & 1u)) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+                    bsum.x += v[j].x; bsum.y += v[j].y; bsum.z += v[j].z; bsum.w += v[j].w;
+                }
+            }
+            __bf16* base = (isA ? At : Gt) + ((size_t)(buf * 3) * 128 + q * 4) * PITCH6 + mb * 4;
+            // component e of the four rows -> LDS row (q*4 + e), columns mb*4 .. mb*4+3, three planes
+#define SPLIT_COL(E, COMP)                                                                           \
+            {                                                                                        \
+                uint2 q1, q2, q3;                                                                    \
+                split4(make_float4(v[0].COMP, v[1].COMP, v[2].COMP, v[3].COMP), q1, q2, q3);        \
+                __bf16* d = base + (E) * PITCH6;                                                     \
+                *reinterpret_cast<uint2*>(d) = q1;                                                   \
+                *reinterpret_cast<uint2*>(d + 128 * PITCH6) = q2;                                    \
+                *reinterpret_cast<uint2*>(d + 2 * 128 * PITCH6) = q3;                                \
+            }
+            SPLIT_COL(0, x) SPLIT_COL(1, y) SPLIT_COL(2, z) SPLIT_COL(3, w)
+#undef SPLIT_COL
+        };
+        if (nsteps > 0) gload(S0);
+        if (nsteps > 1) gload(S1);
+        if (nsteps > 0) lstore(S0, 0);
+        if (nsteps > 2) gload(S0);
+        __syncthreads();
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            lstore(S1, 1);
+            if (s + 3 < nsteps) gload(S1);
+            __syncthreads();
+            if (s + 2 < nsteps) {
+                lstore(S0, 0);
+                if (s + 4 < nsteps) gload(S0);
+            }
+            __syncthreads();
+        }
+        if (s < nsteps) __syncthreads();
+    } else {
+        // ------------------------------------------------------------------ MFMA waves
+        const int wk = wave >> 1, wn = wave & 1;
+        struct Frag { bf16x8 a[2][3], b[2][3]; };
+        Frag F;
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int buf = s & 1;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    F.a[t][pl] = *reinterpret_cast<const bf16x8*>(
+                        At + ((size_t)(buf * 3 + pl) * 128 + wk * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
+                    F.b[t][pl] = *reinterpret_cast<const bf16x8*>(
+                        Gt + ((size_t)(buf * 3 + pl) * 128 + wn * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][2], F.b[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][0], acc[a][b], 0, 0, 0);
+                }
+            __syncthreads();
+        }
+        // slab store: ws[split][n][k], D row = k (regs, 4 consecutive), D col = n (lane)
+        float* slab = p.ws + (size_t)split * p.Cout * p.K;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = ntile * 128 + wn * 64 + b * 32 + lr;
+            if (n >= p.Cout) continue;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int k = ktile * 128 + wk * 64 + a * 32 + 8 * qq + 4 * lh;
+                    if (k < p.K)
+                        *reinterpret_cast<float4*>(slab + (size_t)n * p.K + k) =
+                            make_float4(acc[a][b][4 * qq + 0], acc[a][b][4 * qq + 1], acc[a][b][4 * qq + 2],
+                                        acc[a][b][4 * qq + 3]);
+                }
+        }
+    }
+    // bias partial: column sums of this split's dY rows (G loader threads of the ktile-0 blocks)
+    if (ktile == 0) {
+        float* red = smem;   // [4][128] floats
+        __syncthreads();
+        if (wave >= 6) {
+            const int ltid = tid - 384;
+            *reinterpret_cast<float4*>(red + (ltid >> 5) * 128 + (ltid & 31) * 4) = bsum;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int n = ntile * 128 + tid;
+            if (n < p.Cout)
+                p.ws[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + n] =
+                    red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+        }
+    }
+}
+
 // Slab reduction: 64 float4 columns x 4 split-lanes per block, 8 loads in flight per thread.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                             float* __restrict__ dbias, int splits, int CK, int Cout,
@@ -1136,9 +1382,34 @@ extern "C" int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g) {
     return (int64_t)sp * g->Cout * (g->R * g->S * g->Cin) + (int64_t)sp * g->Cout;
 }
 
+static int conv_wgrad_impl(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                           const float* dy, float* ws, float* dw, float* dbias, int accumulate,
+                           const dsnt_conv_geom* g, void* stream, bool bf16x6);
+
 extern "C" int dsnt_conv_wgrad(const float* x, const float* in_scale, const float* in_shift,
                                int in_relu, const float* dy, float* ws, float* dw, float* dbias,
                                int accumulate, const dsnt_conv_geom* g, void* stream) {
+    return conv_wgrad_impl(x, in_scale, in_shift, in_relu, dy, ws, dw, dbias, accumulate, g, stream, false);
+}
+
+extern "C" int dsnt_conv_wgrad_bf16x6_ok(const dsnt_conv_geom* g) {
+    if (!g) return 0;
+    return g->Cin % 4 == 0 && g->Cout % 4 == 0 && g->Wo % 4 == 0 &&
+           (size_t)g->N * g->H * g->W * g->Cin * 4u < (1ull << 31) &&
+           (size_t)g->N * g->Ho * g->Wo * g->Cout * 4u < (1ull << 31);
+}
+
+extern "C" int dsnt_conv_wgrad_bf16x6(const float* x, const float* in_scale, const float* in_shift,
+                                      int in_relu, const float* dy, float* ws, float* dw, float* dbias,
+                                      int accumulate, const dsnt_conv_geom* g, void* stream) {
+    DSNT_REQUIRE(dsnt_conv_wgrad_bf16x6_ok(g), DSNT_ERR_SHAPE,
+                 "dsnt_conv_wgrad_bf16x6: geometry not supported (need Wo %% 4 == 0, tensors < 2 GiB)");
+    return conv_wgrad_impl(x, in_scale, in_shift, in_relu, dy, ws, dw, dbias, accumulate, g, stream, true);
+}
+
+static int conv_wgrad_impl(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                           const float* dy, float* ws, float* dw, float* dbias, int accumulate,
+                           const dsnt_conv_geom* g, void* stream, bool bf16x6) {
     if (int e = check_geom(g, "dsnt_conv_wgrad")) return e;
     DSNT_REQUIRE(x && dy && ws && dw, DSNT_ERR_ARG, "dsnt_conv_wgrad: null tensor");
     DSNT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DSNT_ERR_ARG,
@@ -1155,7 +1426,17 @@ extern "C" int dsnt_conv_wgrad(const float* x, const float* in_scale, const floa
     wgrad_plan(g, p.ktiles, p.ntiles, p.splits, p.rows_per_split);
     hipStream_t st = (hipStream_t)stream;
     const int grid = p.ktiles * p.ntiles * p.splits;
-    if (in_scale)
+    if (bf16x6) {
+        const int lds = 2 * 2 * 3 * 128 * PITCH6 * 2;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_done = true;
+        }
+        if (in_scale) hipLaunchKernelGGL(conv_wgrad_bf16x6_kernel<true>, dim3(grid), dim3(512), lds, st, p);
+        else hipLaunchKernelGGL(conv_wgrad_bf16x6_kernel<false>, dim3(grid), dim3(512), lds, st, p);
+    } else if (in_scale)
         hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(grid), dim3(256), 0, st, p);

@@ -43,9 +43,11 @@ SIGNATURES = {
     'dsnt_head_bwd': [P, P, P, P, P, P, P, L, I, I, F, I, P],
     'dsnt_conv_fwd': [P, P, P, P, P, P, I, P, P, P, GP, P],
     'dsnt_conv_pack_dgrad': [P, P, I, I, I, I, P],
+    'dsnt_conv_pack_dgrad_all': [P, I, P, P, P, L, P],
     'dsnt_conv_fwd_bf16x6': [P, P, L, P, P, P, P, I, P, P, P, GP, P],
     'dsnt_split_bf16x3': [P, P, L, P],
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
+    'dsnt_conv_wgrad_bf16x6': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_bn_stats': [P, P, L, I, P],
     'dsnt_bn_finalize': [P, I, L, I, P, P, P, P, F, F, I, P, P, P, P, P],
     'dsnt_bn_act_fwd': [P, P, P, I, P, L, I, P],
@@ -72,6 +74,7 @@ PLAIN = {
     'dsnt_last_error': (C.c_char_p, []),
     'dsnt_conv_fwd_bm': (I, [GP]),
     'dsnt_conv_bf16x6_ok': (I, [GP]),
+    'dsnt_conv_wgrad_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
     'dsnt_debug_set_timeline': (I, [P, I]),
 }

@@ -88,6 +88,11 @@ class Tape:
         self.use_bf16x6 = os.environ.get('DSNT_MFMA', 'bf16x6') != 'f32'
         self.bf16x6_min_rows = int(os.environ.get('DSNT_BF16X6_MIN_ROWS', '16384'))
         self.acts = []          # every activation in creation order (debugging / introspection)
+        self.dgrad_slots = []   # (conv params, dst offset) of every conv whose data gradient is needed
+        self.dgrad_total = 0
+        self.dgrad_f32 = None
+        self.dgrad_planes = None
+        self.param_arena = None  # flat fp32 parameter arena (set by the Program) for the one-launch pack
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float32):
@@ -153,6 +158,20 @@ class Tape:
 
     def finish(self):
         """Emit the backward list (reverse order of the forward ops)."""
+        if self.dgrad_slots:
+            # one launch re-packs (tap-flipped, transposed) and bf16-splits every dgrad weight
+            total = (self.dgrad_total + 7) // 8 * 8
+            self.dgrad_f32 = self.empty(total)
+            self.dgrad_planes = self.empty(3 * total, dtype=torch.bfloat16)
+            rows = []
+            for p, dst in self.dgrad_slots:
+                src = (p.w.data_ptr() - self.param_arena.data_ptr()) // 4
+                rows.append([src, dst, p.Cout, p.R, p.S, p.Cin])
+            table = torch.tensor(rows, dtype=torch.int32).to(self.device)
+            self._keep.append(table)
+            self.b('dsnt_conv_pack_dgrad_all', table, len(rows), self.param_arena, self.dgrad_f32,
+                   self.dgrad_planes, total)
+            self.dgrad_total = total
         for fn in reversed(self._bwd_emitters):
             fn()
         self._bwd_emitters = []
@@ -265,28 +284,40 @@ class Tape:
             self.f('dsnt_conv_fwd', x.buf, p.w, p.b, y.buf, sc, sh, relu, r1, r2, part, g)
         if not self.training:
             return y
+        slot = None
+        if need_input_grad and self.param_arena is not None:
+            slot = self.dgrad_total
+            self.dgrad_slots.append((p, slot))
+            self.dgrad_total += (p.w.numel() + 7) // 8 * 8
 
         def backward():
             gy = y.grad
             assert gy is not None, 'no gradient reached conv output ' + name
             # parameter gradients (flat arena, overwritten every step)
             ws = self.scratch('wgrad', self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g)))
-            self.b('dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws, p.gw, p.gb, 0, g)
+            w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
+            self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
+                   p.gw, p.gb, 0, g)
             if need_input_grad:
                 assert p.stride == 1, 'data gradient of strided convs is not needed on this path'
                 nw = p.w.numel()
-                wd = self.scratch('wdgrad', nw)
-                self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
                 gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1,
                               p.dil * (p.R - 1) - p.pad, p.dil)
-                d6 = self._use6(gd) and nw % 8 == 0
-                if d6:
-                    wq = self.scratch_bf16('wdgrad6', 3 * nw)
-                    self.b('dsnt_split_bf16x3', wd, wq, nw)
+                if slot is not None:
+                    wd = self.dgrad_f32[slot:slot + nw]
+                    wq, wq_stride = self.dgrad_planes[slot:slot + nw], self.dgrad_total
+                    d6 = self._use6(gd)
+                else:       # stand-alone use without a parameter arena
+                    wd = self.scratch('wdgrad', nw)
+                    self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
+                    d6 = self._use6(gd) and nw % 8 == 0
+                    if d6:
+                        wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
+                        self.b('dsnt_split_bf16x3', wd, wq, nw)
 
                 def dgrad(out, res):
                     if d6:
-                        self.b('dsnt_conv_fwd_bf16x6', gy, wq, nw, None, out, None, None, 0, res, None, None, gd)
+                        self.b('dsnt_conv_fwd_bf16x6', gy, wq, wq_stride, None, out, None, None, 0, res, None, None, gd)
                     else:
                         self.b('dsnt_conv_fwd', gy, wd, None, out, None, None, 0, res, None, None, gd)
                 if normed:

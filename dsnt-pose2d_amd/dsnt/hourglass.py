@@ -135,6 +135,7 @@ class Program:
         self.token = 0
         dev = arena.device
         tape = Tape(dev, training)
+        tape.param_arena = arena.params
         self.tape = tape
         names = {id(m): n for n, m in root.named_modules()}
 

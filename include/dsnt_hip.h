@@ -142,6 +142,12 @@ int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_t plane_str
 int dsnt_conv_pack_dgrad(const float* w, float* wd, int Cout, int R, int S, int Cin,
                          void* stream);
 
+/* The same for every convolution of a backward pass in one launch.  table[nconv][6] (device, int32) =
+ * {src offset into params, dst offset, Cout, R, S, Cin}; writes fp32 into out[dst..] and the exact
+ * bf16x3 split into planes (plane stride = total elements). */
+int dsnt_conv_pack_dgrad_all(const int* table, int nconv, const float* params, float* out,
+                             void* planes, int64_t total, void* stream);
+
 /* Weight / bias gradient: dw[Cout][R][S][Cin] = sum_m act(x)[m, (r,s,c)] * dy[m, cout],
  * dbias[cout] = sum_m dy.  `ws` is caller workspace of dsnt_conv_wgrad_ws_floats() floats.
  * accumulate != 0 adds into dw/dbias instead of overwriting. */
@@ -149,6 +155,13 @@ int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g);
 int dsnt_conv_wgrad(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                     const float* dy, float* ws, float* dw, float* dbias, int accumulate,
                     const dsnt_conv_geom* g, void* stream);
+
+/* bf16x6 variant of the weight gradient (same arguments and workspace; both operands are split into
+ * bf16 planes while they are staged).  dsnt_conv_wgrad_bf16x6_ok(g) != 0 if supported. */
+int dsnt_conv_wgrad_bf16x6_ok(const dsnt_conv_geom* g);
+int dsnt_conv_wgrad_bf16x6(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                           const float* dy, float* ws, float* dw, float* dbias, int accumulate,
+                           const dsnt_conv_geom* g, void* stream);
 
 /* ----------------------------------------------------- batch-norm, elementwise
  * x viewed as [M][C] (M = N*H*W), C % 4 == 0. */

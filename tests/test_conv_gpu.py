@@ -266,3 +266,38 @@ def test_conv_bf16x6_matches_fp32_accuracy(case, pro):
     yd = (y32 + res).permute(0, 2, 3, 1).reshape(M, Cout).double()
     s = stats.cpu().double().sum(0)
     assert (s[0] - yd.sum(0)).abs().max().item() <= 1e-4 * max(1.0, yd.sum(0).abs().max().item())
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[3] % 4 == 0 and c[4] % 4 == 0])
+@pytest.mark.parametrize('pro', [False, True])
+def test_wgrad_bf16x6(case, pro):
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    dev = torch.device('cuda:0')
+    tag = 'c' + '_'.join(map(str, case))
+    g = _geom(N, H, W, Cin, Cout, k, k, stride, pad, dil)
+    if not _lib.fn('dsnt_conv_wgrad_bf16x6_ok')(C.byref(g)):
+        pytest.skip('geometry not supported by the bf16x6 weight gradient (Wo % 4 != 0)')
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=1)
+    sc = synthetic.tensor(tag + 's', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'h', (Cin,), seed=1, scale=0.3)
+    act = (F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if pro else x).double()
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(act, w, b, stride=stride, padding=pad, dilation=dil)
+    gy = synthetic.tensor(tag + 'g', tuple(y.shape), seed=2)
+    y.backward(gy.double())
+    xd, gyd, scd, shd = _nhwc(x).to(dev), _nhwc(gy).to(dev), sc.to(dev), sh.to(dev)
+    ws = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev)
+    dw6, dw32 = torch.empty(Cout, k, k, Cin, device=dev), torch.empty(Cout, k, k, Cin, device=dev)
+    db6, db32 = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+    args = (ptr(xd), ptr(scd) if pro else None, ptr(shd) if pro else None, 1, ptr(gyd), ptr(ws))
+    call('dsnt_conv_wgrad_bf16x6', *args, ptr(dw6), ptr(db6), 0, C.byref(g))
+    call('dsnt_conv_wgrad', *args, ptr(dw32), ptr(db32), 0, C.byref(g))
+    ref = w.grad.permute(0, 2, 3, 1)
+    scale = max(1.0, ref.abs().max().item())
+    e6 = (dw6.cpu().double() - ref).abs().max().item()
+    e32 = (dw32.cpu().double() - ref).abs().max().item()
+    assert e6 <= 3e-5 * scale and e6 <= max(4 * e32, 2e-6 * scale), (e6, e32)
+    assert (db6.cpu().double() - b.grad).abs().max().item() <= 3e-5 * max(1.0, b.grad.abs().max().item())

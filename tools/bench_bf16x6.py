@@ -33,3 +33,17 @@ for (H, Cin, Cout, k) in shapes:
         err = (y - y6).abs().max().item() / y.abs().max().item()
         print('H%3d %3d->%3d k%d pro=%d | fp32 %7.1f us %6.1f TF | bf16x6 %7.1f us %6.1f TF-equiv | x%.2f | rel diff %.1e' % (
             H, Cin, Cout, k, pro, t32 * 1e6, flops / t32 / 1e12, t6 * 1e6, flops / t6 / 1e12, t32 / t6, err))
+
+print('--- wgrad')
+for (H, Cin, Cout, k) in shapes:
+    g = ConvGeom(B, H, H, Cin, H, H, Cout, k, k, 1, k // 2, 1)
+    M = B * H * H; K = k * k * Cin
+    x = torch.randn(B, H, H, Cin, device=dev); gy = torch.randn(B, H, H, Cout, device=dev)
+    sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
+    ws = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev)
+    dw = torch.empty(Cout, k, k, Cin, device=dev); dw6 = torch.empty_like(dw); db = torch.empty(Cout, device=dev)
+    flops = 2.0 * M * K * Cout
+    t32 = timeit(_lib.fn('dsnt_conv_wgrad'), (ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), ptr(dw), ptr(db), 0, C.byref(g)))
+    t6 = timeit(_lib.fn('dsnt_conv_wgrad_bf16x6'), (ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), ptr(dw6), ptr(db), 0, C.byref(g)))
+    print('H%3d %3d->%3d k%d | fp32 %7.1f us %6.1f TF | bf16x6 %7.1f us %6.1f TF-equiv | x%.2f | rel diff %.1e' % (
+        H, Cin, Cout, k, t32 * 1e6, flops / t32 / 1e12, t6 * 1e6, flops / t6 / 1e12, t32 / t6, (dw - dw6).abs().max().item() / dw.abs().max().item()))
