@@ -29,6 +29,10 @@ struct ConvP {
     const float* res1; const float* res2; float* stats;
     const unsigned short* wq;      // bf16x6 path: plane 0 of the weights; planes are `wq_stride` elements apart
     long wq_stride;
+    // optional batch-norm-backward epilogue (data-gradient launches): y = dz = acc * [bn(x) > 0],
+    // stats = per-tile (sum dz, sum dz*xhat); the BN input x is passed through res1
+    const float* bnb_scale; const float* bnb_shift; const float* bnb_mean; const float* bnb_invstd;
+    int bnb_relu;
     int in_relu;
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil;
     int M, K, mtiles, ntiles;
@@ -91,6 +95,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
     const bool vn = n0 < p.Cout;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && vn) bias4 = *reinterpret_cast<const float4*>(p.bias + n0);
+    const bool bnb = p.bnb_scale != nullptr;
+    float4 bsc = bias4, bsh = bias4, bmu = bias4, bis = bias4;
+    if (bnb && vn) {
+        bsc = *reinterpret_cast<const float4*>(p.bnb_scale + n0);
+        bsh = *reinterpret_cast<const float4*>(p.bnb_shift + n0);
+        bmu = *reinterpret_cast<const float4*>(p.bnb_mean + n0);
+        bis = *reinterpret_cast<const float4*>(p.bnb_invstd + n0);
+    }
     float4 r1[NP], r2[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -107,6 +119,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const int m = mtile * BM + row;
         if (vn && m < p.M) {
             float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + ch * 4);
+            if (bnb) {
+                // v = dL/d relu(bn(x)); r1[j] = x: mask by the ReLU, accumulate the BN-backward sums
+                const float4 xv = r1[j];
+                if (p.bnb_relu) {
+                    if (fmaf(xv.x, bsc.x, bsh.x) <= 0.f) v.x = 0.f;
+                    if (fmaf(xv.y, bsc.y, bsh.y) <= 0.f) v.y = 0.f;
+                    if (fmaf(xv.z, bsc.z, bsh.z) <= 0.f) v.z = 0.f;
+                    if (fmaf(xv.w, bsc.w, bsh.w) <= 0.f) v.w = 0.f;
+                }
+                *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n0) = v;
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x = fmaf(v.x, (xv.x - bmu.x) * bis.x, s2.x); s2.y = fmaf(v.y, (xv.y - bmu.y) * bis.y, s2.y);
+                s2.z = fmaf(v.z, (xv.z - bmu.z) * bis.z, s2.z); s2.w = fmaf(v.w, (xv.w - bmu.w) * bis.w, s2.w);
+                continue;
+            }
             v.x += bias4.x + r1[j].x + r2[j].x; v.y += bias4.y + r1[j].y + r2[j].y;
             v.z += bias4.z + r1[j].z + r2[j].z; v.w += bias4.w + r1[j].w + r2[j].w;
             *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n0) = v;
@@ -750,11 +777,15 @@ static int check_geom(const dsnt_conv_geom* g, const char* who) {
     return DSNT_OK;
 }
 
-extern "C" int dsnt_conv_fwd(const float* x, const float* w, const float* bias, float* y,
-                             const float* in_scale, const float* in_shift, int in_relu,
-                             const float* res1, const float* res2, float* stats_partial,
-                             const dsnt_conv_geom* g, void* stream) {
+static int conv_fwd_impl(const float* x, const float* w, const float* bias, float* y,
+                         const float* in_scale, const float* in_shift, int in_relu,
+                         const float* res1, const float* res2, float* stats_partial,
+                         const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, void* stream) {
     if (int e = check_geom(g, "dsnt_conv_fwd")) return e;
+    DSNT_REQUIRE(!g_bnb || (g_bnb->x && g_bnb->scale && g_bnb->shift && g_bnb->mean && g_bnb->invstd &&
+                            stats_partial && !res1 && !res2 && !bias), DSNT_ERR_ARG,
+                 "dsnt_conv_fwd_ex: the batch-norm-backward epilogue needs x/scale/shift/mean/invstd and "
+                 "stats_partial, and excludes bias/residuals");
     DSNT_REQUIRE(x && w && y, DSNT_ERR_ARG, "dsnt_conv_fwd: null tensor");
     DSNT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DSNT_ERR_ARG,
                  "dsnt_conv_fwd: in_scale/in_shift must be given together");
@@ -764,6 +795,11 @@ extern "C" int dsnt_conv_fwd(const float* x, const float* w, const float* bias, 
     ConvP p;
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift;
     p.res1 = res1; p.res2 = res2; p.stats = stats_partial; p.in_relu = in_relu; p.wq = nullptr; p.wq_stride = 0;
+    p.bnb_scale = p.bnb_shift = p.bnb_mean = p.bnb_invstd = nullptr; p.bnb_relu = 0;
+    if (g_bnb) {
+        p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
+        p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
+    }
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
@@ -777,6 +813,20 @@ extern "C" int dsnt_conv_fwd(const float* x, const float* w, const float* bias, 
     else if (BM == 128 && BN == 32) launch_fwd<4, 1, 1, 1>(p, pro, st);
     else launch_fwd<1, 4, 1, 1>(p, pro, st);
     DSNT_CHECK_LAUNCH("dsnt_conv_fwd");
+}
+
+extern "C" int dsnt_conv_fwd(const float* x, const float* w, const float* bias, float* y,
+                             const float* in_scale, const float* in_shift, int in_relu,
+                             const float* res1, const float* res2, float* stats_partial,
+                             const dsnt_conv_geom* g, void* stream) {
+    return conv_fwd_impl(x, w, bias, y, in_scale, in_shift, in_relu, res1, res2, stats_partial, g, nullptr, stream);
+}
+
+extern "C" int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y,
+                                const float* in_scale, const float* in_shift, int in_relu,
+                                const float* res1, const float* res2, float* stats_partial,
+                                const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream) {
+    return conv_fwd_impl(x, w, bias, y, in_scale, in_shift, in_relu, res1, res2, stats_partial, g, bnb, stream);
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -798,11 +848,15 @@ static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
     else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false>), gr, bl, lds, st, p);
 }
 
-extern "C" int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_t plane_stride, const float* bias, float* y,
-                                    const float* in_scale, const float* in_shift, int in_relu,
-                                    const float* res1, const float* res2, float* stats_partial,
-                                    const dsnt_conv_geom* g, void* stream) {
+static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_stride, const float* bias, float* y,
+                          const float* in_scale, const float* in_shift, int in_relu,
+                          const float* res1, const float* res2, float* stats_partial,
+                          const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, void* stream) {
     if (int e = check_geom(g, "dsnt_conv_fwd_bf16x6")) return e;
+    DSNT_REQUIRE(!g_bnb || (g_bnb->x && g_bnb->scale && g_bnb->shift && g_bnb->mean && g_bnb->invstd &&
+                            stats_partial && !res1 && !res2 && !bias), DSNT_ERR_ARG,
+                 "dsnt_conv_fwd_bf16x6_ex: the batch-norm-backward epilogue needs x/scale/shift/mean/invstd "
+                 "and stats_partial, and excludes bias/residuals");
     DSNT_REQUIRE(x && w_planes && y, DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6: null tensor");
     DSNT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DSNT_ERR_ARG,
                  "dsnt_conv_fwd_bf16x6: in_scale/in_shift must be given together");
@@ -817,6 +871,11 @@ extern "C" int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_
     p.x = x; p.w = nullptr; p.wq = (const unsigned short*)w_planes; p.wq_stride = plane_stride; p.bias = bias; p.y = y;
     p.in_scale = in_scale; p.in_shift = in_shift; p.res1 = res1; p.res2 = res2; p.stats = stats_partial;
     p.in_relu = in_relu;
+    p.bnb_scale = p.bnb_shift = p.bnb_mean = p.bnb_invstd = nullptr; p.bnb_relu = 0;
+    if (g_bnb) {
+        p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
+        p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
+    }
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
@@ -826,6 +885,22 @@ extern "C" int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_
     if (BN == 128) launch_fwd6<2, 2, 2, 2>(p, in_scale != nullptr, st);
     else launch_fwd6<2, 2, 2, 1>(p, in_scale != nullptr, st);
     DSNT_CHECK_LAUNCH("dsnt_conv_fwd_bf16x6");
+}
+
+extern "C" int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_t plane_stride, const float* bias, float* y,
+                                    const float* in_scale, const float* in_shift, int in_relu,
+                                    const float* res1, const float* res2, float* stats_partial,
+                                    const dsnt_conv_geom* g, void* stream) {
+    return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
+                          stats_partial, g, nullptr, stream);
+}
+
+extern "C" int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* bias,
+                                       float* y, const float* in_scale, const float* in_shift, int in_relu,
+                                       const float* res1, const float* res2, float* stats_partial,
+                                       const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream) {
+    return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
+                          stats_partial, g, bnb, stream);
 }
 
 // wd[ci][R-1-r][S-1-s][co] = w[co][r][s][ci]

@@ -25,6 +25,14 @@ class ConvGeom(C.Structure):
 
 GP = C.POINTER(ConvGeom)
 
+
+class BnBwdEpilogue(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p),
+                ('invstd', C.c_void_p), ('relu', C.c_int)]
+
+
+BP = C.POINTER(BnBwdEpilogue)
+
 # name -> argtypes (the trailing `void* stream` included where the C signature has it)
 SIGNATURES = {
     'dsnt_preact_fwd': [P, P, L, I, I, F, F, P],
@@ -42,6 +50,8 @@ SIGNATURES = {
     'dsnt_head_loss_rows': [P, P, P, P, P, L, I, I, F, I, P],
     'dsnt_head_bwd': [P, P, P, P, P, P, P, L, I, I, F, I, P],
     'dsnt_conv_fwd': [P, P, P, P, P, P, I, P, P, P, GP, P],
+    'dsnt_conv_fwd_ex': [P, P, P, P, P, P, I, P, P, P, GP, BP, P],
+    'dsnt_conv_fwd_bf16x6_ex': [P, P, L, P, P, P, P, I, P, P, P, GP, BP, P],
     'dsnt_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'dsnt_conv_pack_dgrad_all': [P, I, P, P, P, L, P],
     'dsnt_conv_fwd_bf16x6': [P, P, L, P, P, P, P, I, P, P, P, GP, P],

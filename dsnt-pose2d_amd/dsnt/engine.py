@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvGeom
+from ._lib import ConvGeom, BnBwdEpilogue
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -140,7 +140,7 @@ class Tape:
         for a in args:
             if isinstance(a, torch.Tensor):
                 conv.append(_lib.ptr(a))
-            elif isinstance(a, ConvGeom):
+            elif isinstance(a, (ConvGeom, BnBwdEpilogue)):
                 self._keep.append(a)
                 conv.append(C.byref(a))
             else:
@@ -244,15 +244,20 @@ class Tape:
                    bn.momentum, bn.eps, 0, n.mean, n.invstd, n.scale, n.shift)
         return n
 
-    def _norm_backward(self, n, da):
-        """Given da = dL/d relu(bn(x)), accumulate dx into n.x.grad and dgamma/dbeta."""
+    def _norm_backward(self, n, da, reduced=None):
+        """Given da = dL/d relu(bn(x)), accumulate dx into n.x.grad and dgamma/dbeta.  With
+        `reduced` = (partials, ntiles) the producer already masked da by the ReLU and reduced it."""
         x, bn = n.x, n.bn
-        tiles = (x.M + 127) // 128
-        part = self.scratch('bnpart', tiles * 2 * bn.C).view(-1)
         coef = self.scratch('bncoef', 2 * bn.C)
         relu = 1 if n.relu else 0
-        self.b('dsnt_bn_act_bwd_reduce', da, x.buf, n.scale, n.shift, n.mean, n.invstd, relu, part,
-               x.M, bn.C)
+        if reduced is not None:
+            part, tiles = reduced
+            relu = 0                      # da is already dz
+        else:
+            tiles = (x.M + 127) // 128
+            part = self.scratch('bnpart', tiles * 2 * bn.C).view(-1)
+            self.b('dsnt_bn_act_bwd_reduce', da, x.buf, n.scale, n.shift, n.mean, n.invstd, relu, part,
+                   x.M, bn.C)
         acc_p = 1 if bn.uses > 0 else 0
         bn.uses += 1
         self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef)
@@ -315,15 +320,23 @@ class Tape:
                         wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
                         self.b('dsnt_split_bf16x3', wd, wq, nw)
 
-                def dgrad(out, res):
+                def dgrad(out, res, part=None, bnb=None):
                     if d6:
-                        self.b('dsnt_conv_fwd_bf16x6', gy, wq, wq_stride, None, out, None, None, 0, res, None, None, gd)
+                        self.b('dsnt_conv_fwd_bf16x6_ex', gy, wq, wq_stride, None, out, None, None, 0, res, None,
+                               part, gd, bnb)
                     else:
-                        self.b('dsnt_conv_fwd', gy, wd, None, out, None, None, 0, res, None, None, gd)
+                        self.b('dsnt_conv_fwd_ex', gy, wd, None, out, None, None, 0, res, None, part, gd, bnb)
                 if normed:
-                    da = self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
-                    dgrad(da, None)
-                    self._norm_backward(src, da)
+                    # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
+                    # data-gradient epilogue; only finalise + apply remain as separate launches
+                    dz = self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
+                    bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
+                    tiles = (x.M + bm - 1) // bm
+                    part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
+                    bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
+                                        _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
+                    dgrad(dz, None, part, bnb)
+                    self._norm_backward(src, dz, reduced=(part, tiles))
                 else:
                     buf, acc = self.grad_target(x)
                     dgrad(buf, buf if acc else None)

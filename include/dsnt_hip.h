@@ -120,6 +120,20 @@ int dsnt_conv_fwd(const float* x, const float* w, const float* bias, float* y,
                   const float* res1, const float* res2, float* stats_partial,
                   const dsnt_conv_geom* g, void* stream);
 
+/* Data-gradient launches can fuse the first half of the BatchNorm+ReLU backward into the epilogue:
+ * with `bnb` != NULL the kernel writes dz = (conv result) * [relu mask of bn(x)] to y and per-tile
+ * (sum dz, sum dz*xhat) to stats_partial (xhat = (x - mean) * invstd), ready for
+ * dsnt_bn_bwd_finalize; dsnt_bn_act_bwd_apply then runs with relu = 0 on dz. */
+typedef struct {
+    const float* x;            /* the BatchNorm input, shape of y */
+    const float* scale; const float* shift; const float* mean; const float* invstd;   /* [C] */
+    int relu;
+} dsnt_bn_bwd_epilogue;
+int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y,
+                     const float* in_scale, const float* in_shift, int in_relu,
+                     const float* res1, const float* res2, float* stats_partial,
+                     const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream);
+
 /* Rows per stats_partial tile that dsnt_conv_fwd uses for this geometry (128 or 32): the
  * caller sizes stats_partial as [ceil(M/bm)][2][Cout] and hands ceil(M/bm) to dsnt_bn_finalize. */
 int dsnt_conv_fwd_bm(const dsnt_conv_geom* g);
@@ -136,6 +150,11 @@ int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_t plane_str
                          const float* in_scale, const float* in_shift, int in_relu,
                          const float* res1, const float* res2, float* stats_partial,
                          const dsnt_conv_geom* g, void* stream);
+
+int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* bias,
+                            float* y, const float* in_scale, const float* in_shift, int in_relu,
+                            const float* res1, const float* res2, float* stats_partial,
+                            const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream);
 
 /* Re-pack OHWI weights for the data-gradient pass: wd[Cin][R][S][Cout] with taps flipped,
  * so that dgrad(dy) == dsnt_conv_fwd(dy, wd) with pad' = dil*(R-1) - pad (stride 1). */
