@@ -87,6 +87,11 @@ class Tape:
         # fp32-accurate split-bf16 matrix-core path for the large convolutions (DSNT_MFMA=f32 disables)
         self.use_bf16x6 = os.environ.get('DSNT_MFMA', 'bf16x6') != 'f32'
         self.bf16x6_min_rows = int(os.environ.get('DSNT_BF16X6_MIN_ROWS', '16384'))
+        # lanes: 0 = the caller's stream, 1 = a side stream for independent branches (the full-resolution
+        # skip branch of every hourglass level runs beside the low-resolution recursion)
+        self.lane = 0
+        self.use_lanes = os.environ.get('DSNT_LANES', '1') != '0'
+        self.side_stream = None
         self.acts = []          # every activation in creation order (debugging / introspection)
         self.dgrad_slots = []   # (conv params, dst offset) of every conv whose data gradient is needed
         self.dgrad_total = 0
@@ -105,6 +110,7 @@ class Tape:
         """Shared scratch (valid only within one op's launches on the single stream)."""
         if os.environ.get('DSNT_NO_SCRATCH'):
             return self.empty(max(numel, 1))
+        key = (key, self.lane)
         t = self._scratch.get(key)
         if t is None or t.numel() < numel:
             if t is not None:
@@ -115,6 +121,7 @@ class Tape:
         return t
 
     def scratch_bf16(self, key, numel):
+        key = (key, self.lane)
         t = self._scratch.get(key)
         if t is None or t.numel() < numel:
             if t is not None:
@@ -145,7 +152,7 @@ class Tape:
                 conv.append(C.byref(a))
             else:
                 conv.append(a)
-        lst.append((fn, tuple(conv), name))
+        lst.append((fn, tuple(conv), name, self.lane))
 
     def f(self, name, *args):
         self._emit(self.fwd, name, *args)
@@ -154,7 +161,40 @@ class Tape:
         self._emit(self.bwd, name, *args)
 
     def on_backward(self, fn):
-        self._bwd_emitters.append(fn)
+        lane = self.lane
+
+        def emit():
+            saved, self.lane = self.lane, lane
+            try:
+                fn()
+            finally:
+                self.lane = saved
+        self._bwd_emitters.append(emit)
+
+    # ------------------------------------------------------------------ lanes
+    def sync(self, src, dst):
+        """`dst` lane waits for everything emitted so far on `src`; mirrored in backward."""
+        if not self.use_lanes:
+            return
+        self.fwd.append((None, (src, dst, torch.cuda.Event()), 'sync', 0))
+        if self.training:
+            self._bwd_emitters.append(
+                lambda: self.bwd.append((None, (dst, src, torch.cuda.Event()), 'sync', 0)))
+
+    def branch(self, x):
+        """Alias of activation x for a branch traced on the side lane: same buffer and statistics,
+        private gradient (the two lanes must not accumulate into one buffer concurrently); the
+        private gradient is added to x's after the lanes have joined in backward."""
+        if not self.use_lanes:
+            return x
+        xb = Act(x.buf, x.name + '/branch')
+        xb.stats = x.stats
+        if self.training:
+            def join_grad():
+                if xb.grad is not None:
+                    self.grad_identity(x, xb.grad, donate=False)
+            self.on_backward(join_grad)        # registered first -> runs after the branch's backward
+        return xb
 
     def finish(self):
         """Emit the backward list (reverse order of the forward ops)."""
@@ -180,20 +220,31 @@ class Tape:
         """Forward position where parameter bucket k starts being used: in the (reversed) backward
         list the marker lands right after the last launch that writes bucket k's gradients."""
         if self.training:
-            self.on_backward(lambda: self.bwd.append((None, k, 'bucket')))
+            self.on_backward(lambda: self.bwd.append((None, k, 'bucket', 0)))
 
-    @staticmethod
-    def run(lst, bucket_hook=None):
-        stream = torch.cuda.current_stream().cuda_stream
-        for fn, args, name in lst:
+    def run(self, lst, bucket_hook=None):
+        main = torch.cuda.current_stream()
+        if self.use_lanes and self.side_stream is None:
+            self.side_stream = torch.cuda.Stream()
+        streams = (main, self.side_stream)
+        ptrs = (main.cuda_stream, self.side_stream.cuda_stream if self.side_stream is not None else 0)
+        if self.use_lanes:
+            self.side_stream.wait_stream(main)
+        for fn, args, name, lane in lst:
             if fn is None:
-                if bucket_hook is not None:
+                if name == 'sync':
+                    src, dst, ev = args
+                    ev.record(streams[src])
+                    streams[dst].wait_event(ev)
+                elif bucket_hook is not None:
                     bucket_hook(args)
                 continue
-            rc = fn(*args, stream)
+            rc = fn(*args, ptrs[lane])
             if rc != 0:
                 raise RuntimeError('%s failed (%d): %s' % (
                     name, rc, _lib.load().dsnt_last_error().decode()))
+        if self.use_lanes:
+            main.wait_stream(self.side_stream)
 
     # ------------------------------------------------------------------ gradient plumbing
     def grad_target(self, a):

@@ -191,7 +191,8 @@ class Program:
                 if x.grad is None:
                     raise RuntimeError('input gradient requested but nothing produced it')
                 tape.b('dsnt_nhwc_to_nchw', x.grad, self.gx, N, Cc, H * W, x.C)
-        self.n_fwd, self.n_bwd = len(tape.fwd), len(tape.bwd)
+        self.n_fwd = sum(1 for e in tape.fwd if e[0] is not None)
+        self.n_bwd = sum(1 for e in tape.bwd if e[0] is not None)
 
 
 class _Run(Function):
@@ -199,7 +200,7 @@ class _Run(Function):
     def forward(ctx, runner, prog, x, *params):
         prog.in_nchw.copy_(x)
         prog.token += 1
-        Tape.run(prog.tape.fwd)
+        prog.tape.run(prog.tape.fwd)
         ctx.runner, ctx.prog, ctx.token, ctx.nparams = runner, prog, prog.token, len(params)
         return tuple(o.clone() for o in prog.outs)
 
@@ -217,7 +218,7 @@ class _Run(Function):
                 gin.zero_()
             else:
                 gin.copy_(g)
-        Tape.run(prog.tape.bwd, runner.bucket_hook)
+        prog.tape.run(prog.tape.bwd, runner.bucket_hook)
         if runner.before_publish is not None:
             runner.before_publish()
         runner.arena.publish_grads(runner.params)
@@ -270,7 +271,7 @@ class Runner:
             with torch.no_grad():
                 prog.in_nchw.copy_(x)
                 prog.token += 1
-                Tape.run(prog.tape.fwd)
+                prog.tape.run(prog.tape.fwd)
                 outs = tuple(o.clone() for o in prog.outs)
         return outs[0] if prog.single else list(outs)
 
@@ -354,10 +355,17 @@ class Hourglass(TapeModule):
 
     def _level(self, n, t, x, P):
         g = self.hg[n - 1]
-        up1 = _trace_seq(g[0], t, x, P)
+        # the full-resolution skip branch is independent of the whole low-resolution recursion:
+        # trace it on the side lane so its few large kernels overlap the many small ones
+        xb = t.branch(x)
+        t.sync(0, 1)
+        t.lane = 1 if t.use_lanes else 0
+        up1 = _trace_seq(g[0], t, xb, P)
+        t.lane = 0
         low = _trace_seq(g[1], t, t.maxpool2(x), P)
         low = self._level(n - 1, t, low, P) if n > 1 else _trace_seq(g[3], t, low, P)
         low = _trace_seq(g[2], t, low, P)
+        t.sync(1, 0)
         return t.upsample2_add(up1, low)
 
     def trace(self, t, x, P):

@@ -30,7 +30,7 @@ def mfma_path(request, monkeypatch):
 
 def _count_launches(module, name):
     progs = module._runner().programs.values()
-    return sum(1 for p in progs for (_, _, n) in p.tape.fwd + p.tape.bwd if n == name)
+    return sum(1 for p in progs for (_, _, n, _) in p.tape.fwd + p.tape.bwd if n == name)
 
 
 def _rel_l2(got, want, floor=0.0):
