@@ -130,6 +130,7 @@ def main():
     ap.add_argument('--workload', default='hg2_js', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dp', action='store_true', help='wire the data-parallel hooks even at world size 1 (testing)')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('DSNT_BENCH_GRAPH', '0')))
     args = ap.parse_args()
 
@@ -161,7 +162,11 @@ def main():
 
     model.hg._runner().ensure(dev)
     opt = optim.RMSprop(model, lr=2.5e-4)             # train.py:88-99 defaults for rmsprop
-    if world > 1:
+    if world > 1 or args.force_dp:
+        if args.force_dp and not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29511')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
         parallel.DataParallel(model, opt)
 
     def step():
@@ -219,8 +224,9 @@ def main():
             out['cpu_baseline'] = cpu_baseline(base, reg)
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -92,6 +92,8 @@ class Tape:
         self.lane = 0
         self.use_lanes = os.environ.get('DSNT_LANES', '1') != '0'
         self.side_stream = None
+        self.wgrad_stream = None
+        self.wgrad_lane = 2 if (self.use_lanes and os.environ.get('DSNT_WGRAD_LANE', '0') != '0') else None
         self.acts = []          # every activation in creation order (debugging / introspection)
         self.dgrad_slots = []   # (conv params, dst offset) of every conv whose data gradient is needed
         self.dgrad_total = 0
@@ -181,6 +183,11 @@ class Tape:
             self._bwd_emitters.append(
                 lambda: self.bwd.append((None, (dst, src, torch.cuda.Event()), 'sync', 0)))
 
+    def sync_bwd(self, src, dst):
+        """Backward-list only: `dst` lane waits for what has been emitted on `src` so far."""
+        if self.use_lanes and src != dst:
+            self.bwd.append((None, (src, dst, torch.cuda.Event()), 'sync', 0))
+
     def branch(self, x):
         """Alias of activation x for a branch traced on the side lane: same buffer and statistics,
         private gradient (the two lanes must not accumulate into one buffer concurrently); the
@@ -220,16 +227,23 @@ class Tape:
         """Forward position where parameter bucket k starts being used: in the (reversed) backward
         list the marker lands right after the last launch that writes bucket k's gradients."""
         if self.training:
-            self.on_backward(lambda: self.bwd.append((None, k, 'bucket', 0)))
+            def mark():
+                if self.wgrad_lane is not None:
+                    self.sync_bwd(self.wgrad_lane, 0)     # the bucket's weight gradients are complete
+                self.sync_bwd(1, 0)
+                self.bwd.append((None, k, 'bucket', 0))
+            self.on_backward(mark)
 
     def run(self, lst, bucket_hook=None):
         main = torch.cuda.current_stream()
         if self.use_lanes and self.side_stream is None:
             self.side_stream = torch.cuda.Stream()
-        streams = (main, self.side_stream)
-        ptrs = (main.cuda_stream, self.side_stream.cuda_stream if self.side_stream is not None else 0)
+            self.wgrad_stream = torch.cuda.Stream()
+        streams = (main, self.side_stream, self.wgrad_stream)
+        ptrs = tuple(st.cuda_stream if st is not None else 0 for st in streams)
         if self.use_lanes:
             self.side_stream.wait_stream(main)
+            self.wgrad_stream.wait_stream(main)
         for fn, args, name, lane in lst:
             if fn is None:
                 if name == 'sync':
@@ -245,6 +259,7 @@ class Tape:
                     name, rc, _lib.load().dsnt_last_error().decode()))
         if self.use_lanes:
             main.wait_stream(self.side_stream)
+            main.wait_stream(self.wgrad_stream)
 
     # ------------------------------------------------------------------ gradient plumbing
     def grad_target(self, a):
@@ -350,10 +365,17 @@ class Tape:
             gy = y.grad
             assert gy is not None, 'no gradient reached conv output ' + name
             # parameter gradients (flat arena, overwritten every step)
+            # the weight gradient feeds nothing downstream in backward: run it on its own lane so the
+            # data-gradient chain never waits for it
+            cur = self.lane
+            wl = self.wgrad_lane if self.wgrad_lane is not None else cur
+            self.sync_bwd(cur, wl)
+            self.lane = wl
             ws = self.scratch('wgrad', self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g)))
             w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
             self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
                    p.gw, p.gb, 0, g)
+            self.lane = cur
             if need_input_grad:
                 assert p.stride == 1, 'data gradient of strided convs is not needed on this path'
                 nw = p.w.numel()
@@ -391,7 +413,10 @@ class Tape:
                 else:
                     buf, acc = self.grad_target(x)
                     dgrad(buf, buf if acc else None)
-            # identity branches last: gy is dead after the launches above
+            # identity branches last: gy is dead after the launches above (the weight-gradient lane
+            # must have read it before anyone accumulates into the donated buffer)
+            if res1 is not None or res2 is not None:
+                self.sync_bwd(wl, cur)
             donated = False
             for r in (res1, res2):
                 if r is not None:
