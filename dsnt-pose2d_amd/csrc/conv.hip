@@ -563,7 +563,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
     if (wave >= 4) {
         // ------------------------------------------------------------------ loader waves
         const int ltid = tid - 256;
-        const int lrow = ltid >> 2, kc = ltid & 3;
+        // 16 consecutive lanes store 4 float4-chunks of rows {r, r+2, r+4, r+6}: with the 48-byte row
+        // pitch those 16 ds_write_b64 hit 16 distinct 8-byte bank groups (rows r..r+3 would 2-way conflict)
+        const int kc = ltid & 3;
+        const int lrow = ((ltid >> 5) << 3) + (((ltid >> 2) & 3) << 1) + ((ltid >> 4) & 1);
         const int HoWo = p.Ho * p.Wo;
         const int RS = p.R * p.S;
         unsigned apix[APASS];
@@ -584,7 +587,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
             }
         }
         // weights: 16-byte chunk `ltid` of each plane's [BN][16] slice: row = ltid>>1, half = ltid&1
-        const int brow = ltid >> 1, bhalf = ltid & 1;
+        const int bhalf = ltid & 1;     // same idea for the 16-byte weight stores (8-lane groups)
+        const int brow = ((ltid >> 4) << 3) + (((ltid >> 1) & 3) << 1) + ((ltid >> 3) & 1);
         const int bn = ntile * BN + brow;
         const bool bvalid = brow < BN && bn < p.Cout;
         unsigned bpix[3];
@@ -1209,7 +1213,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
         // ------------------------------------------------------------------ loader waves
         const int ltid = tid - 256;
         const bool isA = ltid < 128;
-        const int q = ltid & 31, mb = (ltid >> 5) & 3;       // 4-wide column chunk, 4-row block
+        // 4-wide column chunk q, 4-row block mb.  mb varies fastest: a 16-lane store group then spans
+        // 4 chunks x 4 blocks (2-way bank conflicts; q fastest would be 8-way with the 48-byte pitch)
+        const int mb = ltid & 3, q = (ltid >> 2) & 31;
         const unsigned OOB = 0xF0000000u;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
@@ -1369,7 +1375,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
         __syncthreads();
         if (wave >= 6) {
             const int ltid = tid - 384;
-            *reinterpret_cast<float4*>(red + (ltid >> 5) * 128 + (ltid & 31) * 4) = bsum;
+            *reinterpret_cast<float4*>(red + (ltid & 3) * 128 + ((ltid >> 2) & 31) * 4) = bsum;
         }
         __syncthreads();
         if (tid < 128) {

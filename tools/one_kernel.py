@@ -16,8 +16,12 @@ M = B * H * H
 stats = torch.empty((M + 127) // 128, 2, Cout, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 ws = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev); dw = torch.empty_like(w); db = torch.empty(Cout, device=dev)
+planes = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=dev)
+_lib.fn('dsnt_split_bf16x3')(ptr(w), ptr(planes), w.numel(), st)
 for _ in range(5):
-    if which == 'fwd':
+    if which == 'fwd6':
+        _lib.fn('dsnt_conv_fwd_bf16x6')(ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
+    elif which == 'fwd':
         _lib.fn('dsnt_conv_fwd')(ptr(x), ptr(w), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
     else:
         _lib.fn('dsnt_conv_wgrad')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), ptr(dw), ptr(db), 0, C.byref(g), st)
