@@ -14,6 +14,8 @@ LIB = os.path.join(CSRC, 'libdsnt_hip.so')
 SOURCES = ['api.cpp', 'conv.hip', 'elementwise.hip', 'head.hip', 'debug.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result']
+if os.environ.get('DSNT_TIMELINE'):      # wave timeline stamps in the conv kernels (tools/timeline*.py)
+    FLAGS.append('-DDSNT_TIMELINE')
 
 
 def _newer(a, b):

@@ -42,10 +42,25 @@ struct ConvP {
 // of workgroup `g_dbg_block` stamps s_memtime at chosen points: dbg[wave*128 + slot].
 __device__ long long* g_dbg = nullptr;
 __device__ int g_dbg_block = 0;
+#ifdef DSNT_TIMELINE        // DSNT_TIMELINE=1 python build.py --force (tools/timeline*.py)
 #define DBG_STAMP(slot)                                                                      \
     do {                                                                                     \
-        if (dbg && (slot) < 128) dbg[wave * 128 + (slot)] = __builtin_amdgcn_s_memtime();   \
+        if (dbg && (slot) < 126) dbg[wave * 128 + (slot)] = __builtin_amdgcn_s_memtime();   \
     } while (0)
+// block < 0: every workgroup stamps into its own 8x128 slab; slots 126/127 hold HW_ID / XCC_ID
+#define DBG_INIT()                                                                                   \
+    long long* dbg = nullptr;                                                                        \
+    if (g_dbg && lane == 0 && (g_dbg_block < 0 || (int)blockIdx.x == g_dbg_block)) {                \
+        dbg = g_dbg + (g_dbg_block < 0 ? (size_t)blockIdx.x * 1024 : 0);                             \
+        dbg[wave * 128 + 126] = __builtin_amdgcn_s_getreg(63492);                                    \
+        dbg[wave * 128 + 127] = __builtin_amdgcn_s_getreg(63508);                                    \
+    }
+#define DBG_WAIT_LDS() do { if (dbg) __builtin_amdgcn_s_waitcnt(0xc07f); } while (0)
+#else
+#define DBG_STAMP(slot) do { } while (0)
+#define DBG_INIT() do { } while (0)
+#define DBG_WAIT_LDS() do { } while (0)
+#endif
 
 extern "C" int dsnt_debug_set_timeline(long long* buf, int block) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &buf, sizeof(buf)) != hipSuccess) return DSNT_ERR_HIP;
@@ -62,10 +77,13 @@ __device__ __forceinline__ void xcd_remap(int bid, int nwg, int& out) {
 }
 
 // Shared epilogue of the forward / data-gradient kernels (fp32 and bf16x6 variants).
-template <int WM, int WN, int TM, int TN>
+// HALO: the tile's 128 rows are an 8 x 16 patch of output pixels starting at row `mbase` (row r of the
+// tile is output row mbase + (r >> 4) * W + (r & 15)) instead of 128 consecutive output rows.
+template <int WM, int WN, int TM, int TN, bool HALO = false>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* smem, int mtile,
-                                              int ntile, int tid, int wave, int lane) {
+                                              int ntile, int tid, int wave, int lane, int mbase = 0) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    auto rowmap = [&](int row) { return HALO ? mbase + (row >> 4) * p.W + (row & 15) : mtile * BM + row; };
     const int lr = lane & 31, lh = lane >> 5;
     const int cw = wave & 3;
     const int wm = cw / WN, wn = cw % WN;
@@ -106,7 +124,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
     float4 r1[NP], r2[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int m = mtile * BM + r0 + RPP * j;
+        const int m = rowmap(r0 + RPP * j);
         const bool ok = vn && m < p.M;
         const size_t o = ok ? (size_t)m * p.Cout + n0 : 0;
         r1[j] = p.res1 ? *reinterpret_cast<const float4*>(p.res1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -116,7 +134,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int row = r0 + RPP * j;
-        const int m = mtile * BM + row;
+        const int m = rowmap(row);
         if (vn && m < p.M) {
             float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + ch * 4);
             if (bnb) {
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
     const int lr = lane & 31, lh = lane >> 5;
     const int cw = wave & 3;
     const int wm = cw / WN, wn = cw % WN;
-    long long* dbg = (g_dbg && (int)blockIdx.x == g_dbg_block && lane == 0) ? g_dbg : nullptr;
+    DBG_INIT();
     DBG_STAMP(0);
 
     f32x16 acc[TM][TN];
@@ -271,28 +289,31 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
                 float4 v = make_float4(__uint_as_float(st.ra[i].x), __uint_as_float(st.ra[i].y),
                                        __uint_as_float(st.ra[i].z), __uint_as_float(st.ra[i].w));
                 float* dst = As + (buf * BM + lrow + 32 * i) * PITCH + kc * 4;
-                if ((st.ok >> i) & 1u) {
-                    if (PRO) {
-                        v.x = fmaf(v.x, st.sc.x, st.sh.x); v.y = fmaf(v.y, st.sc.y, st.sh.y);
-                        v.z = fmaf(v.z, st.sc.z, st.sh.z); v.w = fmaf(v.w, st.sc.w, st.sh.w);
-                        if (p.in_relu) {
-                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                        }
+                // branch-free on purpose: consuming the loaded registers inside a divergent branch makes
+                // hipcc lose track of which loads have completed and drain vmcnt(0) before the next
+                // prefetch is issued (seen in the ISA) — the register prefetch pipeline collapses
+                if (PRO) {
+                    v.x = fmaf(v.x, st.sc.x, st.sh.x); v.y = fmaf(v.y, st.sc.y, st.sh.y);
+                    v.z = fmaf(v.z, st.sc.z, st.sh.z); v.w = fmaf(v.w, st.sc.w, st.sh.w);
+                    if (p.in_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    *reinterpret_cast<float4*>(dst) = v;
-                } else {
-                    *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+                const bool ok = (st.ok >> i) & 1u;
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                *reinterpret_cast<float4*>(dst) = v;
             }
 #pragma unroll
             for (int j = 0; j < BPASS; ++j)
                 *reinterpret_cast<u32x4*>(Bs + (buf * BN + lrow + 32 * j) * PITCH + kc * 4) = st.rb[j];
         };
+        // no conditionals around gload/lstore (see the bf16x6 loader): the tail re-loads the last step
+        const int last = nsteps - 1;
         gload(S0, 0);
-        if (nsteps > 1) gload(S1, 1);
+        gload(S1, min(1, last));
         lstore(S0, 0);
-        if (nsteps > 2) gload(S0, 2);
+        gload(S0, min(2, last));
         DBG_STAMP(1);
         __syncthreads();
         int s = 0;
@@ -300,16 +321,14 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
             DBG_STAMP(2 + 3 * s);
             lstore(S1, 1);
             DBG_STAMP(3 + 3 * s);
-            if (s + 3 < nsteps) gload(S1, s + 3);
+            gload(S1, min(s + 3, last));
             DBG_STAMP(4 + 3 * s);
             __syncthreads();
             DBG_STAMP(5 + 3 * s);
-            if (s + 2 < nsteps) {
-                lstore(S0, 0);
-                DBG_STAMP(6 + 3 * s);
-                if (s + 4 < nsteps) gload(S0, s + 4);
-                DBG_STAMP(7 + 3 * s);
-            }
+            lstore(S0, 0);                 // s + 2 == nsteps: refills the idle buffer 0, harmless
+            DBG_STAMP(6 + 3 * s);
+            gload(S0, min(s + 4, last));
+            DBG_STAMP(7 + 3 * s);
             __syncthreads();
         }
         if (s < nsteps) __syncthreads();
@@ -398,10 +417,12 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
                 *reinterpret_cast<float4*>(Bs + (buf * BN + lrow + 32 * j) * PITCH + kc * 4) = v;
             }
         };
+        // no conditionals around gload/lstore (see the bf16x6 loader): the tail re-loads the last step
+        const int last = nsteps - 1;
         gload(S0, 0);
-        if (nsteps > 1) gload(S1, 1);
+        gload(S1, min(1, last));
         lstore(S0, 0);
-        if (nsteps > 2) gload(S0, 2);
+        gload(S0, min(2, last));
         DBG_STAMP(1);
         __syncthreads();
         // iteration s stores K-step s+1 (held in S1 for even s, S0 for odd s) into the buffer the
@@ -411,16 +432,14 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
             DBG_STAMP(2 + 3 * s);
             lstore(S1, 1);
             DBG_STAMP(3 + 3 * s);
-            if (s + 3 < nsteps) gload(S1, s + 3);
+            gload(S1, min(s + 3, last));
             DBG_STAMP(4 + 3 * s);
             __syncthreads();
             DBG_STAMP(5 + 3 * s);
-            if (s + 2 < nsteps) {
-                lstore(S0, 0);
-                DBG_STAMP(6 + 3 * s);
-                if (s + 4 < nsteps) gload(S0, s + 4);
-                DBG_STAMP(7 + 3 * s);
-            }
+            lstore(S0, 0);                 // s + 2 == nsteps: refills the idle buffer 0, harmless
+            DBG_STAMP(6 + 3 * s);
+            gload(S0, min(s + 4, last));
+            DBG_STAMP(7 + 3 * s);
             __syncthreads();
         }
         if (s < nsteps) __syncthreads();     // odd step count: the last iteration only synchronises
@@ -478,10 +497,10 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
         }
         __builtin_amdgcn_s_setprio(0);
     }
-    DBG_STAMP(120);
+    DBG_STAMP(124);
 
     conv_epilogue<WM, WN, TM, TN>(p, acc, smem, mtile, ntile, tid, wave, lane);
-    DBG_STAMP(121);
+    DBG_STAMP(125);
 }
 
 // ==========================================================================================
@@ -551,6 +570,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
     const int lr = lane & 31, lh = lane >> 5;
     const int cw = wave & 3;
     const int wm = cw / WN, wn = cw % WN;
+    DBG_INIT();
+    DBG_STAMP(0);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -628,18 +649,20 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
             for (int i = 0; i < APASS; ++i) {
                 float4 v = make_float4(__uint_as_float(st.ra[i].x), __uint_as_float(st.ra[i].y),
                                        __uint_as_float(st.ra[i].z), __uint_as_float(st.ra[i].w));
-                uint2 q1 = make_uint2(0u, 0u), q2 = q1, q3 = q1;
-                if ((st.ok >> i) & 1u) {
-                    if (PRO) {
-                        v.x = fmaf(v.x, st.sc.x, st.sh.x); v.y = fmaf(v.y, st.sc.y, st.sh.y);
-                        v.z = fmaf(v.z, st.sc.z, st.sh.z); v.w = fmaf(v.w, st.sc.w, st.sh.w);
-                        if (p.in_relu) {
-                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                        }
+                uint2 q1, q2, q3;
+                if (PRO) {
+                    v.x = fmaf(v.x, st.sc.x, st.sh.x); v.y = fmaf(v.y, st.sc.y, st.sh.y);
+                    v.z = fmaf(v.z, st.sc.z, st.sh.z); v.w = fmaf(v.w, st.sc.w, st.sh.w);
+                    if (p.in_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    split4(v, q1, q2, q3);
                 }
+                // branch-free zero padding (a divergent branch around the loaded registers makes hipcc
+                // drain vmcnt(0) before the next prefetch: see the fp32 loader)
+                const bool ok = (st.ok >> i) & 1u;
+                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                split4(v, q1, q2, q3);
                 __bf16* dst = A6 + ((size_t)(buf * 3) * BM + lrow + 64 * i) * PITCH6 + kc * 4;
                 *reinterpret_cast<uint2*>(dst) = q1;
                 *reinterpret_cast<uint2*>(dst + BM * PITCH6) = q2;
@@ -651,20 +674,29 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
                     *reinterpret_cast<u32x4*>(B6 + ((size_t)(buf * 3 + j) * BN + brow) * PITCH6 + bhalf * 8) = st.rb[j];
             }
         };
+        // No conditionals around gload/lstore: hipcc's vmcnt bookkeeping is exact only on straight-line
+        // code.  With `if (s + 3 < nsteps) gload(...)` it assumed the loads might not have been issued
+        // and waited for vmcnt(0) before every LDS store, i.e. no load ever stayed in flight across a
+        // step.  The tail re-loads the last step (never stored, or stored into the idle buffer).
+        const int last = nsteps - 1;
         gload(S0, 0);
-        if (nsteps > 1) gload(S1, 1);
+        gload(S1, min(1, last));
         lstore(S0, 0);
-        if (nsteps > 2) gload(S0, 2);
+        gload(S0, min(2, last));
         __syncthreads();
         int s = 0;
         for (; s + 1 < nsteps; s += 2) {
+            DBG_STAMP(1 + 3 * s);
             lstore(S1, 1);
-            if (s + 3 < nsteps) gload(S1, s + 3);
+            DBG_STAMP(2 + 3 * s);
+            gload(S1, min(s + 3, last));
+            DBG_STAMP(3 + 3 * s);
             __syncthreads();
-            if (s + 2 < nsteps) {
-                lstore(S0, 0);
-                if (s + 4 < nsteps) gload(S0, s + 4);
-            }
+            DBG_STAMP(4 + 3 * s);
+            lstore(S0, 0);                 // when s + 2 == nsteps this refills idle buffer 0: harmless
+            DBG_STAMP(5 + 3 * s);
+            gload(S0, min(s + 4, last));
+            DBG_STAMP(6 + 3 * s);
             __syncthreads();
         }
         if (s < nsteps) __syncthreads();
@@ -701,12 +733,18 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
         };
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
+            DBG_STAMP(1 + 3 * s);
             rd(F, s & 1);
+            DBG_WAIT_LDS();                // timeline builds only: fragment reads landed
+            DBG_STAMP(2 + 3 * s);
             mm(F);
+            DBG_STAMP(3 + 3 * s);
             __syncthreads();
         }
     }
+    DBG_STAMP(124);
     conv_epilogue<WM, WN, TM, TN>(p, acc, smem, mtile, ntile, tid, wave, lane);
+    DBG_STAMP(125);
 }
 
 extern "C" int dsnt_conv_bf16x6_ok(const dsnt_conv_geom* g) {
@@ -833,6 +871,221 @@ extern "C" int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bia
     return conv_fwd_impl(x, w, bias, y, in_scale, in_shift, in_relu, res1, res2, stats_partial, g, bnb, stream);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution on bf16x6 with an LDS halo tile.
+//
+// Why: on this hardware a wave that issues MFMAs back-to-back monopolises its SIMD — VALU work of
+// other waves on that SIMD only runs in the gaps (tools/starve.py: a 128-instruction VALU burst takes
+// the whole MFMA phase to finish), and when it runs it runs instead of, not beside, the matrix pipe.
+// In the implicit-GEMM kernel above every filter tap re-loads, re-normalises and re-splits the same
+// input pixels (9x the VALU work, 2.4x the HBM traffic of the tensor).  Here a workgroup owns an
+// 8 x 16 patch of output pixels: the (8+2) x (16+2) input halo of 16 channels is transformed and
+// split ONCE into LDS, then all nine taps run from it with shifted fragment addresses (immediate
+// offsets), while only the pre-split weights stream through the double-buffered B tile.
+//   LDS: A halo [3 planes][192 px][24] bf16 (27.6 KB, single buffer: refilled at chunk boundaries
+//   from registers that were loaded nine steps earlier) + B [2][3][BN][24] bf16 (36.9 KB).
+// K order is (16-channel chunk, tap) instead of (tap, channel): same products, different fp32
+// summation order than the implicit-GEMM kernel (differences at the 1e-7 level).
+template <int TN, bool PRO>
+__global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int WN = 2, TM = 2, BM = 128, BN = WN * TN * 32;
+    constexpr int HWD = 18, HPP = 192;                 // halo row width; halo pixels (180) padded to 192
+    constexpr int BROWS = BN * 2 / 256 >= 1 ? 3 : 3;   // three planes per loader thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* A6 = reinterpret_cast<__bf16*>(smem);          // [3][HPP][PITCH6]
+    __bf16* B6 = A6 + 3 * HPP * PITCH6;                    // [2][3][BN][PITCH6]
+
+    int tile;
+    xcd_remap(blockIdx.x, p.mtiles * p.ntiles, tile);
+    const int ntile = tile % p.ntiles, mtile = tile / p.ntiles;
+    const int tws = p.W >> 4, ths = p.H >> 3;
+    const int tw = mtile % tws, th = (mtile / tws) % ths, img = mtile / (tws * ths);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = p.Cin >> 4;                    // even (Cin % 32 == 0)
+    const int lr = lane & 31, lh = lane >> 5;
+    const int cw = wave & 3;
+    const int wm = cw >> 1, wn = cw & 1;
+    (void)BROWS;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int ltid = tid - 256;
+        const int kc = ltid & 3;
+        const unsigned OOB = 0xF0000000u;
+        unsigned aoffs[3], alds[3], aok = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pix = (ltid >> 2) + 64 * i;      // 0..191, halo pixels 0..179
+            const int hy = pix / HWD, hx = pix - hy * HWD;
+            const int ih = th * 8 - 1 + hy, iw = tw * 16 - 1 + hx;
+            const bool in = pix < 180 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            aoffs[i] = in ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + kc * 4) * 4u : OOB;
+            alds[i] = (unsigned)(pix * PITCH6 + kc * 4);
+            aok |= (in ? 1u : 0u) << i;
+        }
+        const int bhalf = ltid & 1;
+        const int brow = ((ltid >> 4) << 3) + (((ltid >> 1) & 3) << 1) + ((ltid >> 3) & 1);
+        const int bn = ntile * BN + brow;
+        const bool bvalid = brow < BN && bn < p.Cout;
+        unsigned bpix[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            bpix[j] = bvalid ? (unsigned)((size_t)j * p.wq_stride + (size_t)bn * p.K + bhalf * 8) * 2u : OOB;
+        const unsigned blds = (unsigned)(brow * PITCH6 + bhalf * 8);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)2 * p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
+        u32x4 ra[3], rb[2][3];
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int lastc = nchunks - 1;
+        auto gloadA = [&](int c) {
+            c = min(c, lastc);
+            if (PRO) {
+                sc = *reinterpret_cast<const float4*>(p.in_scale + c * 16 + kc * 4);
+                sh = *reinterpret_cast<const float4*>(p.in_shift + c * 16 + kc * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoffs[i], c * 64, 0);
+        };
+        auto storeA = [&]() {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float4 v = make_float4(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y),
+                                       __uint_as_float(ra[i].z), __uint_as_float(ra[i].w));
+                if (PRO) {
+                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                    v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                    if (p.in_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    const bool ok = (aok >> i) & 1u;       // zero padding is applied after BN + ReLU
+                    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                }
+                uint2 q1, q2, q3;
+                split4(v, q1, q2, q3);
+                __bf16* dst = A6 + alds[i];
+                *reinterpret_cast<uint2*>(dst) = q1;
+                *reinterpret_cast<uint2*>(dst + HPP * PITCH6) = q2;
+                *reinterpret_cast<uint2*>(dst + 2 * HPP * PITCH6) = q3;
+            }
+        };
+        // weights of K-step (chunk c, tap t): OHWI columns t*Cin + c*16 .. +16 of the three planes
+        auto gloadB = [&](int stage, int c, int t) {
+            c = min(c, lastc);
+            const unsigned koff = (unsigned)(t * p.Cin + c * 16) * 2u;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rb[stage][j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bpix[j], koff, 0);
+        };
+        auto storeB = [&](int stage, int buf) {
+            if (brow < BN) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    *reinterpret_cast<u32x4*>(B6 + (size_t)(buf * 3 + j) * BN * PITCH6 + blds) = rb[stage][j];
+            }
+        };
+        // step s = 9 * chunk + tap reads B buffer s & 1; its weights sit in register stage s & 1
+        gloadA(0);
+        gloadB(0, 0, 0);
+        gloadB(1, 0, 1);
+        storeA();
+        storeB(0, 0);
+        gloadA(1);
+        gloadB(0, 0, 2);
+        __syncthreads();
+        for (int c2 = 0; c2 < nchunks; c2 += 2) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                // while the MFMA waves work on step j: stage step j+1, fetch step j+3
+                storeB((j + 1) & 1, (j + 1) & 1);
+                gloadB((j + 1) & 1, c2 + (j + 3) / 9, (j + 3) % 9);
+                if (j % 9 == 8) {
+                    __syncthreads();                 // the MFMA waves hold the last fragments of this chunk
+                    storeA();
+                    gloadA(c2 + j / 9 + 2);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ MFMA waves
+        struct Frag { bf16x8 a[TM][3], b[TN][3]; };
+        Frag F;
+        int aoff[TM], boff[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+            aoff[a] = (((wm * TM + a) * 2 + (lr >> 4)) * HWD + (lr & 15)) * PITCH6 + 8 * lh;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) boff[b] = ((wn * TN + b) * 32 + lr) * PITCH6 + 8 * lh;
+        __syncthreads();
+        for (int c2 = 0; c2 < nchunks; c2 += 2) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                const int t = j % 9, buf = j & 1;
+                const int toff = ((t / 3) * HWD + (t % 3)) * PITCH6;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+                        F.a[a][pl] = *reinterpret_cast<const bf16x8*>(A6 + pl * HPP * PITCH6 + aoff[a] + toff);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        F.b[b][pl] = *reinterpret_cast<const bf16x8*>(B6 + (buf * 3 + pl) * BN * PITCH6 + boff[b]);
+                }
+                if (t == 8) __syncthreads();         // fragments are in registers: the halo may be refilled
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][2], F.b[b][0], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][2], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][1], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][0], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][1], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][0], acc[a][b], 0, 0, 0);
+                    }
+                __syncthreads();
+            }
+        }
+    }
+    const int mbase = (img * p.H + th * 8) * p.W + tw * 16;
+    conv_epilogue<2, WN, TM, TN, true>(p, acc, smem, mtile, ntile, tid, wave, lane, mbase);
+}
+
+template <int TN>
+static void launch_conv3x3_6(const ConvP& p, bool pro, hipStream_t st) {
+    constexpr int BN = 64 * TN;
+    size_t lds = (size_t)(3 * 192 + 2 * 3 * BN) * PITCH6 * 2;
+    const size_t epi = (size_t)128 * (BN + 4) * 4;
+    if (epi > lds) lds = epi;
+    static bool attr_done = false;
+    if (!attr_done && lds > 65536) {
+        hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 gr(p.mtiles * p.ntiles), bl(512);
+    if (pro) hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TN, true>), gr, bl, lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TN, false>), gr, bl, lds, st, p);
+}
+
+static bool conv3x3_halo_ok(const dsnt_conv_geom* g) {
+    return g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1 && g->dil == 1 && g->Ho == g->H && g->Wo == g->W &&
+           g->H % 8 == 0 && g->W % 16 == 0 && g->Cin % 32 == 0;
+}
+
 template <int WM, int WN, int TM, int TN>
 static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -851,6 +1104,9 @@ static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
     if (pro) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true>), gr, bl, lds, st, p);
     else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false>), gr, bl, lds, st, p);
 }
+
+static bool g_force_gemm6 = false;      // debug/bench: route 3x3 convolutions through the implicit-GEMM kernel
+extern "C" int dsnt_debug_force_gemm6(int on) { g_force_gemm6 = on != 0; return DSNT_OK; }
 
 static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_stride, const float* bias, float* y,
                           const float* in_scale, const float* in_shift, int in_relu,
@@ -886,7 +1142,10 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     const int BN = g->Cout <= 64 ? 64 : 128;
     p.mtiles = (p.M + 127) / 128; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
-    if (BN == 128) launch_fwd6<2, 2, 2, 2>(p, in_scale != nullptr, st);
+    if (conv3x3_halo_ok(g) && !g_force_gemm6) {
+        if (BN == 128) launch_conv3x3_6<2>(p, in_scale != nullptr, st);
+        else launch_conv3x3_6<1>(p, in_scale != nullptr, st);
+    } else if (BN == 128) launch_fwd6<2, 2, 2, 2>(p, in_scale != nullptr, st);
     else launch_fwd6<2, 2, 2, 1>(p, in_scale != nullptr, st);
     DSNT_CHECK_LAUNCH("dsnt_conv_fwd_bf16x6");
 }
@@ -1072,20 +1331,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
             const float4 vg = make_float4(__uint_as_float(st.g[i].x), __uint_as_float(st.g[i].y),
                                           __uint_as_float(st.g[i].z), __uint_as_float(st.g[i].w));
             if (PRO) {
-                if ((st.ok >> i) & 1u) {
-                    va.x = fmaf(va.x, sc.x, sh.x); va.y = fmaf(va.y, sc.y, sh.y);
-                    va.z = fmaf(va.z, sc.z, sh.z); va.w = fmaf(va.w, sc.w, sh.w);
-                    if (p.in_relu) {
-                        va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f);
-                        va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
-                    }
-                    *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = va;
-                } else {
-                    *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                va.x = fmaf(va.x, sc.x, sh.x); va.y = fmaf(va.y, sc.y, sh.y);
+                va.z = fmaf(va.z, sc.z, sh.z); va.w = fmaf(va.w, sc.w, sh.w);
+                if (p.in_relu) {
+                    va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f);
+                    va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
                 }
-            } else {
-                *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = va;   // OOB loads are zeros
+                const bool ok = (st.ok >> i) & 1u;     // branch-free (see the forward loader)
+                va.x = ok ? va.x : 0.f; va.y = ok ? va.y : 0.f; va.z = ok ? va.z : 0.f; va.w = ok ? va.w : 0.f;
             }
+            *reinterpret_cast<float4*>(&As[buf][lrow + 8 * i][cc * 4]) = va;   // OOB loads are zeros
             *reinterpret_cast<float4*>(&Gs[buf][lrow + 8 * i][cc * 4]) = vg;
             bsum.x += vg.x; bsum.y += vg.y; bsum.z += vg.z; bsum.w += vg.w;
         }
@@ -1117,24 +1372,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
 
     const int nsteps = (m_end - m_begin + 31) / 32;
     // S0 holds step 0 (then 2, 4, ...), S1 holds step 1 (3, 5, ...): two steps of loads in flight
-    if (nsteps > 0) gload(S0);
-    if (nsteps > 1) gload(S1);
-    if (nsteps > 0) lstore(S0, 0);
-    if (nsteps > 2) gload(S0);
+    // unconditional on purpose (hipcc's vmcnt bookkeeping is exact only on straight-line code, see the
+    // forward loader): rows past m_end load nothing (out-of-range buffer offsets) and store zeros
+    gload(S0);
+    gload(S1);
+    lstore(S0, 0);
+    gload(S0);
     __syncthreads();
     int st = 0;
     for (; st + 1 < nsteps; st += 2) {
         compute(0);
         __builtin_amdgcn_sched_barrier(0);
         lstore(S1, 1);
-        if (st + 3 < nsteps) gload(S1);
+        gload(S1);
         __syncthreads();
         compute(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (st + 2 < nsteps) {
-            lstore(S0, 0);
-            if (st + 4 < nsteps) gload(S0);
-        }
+        lstore(S0, 0);
+        gload(S0);
         __syncthreads();
     }
     if (st < nsteps) compute(0);
@@ -1212,15 +1467,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
     if (wave >= 4) {
         // ------------------------------------------------------------------ loader waves
         const int ltid = tid - 256;
-        const bool isA = ltid < 128;
+        const bool isA = __builtin_amdgcn_readfirstlane(ltid) < 128;     // wave-uniform: scalar branches
         // 4-wide column chunk q, 4-row block mb.  mb varies fastest: a 16-lane store group then spans
         // 4 chunks x 4 blocks (2-way bank conflicts; q fastest would be 8-way with the 48-byte pitch)
         const int mb = ltid & 3, q = (ltid >> 2) & 31;
         const unsigned OOB = 0xF0000000u;
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(p.dy), 0, (int)((size_t)p.M * p.Cout * 4u), 0x00020000);
+        // one descriptor per wave (x for the A waves, dy for the G waves), picked with scalar selects so
+        // that both kinds run the same straight-line load sequence
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(isA ? p.x : p.dy), 0,
+            isA ? (int)((size_t)p.N * p.H * p.W * p.Cin * 4u) : (int)((size_t)p.M * p.Cout * 4u), 0x00020000);
         // A side: fixed tap / channel chunk
         const int k0 = ktile * 128 + q * 4;
         const bool vk = k0 < p.K;
@@ -1245,25 +1501,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
         const int adv_h = 16 / p.Wo, adv_w = 16 - adv_h * p.Wo;
         struct Stage { u32x4 v[4]; unsigned ok; };
         Stage S0, S1;
+        const bool relu = PRO && isA && p.in_relu;
         auto gload = [&](Stage& st) {
             st.ok = 0;
-            if (isA) {
-                const int ih = roh * p.stride + dh;
-                const bool vrow = vk && ih >= 0 && ih < p.H;
-                const int base = ((rn * p.H + ih) * p.W) * p.Cin + c;
+            const int ih = roh * p.stride + dh;
+            const bool vrow = vk && ih >= 0 && ih < p.H;
+            const int base = ((rn * p.H + ih) * p.W) * p.Cin + c;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int iw = (row_ + j) * p.stride + dw;
-                    const bool ok = vrow && (rm + j) < m_end && iw >= 0 && iw < p.W;
-                    st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)(base + iw * p.Cin) * 4u : OOB, 0, 0);
-                    st.ok |= (ok ? 1u : 0u) << j;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = vn && (rm + j) < m_end;
-                    st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(gr, ok ? (unsigned)((rm + j) * p.Cout + n0) * 4u : OOB, 0, 0);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int iw = (row_ + j) * p.stride + dw;
+                const bool vm = (rm + j) < m_end;
+                const bool ok = vm && (isA ? (vrow && iw >= 0 && iw < p.W) : vn);
+                const unsigned off = (unsigned)(isA ? base + iw * p.Cin : (rm + j) * p.Cout + n0) * 4u;
+                st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
+                st.ok |= (ok ? 1u : 0u) << j;
             }
             rm += 16;
             row_ += adv_w; roh += adv_h;
@@ -1276,17 +1527,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
             for (int j = 0; j < 4; ++j) {
                 v[j] = make_float4(__uint_as_float(st.v[j].x), __uint_as_float(st.v[j].y),
                                    __uint_as_float(st.v[j].z), __uint_as_float(st.v[j].w));
-                if (isA) {
-                    if (PRO) {
-                        v[j].x = fmaf(v[j].x, sc.x, sh.x); v[j].y = fmaf(v[j].y, sc.y, sh.y);
-                        v[j].z = fmaf(v[j].z, sc.z, sh.z); v[j].w = fmaf(v[j].w, sc.w, sh.w);
-                        if (p.in_relu) {
-                            v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f);
-                            v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
-                        }
-                        if (!((st.ok >> j) & 1u)) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (PRO) {      // the G waves hold scale 1 / shift 0 and relu off: same code, identity
+                    v[j].x = fmaf(v[j].x, sc.x, sh.x); v[j].y = fmaf(v[j].y, sc.y, sh.y);
+                    v[j].z = fmaf(v[j].z, sc.z, sh.z); v[j].w = fmaf(v[j].w, sc.w, sh.w);
+                    if (relu) {
+                        v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f);
+                        v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
                     }
-                } else {
+                    const bool ok = (st.ok >> j) & 1u;
+                    v[j].x = ok ? v[j].x : 0.f; v[j].y = ok ? v[j].y : 0.f;
+                    v[j].z = ok ? v[j].z : 0.f; v[j].w = ok ? v[j].w : 0.f;
+                }
+            }
+            if (!isA) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
                     bsum.x += v[j].x; bsum.y += v[j].y; bsum.z += v[j].z; bsum.w += v[j].w;
                 }
             }
@@ -1304,20 +1559,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
             SPLIT_COL(0, x) SPLIT_COL(1, y) SPLIT_COL(2, z) SPLIT_COL(3, w)
 #undef SPLIT_COL
         };
-        if (nsteps > 0) gload(S0);
-        if (nsteps > 1) gload(S1);
-        if (nsteps > 0) lstore(S0, 0);
-        if (nsteps > 2) gload(S0);
+        // unconditional (see the forward loader): rows past m_end load nothing and store zeros
+        gload(S0);
+        gload(S1);
+        lstore(S0, 0);
+        gload(S0);
         __syncthreads();
         int s = 0;
         for (; s + 1 < nsteps; s += 2) {
             lstore(S1, 1);
-            if (s + 3 < nsteps) gload(S1);
+            gload(S1);
             __syncthreads();
-            if (s + 2 < nsteps) {
-                lstore(S0, 0);
-                if (s + 4 < nsteps) gload(S0);
-            }
+            lstore(S0, 0);
+            gload(S0);
             __syncthreads();
         }
         if (s < nsteps) __syncthreads();

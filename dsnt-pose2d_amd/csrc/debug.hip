@@ -113,3 +113,74 @@ extern "C" int dsnt_debug_bf16_peak(float* out, int blocks, int threads, int mfm
     hipLaunchKernelGGL(bf16_peak_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, out, mfma_iters, valu_iters, 0.5f);
     DSNT_CHECK_LAUNCH("dsnt_debug_bf16_peak");
 }
+
+// Issue-starvation probe: waves 0..3 keep the matrix pipe saturated with bf16 MFMAs for `mfma_iters` x 16
+// instructions while waves 4..7 time (s_memtime) a burst of `valu_n` x 16 v_fma_f32 (16 independent chains)
+// issued in the middle of it.  out_cycles[block*4 + w] = cycles of the burst.  prio: s_setprio of the VALU waves.
+template <int PAD>     // PAD: s_nop cycles (x16) after each MFMA: 0 = back-to-back
+__global__ __launch_bounds__(512) void starve_kernel(float* out, long long* out_cycles, int mfma_iters, int valu_n,
+                                                     int prio, float a0) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float s = 0.f;
+    if (wave < 4) {
+        f32x16 acc[4];
+        for (int i = 0; i < 4; ++i)
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        bf16x8 a, b;
+        for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(a0 + threadIdx.x * 1e-3f + e); b[e] = (__bf16)(a0 - e * 0.1f); }
+        const long long m0 = __builtin_amdgcn_s_memtime();
+        constexpr int pad = PAD;            // 0: back-to-back; 1..6: s_nop 1/3/5/6/7/9 after each MFMA; 7: s_sleep 1
+        for (int it = 0; it < mfma_iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[r & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r & 3], 0, 0, 0);
+                if (pad >= 1) __builtin_amdgcn_sched_barrier(0);
+                if (pad == 1) asm volatile("s_nop 1");
+                if (pad == 2) asm volatile("s_nop 3");
+                if (pad == 3) asm volatile("s_nop 5");
+                if (pad == 4) asm volatile("s_nop 6");
+                if (pad == 5) asm volatile("s_nop 7");
+                if (pad == 6) asm volatile("s_nop 9");
+                if (pad == 7) asm volatile("s_sleep 1");
+                if (pad >= 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const long long m1 = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0 && mfma_iters > 0) out_cycles[gridDim.x * 4 + blockIdx.x * 4 + wave] = m1 - m0;
+        for (int i = 0; i < 4; ++i)
+            for (int e = 0; e < 16; ++e) s += acc[i][e];
+    } else {
+        prio &= 15;
+        if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        float v[16];
+        for (int i = 0; i < 16; ++i) v[i] = a0 + i + threadIdx.x;
+        const float m = 1.0001f, c = 1e-4f;
+        __builtin_amdgcn_s_sleep(20);           // let the MFMA waves get going
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < valu_n; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], m, c);
+        }
+        for (int i = 0; i < 16; ++i) s += v[i];
+        asm volatile("" :: "v"(s));
+        const long long t1 = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) out_cycles[blockIdx.x * 4 + wave - 4] = t1 - t0;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" int dsnt_debug_starve(float* out, long long* out_cycles, int blocks, int mfma_iters, int valu_n, int prio,
+                                 void* stream) {
+    DSNT_REQUIRE(out && out_cycles && blocks > 0, DSNT_ERR_ARG, "dsnt_debug_starve: bad argument");
+    const int pad = prio >> 4;
+#define LAUNCH_STARVE(P) hipLaunchKernelGGL(starve_kernel<P>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, \
+                                            out_cycles, mfma_iters, valu_n, prio, 0.5f)
+    switch (pad) {
+        case 0: LAUNCH_STARVE(0); break; case 1: LAUNCH_STARVE(1); break; case 2: LAUNCH_STARVE(2); break;
+        case 3: LAUNCH_STARVE(3); break; case 4: LAUNCH_STARVE(4); break; case 5: LAUNCH_STARVE(5); break;
+        case 6: LAUNCH_STARVE(6); break; default: LAUNCH_STARVE(7); break;
+    }
+#undef LAUNCH_STARVE
+    DSNT_CHECK_LAUNCH("dsnt_debug_starve");
+}

@@ -77,6 +77,8 @@ SIGNATURES = {
     'dsnt_debug_mfma_peak': [P, I, I, I, I, P],
     'dsnt_debug_coexec': [P, I, I, I, P],
     'dsnt_debug_bf16_peak': [P, I, I, I, I, P],
+    'dsnt_debug_starve': [P, P, I, I, I, I, P],
+    'dsnt_debug_force_gemm6': [I],
 }
 # entry points without the status/stream convention
 PLAIN = {

@@ -271,6 +271,13 @@ int dsnt_debug_set_timeline(long long* buf, int block);
 int dsnt_debug_coexec(float* out, int blocks, int mfma_iters, int valu_iters, void* stream);
 /* bf16 MFMA rate (v_mfma_f32_32x32x16_bf16) and its co-execution with VALU (threads 256 or 512). */
 int dsnt_debug_bf16_peak(float* out, int blocks, int threads, int mfma_iters, int valu_iters, void* stream);
+/* Debug/bench switch: route 3x3 convolutions of the bf16x6 path through the implicit-GEMM kernel instead of
+ * the LDS halo-tile kernel (process-wide; not for production use). */
+int dsnt_debug_force_gemm6(int on);
+/* Issue-starvation probe: cycles a burst of valu_n x 16 v_fma_f32 takes on waves that share their SIMDs with
+ * waves saturating the bf16 matrix pipe (out_cycles[blocks*4], s_memtime units); prio = s_setprio level. */
+int dsnt_debug_starve(float* out, long long* out_cycles, int blocks, int mfma_iters, int valu_n, int prio,
+                      void* stream);
 
 #ifdef __cplusplus
 }

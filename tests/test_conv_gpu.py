@@ -221,7 +221,13 @@ def test_pool_upsample(N, H, W, Cc):
     assert torch.equal(back.cpu(), img)
 
 
-BF16X6_CASES = [c for c in CASES if c[3] % 16 == 0 and c[4] % 4 == 0]
+BF16X6_CASES = [c for c in CASES if c[3] % 16 == 0 and c[4] % 4 == 0] + [
+    # 3x3 / stride 1 / pad 1 with H % 8 == 0, W % 16 == 0, Cin % 32 == 0 run on the LDS halo-tile kernel
+    (2, 8, 32, 64, 64, 3, 1, 1, 1),      # 64-wide N tile
+    (1, 24, 48, 32, 160, 3, 1, 1, 1),    # ragged Cout (second N tile masked), two chunks
+    (3, 16, 16, 96, 128, 3, 1, 1, 1),    # six chunks
+    (1, 8, 16, 32, 128, 3, 1, 1, 1),     # a single tile: every halo edge is padding
+]
 
 
 @pytest.mark.parametrize('case', BF16X6_CASES)
