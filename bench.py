@@ -85,7 +85,7 @@ def dominant_kernel_roofline(batch, iters=20):
     peak = PEAK_BF16_MFMA / 6.0
     return {
         'bound': 'mfma',
-        'kernel': 'conv_fwd_bf16x6_kernel<2,2,2,2,true> 3x3 128->128 @64x64 B=%d' % batch,
+        'kernel': 'conv3x3_bf16x6_kernel<2,true> 3x3 128->128 @64x64 B=%d' % batch,
         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4), 'traffic': traffic,
         'peak_note': 'algorithmic fp32 FLOPs; peak = 2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per product '

@@ -79,7 +79,7 @@ __device__ __forceinline__ void xcd_remap(int bid, int nwg, int& out) {
 // Shared epilogue of the forward / data-gradient kernels (fp32 and bf16x6 variants).
 // HALO: the tile's 128 rows are an 8 x 16 patch of output pixels starting at row `mbase` (row r of the
 // tile is output row mbase + (r >> 4) * W + (r & 15)) instead of 128 consecutive output rows.
-template <int WM, int WN, int TM, int TN, bool HALO = false>
+template <int WM, int WN, int TM, int TN, bool HALO = false, int NT = 512>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* smem, int mtile,
                                               int ntile, int tid, int wave, int lane, int mbase = 0) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -106,8 +106,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
     }
     __syncthreads();
     constexpr int CH = BN / 4;                 // float4 chunks per row
-    constexpr int RPP = 512 / CH;              // rows per pass
-    constexpr int NP = BM / RPP;               // passes
+    constexpr int RPP = NT / CH;               // rows per pass
+    constexpr int NPT = BM / RPP;              // passes
+    constexpr int NP = NPT > 8 ? 8 : NPT;      // passes per group (bounds the residual registers)
+    constexpr int NG = NPT / NP;
     const int ch = tid % CH, r0 = tid / CH;
     const int n0 = ntile * BN + ch * 4;
     const bool vn = n0 < p.Cout;
@@ -121,19 +123,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         bmu = *reinterpret_cast<const float4*>(p.bnb_mean + n0);
         bis = *reinterpret_cast<const float4*>(p.bnb_invstd + n0);
     }
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
     float4 r1[NP], r2[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int m = rowmap(r0 + RPP * j);
+        const int m = rowmap(r0 + RPP * (gi * NP + j));
         const bool ok = vn && m < p.M;
         const size_t o = ok ? (size_t)m * p.Cout + n0 : 0;
         r1[j] = p.res1 ? *reinterpret_cast<const float4*>(p.res1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         r2[j] = p.res2 ? *reinterpret_cast<const float4*>(p.res2 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int row = r0 + RPP * j;
+        const int row = r0 + RPP * (gi * NP + j);
         const int m = rowmap(row);
         if (vn && m < p.M) {
             float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + ch * 4);
@@ -159,6 +163,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
             s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
         }
+    }
     }
     if (p.stats) {
         __syncthreads();                       // every thread has read its part of Cs
@@ -875,14 +880,18 @@ extern "C" int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bia
 // ---------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution on bf16x6 with an LDS halo tile.
 //
-// Why: on this hardware a wave that issues MFMAs back-to-back monopolises its SIMD — VALU work of
-// other waves on that SIMD only runs in the gaps (tools/starve.py: a 128-instruction VALU burst takes
-// the whole MFMA phase to finish), and when it runs it runs instead of, not beside, the matrix pipe.
-// In the implicit-GEMM kernel above every filter tap re-loads, re-normalises and re-splits the same
-// input pixels (9x the VALU work, 2.4x the HBM traffic of the tensor).  Here a workgroup owns an
-// 8 x 16 patch of output pixels: the (8+2) x (16+2) input halo of 16 channels is transformed and
-// split ONCE into LDS, then all nine taps run from it with shifted fragment addresses (immediate
-// offsets), while only the pre-split weights stream through the double-buffered B tile.
+// Why: VALU issue on a SIMD is arbitrated by priority, then age, and a wave issuing MFMAs back to back
+// keeps winning: the loader waves' VALU work only runs in the gaps (tools/starve.py: a 128-instruction
+// VALU burst next to a saturated matrix pipe takes the whole MFMA phase to finish).  In the implicit-GEMM
+// kernel above every filter tap re-loads, re-normalises and re-splits the same input pixels (9x the
+// VALU work, 2.4x the HBM traffic of the tensor).  Here a workgroup owns an 8 x 16 patch of output
+// pixels: the (8+2) x (16+2) input halo of 16 channels is transformed and split ONCE into LDS, then all
+// nine taps run from it with shifted fragment addresses (immediate offsets), while only the pre-split
+// weights stream through the double-buffered B tile (a 16-byte copy, no VALU).
+// (A variant without the loader/MFMA role split — 256 threads, fragments of step s+1 read during the
+// MFMAs of step s — reached 84 % matrix-pipe use inside the K loop but was 8 % slower end to end: with
+// 72 K-steps per tile the ~10k-cycle prologue and ~12k-cycle epilogue of two lock-stepped workgroups
+// per CU dominate either way.)
 //   LDS: A halo [3 planes][192 px][24] bf16 (27.6 KB, single buffer: refilled at chunk boundaries
 //   from registers that were loaded nine steps earlier) + B [2][3][BN][24] bf16 (36.9 KB).
 // K order is (16-channel chunk, tap) instead of (tap, channel): same products, different fp32

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libdsnt_hip.so')
+# DSNT_HIP_LIB points at another build of the same library (kernel experiments); default: the in-tree build
+LIB_PATH = os.environ.get('DSNT_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libdsnt_hip.so')
 
 P = C.c_void_p
 I = C.c_int
@@ -111,6 +112,8 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = res
+        if os.environ.get('DSNT_FORCE_GEMM6'):       # A/B switch: 3x3 convolutions on the implicit-GEMM kernel
+            lib.dsnt_debug_force_gemm6(1)
         _lib = lib
     return _lib
 

@@ -47,7 +47,8 @@ t0 = t[:, :, 0][t[:, :, 0] > 0].min()
 start = t[:, 0, 0] - t0; end = t[:, 0, 125] - t0
 print('workgroups %d, distinct CUs %d, kernel span %d cycles' % (nwg, len(set(key.tolist())), end.max()))
 nst = min(41, (k * k * Cin) // 16)
-mf = t[:, 0:4, :] - t0; ld = t[:, 4:8, :] - t0
+nthreads = int(os.environ.get('TL_WAVES', '8'))
+mf = t[:, 0:4, :] - t0; ld = (t[:, 4:8, :] if nthreads == 8 else t[:, 0:4, :]) - t0
 sl = np.arange(nst)
 step_start = mf[:, :, 1 + 3 * sl]; rd_done = mf[:, :, 2 + 3 * sl]; mm_done = mf[:, :, 3 + 3 * sl]
 # steady-state workgroups only: started in the first wave of the launch
@@ -77,3 +78,10 @@ for s in range(8, 14):
             i, mf[i, 0, 1 + 3 * s], mf[i, 0, 2 + 3 * s] - mf[i, 0, 1 + 3 * s], mf[i, 0, 3 + 3 * s] - mf[i, 0, 2 + 3 * s],
             ld[i, 0, 1 + 3 * s], ld[i, 0, 2 + 3 * s] - ld[i, 0, 1 + 3 * s], ld[i, 0, 3 + 3 * s] - ld[i, 0, 2 + 3 * s]))
     print('  s=%d ' % s + ' | '.join(row))
+# launch-level view: when do workgroups start / end, how long do they live
+dur = (t[:, 0, 125] - t[:, 0, 0])
+print('workgroup lifetime: mean %d  p10 %d  p90 %d cycles' % (dur.mean(), np.percentile(dur, 10), np.percentile(dur, 90)))
+print('start time percentiles (0,10,25,50,75,90,100):', [int(np.percentile(start, q)) for q in (0, 10, 25, 50, 75, 90, 100)])
+print('end   time percentiles (0,10,25,50,75,90,100):', [int(np.percentile(end, q)) for q in (0, 10, 25, 50, 75, 90, 100)])
+pro = t[:, 0, 1] - t[:, 0, 0]; epi = t[:, 0, 125] - t[:, 0, 124]
+print('prologue (start -> first step) mean %d p90 %d ; epilogue mean %d p90 %d' % (pro.mean(), np.percentile(pro, 90), epi.mean(), np.percentile(epi, 90)))
