@@ -83,7 +83,11 @@ template <int WM, int WN, int TM, int TN, bool HALO = false, int NT = 512>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][TN], float* smem, int mtile,
                                               int ntile, int tid, int wave, int lane, int mbase = 0) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    auto rowmap = [&](int row) { return HALO ? mbase + (row >> 4) * p.W + (row & 15) : mtile * BM + row; };
+    // (odd patch rows are rotated by two pixels: tile row r holds pixel column (r + 14) & 15 there, which keeps
+    // the 18-pixel halo pitch on the conflict-free ds_read_b128 bank pattern — see conv3x3_bf16x6_kernel)
+    auto rowmap = [&](int row) {
+        return HALO ? mbase + (row >> 4) * p.W + (((row & 15) + ((row >> 4) & 1) * 14) & 15) : mtile * BM + row;
+    };
     const int lr = lane & 31, lh = lane >> 5;
     const int cw = wave & 3;
     const int wm = cw / WN, wn = cw % WN;
@@ -1035,7 +1039,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
         int aoff[TM], boff[TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
-            aoff[a] = (((wm * TM + a) * 2 + (lr >> 4)) * HWD + (lr & 15)) * PITCH6 + 8 * lh;
+            // lanes 16..31 sit one halo row (18 pixels) further: rotating their pixel column by two restores
+            // the 16-pixel period of the conflict-free ds_read_b128 pattern (26 % -> ~0 % bank conflicts)
+            aoff[a] = (((wm * TM + a) * 2 + (lr >> 4)) * HWD + ((lr + (lr >> 4) * 14) & 15)) * PITCH6 + 8 * lh;
 #pragma unroll
         for (int b = 0; b < TN; ++b) boff[b] = ((wn * TN + b) * 32 + lr) * PITCH6 + 8 * lh;
         __syncthreads();
