@@ -1657,13 +1657,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
 }
 
 // Slab reduction: 64 float4 columns x 4 split-lanes per block, 8 loads in flight per thread.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                            float* __restrict__ dbias, int splits, int CK, int Cout,
-                                                            int accumulate) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, float* __restrict__ dw,
+                                                  float* __restrict__ dbias, int splits, int CK, int Cout,
+                                                  int accumulate, int block) {
     __shared__ float4 red[256];
     const int total4 = CK / 4;
     const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + col;
+    const int i = block * 64 + col;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < total4) {
         int s = sl;
@@ -1708,6 +1708,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                            float* __restrict__ dbias, int splits, int CK, int Cout,
+                                                            int accumulate) {
+    wgrad_reduce_body(ws, dw, dbias, splits, CK, Cout, accumulate, blockIdx.x);
+}
+
+// Deferred slab reduction of many convolutions in one launch: blockIdx.y = table row
+// {ws, dw, dbias (0 = none), splits, Cout*K, Cout, accumulate}, blockIdx.x = 64-column block of that row.
+__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const long long* __restrict__ table) {
+    const long long* t = table + (size_t)blockIdx.y * 7;
+    const int CK = (int)t[4], Cout = (int)t[5];
+    const int total = CK / 4 + (Cout + 3) / 4;
+    if ((int)blockIdx.x * 64 >= total) return;
+    wgrad_reduce_body(reinterpret_cast<const float*>(t[0]), reinterpret_cast<float*>(t[1]),
+                      reinterpret_cast<float*>(t[2]), (int)t[3], CK, Cout, (int)t[6], blockIdx.x);
+}
+
+extern "C" int dsnt_wgrad_reduce_all(const int64_t* table, int rows, int max_blocks, void* stream) {
+    DSNT_REQUIRE(table && rows > 0 && rows <= 65535 && max_blocks > 0, DSNT_ERR_ARG, "dsnt_wgrad_reduce_all: bad argument");
+    hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(max_blocks, rows), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)table);
+    DSNT_CHECK_LAUNCH("dsnt_wgrad_reduce_all");
+}
+
 static void wgrad_plan(const dsnt_conv_geom* g, int& ktiles, int& ntiles, int& splits, int& rps) {
     const long M = (long)g->N * g->Ho * g->Wo;
     const int K = g->R * g->S * g->Cin;
@@ -1730,6 +1754,13 @@ extern "C" int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g) {
     int kt, nt, sp, rps;
     wgrad_plan(g, kt, nt, sp, rps);
     return (int64_t)sp * g->Cout * (g->R * g->S * g->Cin) + (int64_t)sp * g->Cout;
+}
+
+extern "C" int dsnt_conv_wgrad_splits(const dsnt_conv_geom* g) {
+    if (!g) return 0;
+    int kt, nt, sp, rps;
+    wgrad_plan(g, kt, nt, sp, rps);
+    return sp;
 }
 
 static int conv_wgrad_impl(const float* x, const float* in_scale, const float* in_shift, int in_relu,
@@ -1761,12 +1792,13 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
                            const float* dy, float* ws, float* dw, float* dbias, int accumulate,
                            const dsnt_conv_geom* g, void* stream, bool bf16x6) {
     if (int e = check_geom(g, "dsnt_conv_wgrad")) return e;
-    DSNT_REQUIRE(x && dy && ws && dw, DSNT_ERR_ARG, "dsnt_conv_wgrad: null tensor");
+    DSNT_REQUIRE(x && dy && ws, DSNT_ERR_ARG, "dsnt_conv_wgrad: null tensor");
+    DSNT_REQUIRE(dw || !dbias, DSNT_ERR_ARG, "dsnt_conv_wgrad: dbias without dw");
     DSNT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DSNT_ERR_ARG,
                  "dsnt_conv_wgrad: in_scale/in_shift must be given together");
     DSNT_REQUIRE(g->Cout % 4 == 0, DSNT_ERR_ALIGN, "dsnt_conv_wgrad: Cout=%d must be a multiple of 4",
                  g->Cout);
-    DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(dy) && dsnt_aligned16(ws) && dsnt_aligned16(dw),
+    DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(dy) && dsnt_aligned16(ws) && (!dw || dsnt_aligned16(dw)),
                  DSNT_ERR_ALIGN, "dsnt_conv_wgrad: tensors must be 16-byte aligned");
     WgradP p;
     p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.dy = dy; p.ws = ws; p.in_relu = in_relu;
@@ -1790,9 +1822,11 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
         hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(256), 0, st, p);
     else
         hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(grid), dim3(256), 0, st, p);
-    const int CK = p.Cout * p.K;
-    const int total = CK / 4 + (p.Cout + 3) / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias,
-                       p.splits, CK, p.Cout, accumulate);
+    if (dw) {       // dw == nullptr: slabs only, the caller reduces later (dsnt_wgrad_reduce_all)
+        const int CK = p.Cout * p.K;
+        const int total = CK / 4 + (p.Cout + 3) / 4;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias,
+                           p.splits, CK, p.Cout, accumulate);
+    }
     DSNT_CHECK_LAUNCH("dsnt_conv_wgrad");
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     'dsnt_split_bf16x3': [P, P, L, P],
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_bf16x6': [P, P, P, I, P, P, P, P, I, GP, P],
+    'dsnt_wgrad_reduce_all': [P, I, I, P],
     'dsnt_bn_stats': [P, P, L, I, P],
     'dsnt_bn_finalize': [P, I, L, I, P, P, P, P, F, F, I, P, P, P, P, P],
     'dsnt_bn_act_fwd': [P, P, P, I, P, L, I, P],
@@ -88,6 +89,7 @@ PLAIN = {
     'dsnt_conv_fwd_bm': (I, [GP]),
     'dsnt_conv_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_bf16x6_ok': (I, [GP]),
+    'dsnt_conv_wgrad_splits': (I, [GP]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
     'dsnt_debug_set_timeline': (I, [P, I]),
 }

@@ -100,6 +100,10 @@ class Tape:
         self.dgrad_f32 = None
         self.dgrad_planes = None
         self.param_arena = None  # flat fp32 parameter arena (set by the Program) for the one-launch pack
+        # weight-gradient slabs are kept per convolution and reduced once per parameter bucket (one launch
+        # instead of one per convolution); DSNT_DEFER_REDUCE=0 reduces inside every dsnt_conv_wgrad call
+        self.defer_reduce = os.environ.get('DSNT_DEFER_REDUCE', '1') != '0'
+        self._pending_reduce = []   # table rows of the slabs written since the last flush
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float32):
@@ -222,6 +226,23 @@ class Tape:
         for fn in reversed(self._bwd_emitters):
             fn()
         self._bwd_emitters = []
+        if self._pending_reduce:          # convolutions outside every parameter bucket (stand-alone modules)
+            if self.wgrad_lane is not None:
+                self.sync_bwd(self.wgrad_lane, 0)
+            self.sync_bwd(1, 0)
+            self.lane = 0
+            self.flush_wgrad()
+
+    def flush_wgrad(self):
+        """Emit the one-launch reduction of every weight-gradient slab written since the last flush."""
+        rows = self._pending_reduce
+        if not rows:
+            return
+        self._pending_reduce = []
+        table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        self._keep.append(table)
+        blocks = max((r[4] // 4 + (r[5] + 3) // 4 + 63) // 64 for r in rows)
+        self.b('dsnt_wgrad_reduce_all', table, len(rows), blocks)
 
     def mark_bucket(self, k):
         """Forward position where parameter bucket k starts being used: in the (reversed) backward
@@ -231,6 +252,9 @@ class Tape:
                 if self.wgrad_lane is not None:
                     self.sync_bwd(self.wgrad_lane, 0)     # the bucket's weight gradients are complete
                 self.sync_bwd(1, 0)
+                lane, self.lane = self.lane, 0
+                self.flush_wgrad()
+                self.lane = lane
                 self.bwd.append((None, k, 'bucket', 0))
             self.on_backward(mark)
 
@@ -371,10 +395,19 @@ class Tape:
             wl = self.wgrad_lane if self.wgrad_lane is not None else cur
             self.sync_bwd(cur, wl)
             self.lane = wl
-            ws = self.scratch('wgrad', self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g)))
+            nws = self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g))
             w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
-            self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
-                   p.gw, p.gb, 0, g)
+            if self.defer_reduce:
+                ws = self.empty(nws)         # lives until the bucket's reduction
+                self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
+                       None, None, 0, g)
+                self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
+                                             self.lib.dsnt_conv_wgrad_splits(C.byref(g)), p.Cout * g.R * g.S * g.Cin,
+                                             p.Cout, 0])
+            else:
+                ws = self.scratch('wgrad', nws)
+                self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
+                       p.gw, p.gb, 0, g)
             self.lane = cur
             if need_input_grad:
                 assert p.stride == 1, 'data gradient of strided convs is not needed on this path'

@@ -169,7 +169,9 @@ int dsnt_conv_pack_dgrad_all(const int* table, int nconv, const float* params, f
 
 /* Weight / bias gradient: dw[Cout][R][S][Cin] = sum_m act(x)[m, (r,s,c)] * dy[m, cout],
  * dbias[cout] = sum_m dy.  `ws` is caller workspace of dsnt_conv_wgrad_ws_floats() floats.
- * accumulate != 0 adds into dw/dbias instead of overwriting. */
+ * accumulate != 0 adds into dw/dbias instead of overwriting.
+ * dw == NULL (and dbias == NULL): only the split-M partial slabs are written to `ws`; the caller keeps `ws`
+ * alive and reduces later with dsnt_wgrad_reduce_all (one launch for many convolutions). */
 int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g);
 int dsnt_conv_wgrad(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                     const float* dy, float* ws, float* dw, float* dbias, int accumulate,
@@ -181,6 +183,13 @@ int dsnt_conv_wgrad_bf16x6_ok(const dsnt_conv_geom* g);
 int dsnt_conv_wgrad_bf16x6(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                            const float* dy, float* ws, float* dw, float* dbias, int accumulate,
                            const dsnt_conv_geom* g, void* stream);
+
+/* Deferred reduction of the slabs of `rows` convolutions in one launch.  table[rows][7] (device, int64) =
+ * {ws pointer, dw pointer, dbias pointer or 0, splits, Cout*R*S*Cin, Cout, accumulate} with `splits` =
+ * dsnt_conv_wgrad_splits(g); max_blocks >= ceil((Cout*K/4 + ceil(Cout/4)) / 64) of the largest row.
+ * Same summation order as the reduction inside dsnt_conv_wgrad (bit-identical results). */
+int dsnt_conv_wgrad_splits(const dsnt_conv_geom* g);
+int dsnt_wgrad_reduce_all(const int64_t* table, int rows, int max_blocks, void* stream);
 
 /* ----------------------------------------------------- batch-norm, elementwise
  * x viewed as [M][C] (M = N*H*W), C % 4 == 0. */
