@@ -59,3 +59,20 @@ def load_reference():
             del sys.modules[k]
         sys.modules.update(saved)
     return ref_nn, ref_hg, ref_model
+
+
+def load_reference_module(name):
+    """One more module of the reference package (e.g. 'dsnt.util'), same isolation as above."""
+    if load_reference() is None:
+        return None
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'dsnt' or k.startswith('dsnt.')}
+    sys.path.insert(0, REF_SRC)
+    try:
+        mod = importlib.import_module(name)
+        assert mod.__file__.startswith(REF_SRC)
+    finally:
+        sys.path.remove(REF_SRC)
+        for k in [k for k in sys.modules if k == 'dsnt' or k.startswith('dsnt.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    return mod

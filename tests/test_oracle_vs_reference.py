@@ -146,3 +146,32 @@ def test_nn_functions_random():
         a = ref_nn.thresholded_softmax(hm.flatten(-2), -0.5)
         b = onn.thresholded_softmax(hm.flatten(-2), -0.5)
         assert (a - b).abs().max() <= tol
+
+
+def test_inference_flip_restatement_matches_reference_pieces():
+    """The reference's `inference.py` imports absent packages (progressbar, tele, torchdata), so its
+    `generate_predictions` cannot run here; pin the pieces the oracle restates instead: `reverse_tensor`
+    (util.py:207-210) and the flip-average steps (inference.py:33-57) run by hand on a reference model."""
+    ref_nn, ref_hg, ref_model = REF
+    ref_util = refimport.load_reference_module('dsnt.util')
+    from dsnt_oracle import inference as oinf, model as omodel
+    from dsnt import synthetic
+    t = torch.arange(24.).view(2, 3, 4)
+    assert torch.equal(oinf.reverse_tensor(t, -1), ref_util.reverse_tensor(t, -1))
+    rm = ref_model.build_mpii_pose_model(base='hg1', output_strat='dsnt', reg='js')
+    om = omodel.build_mpii_pose_model(base='hg1', output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(rm, seed=0)
+    om.load_state_dict(rm.state_dict())
+    rm.eval()
+    x, _, _ = synthetic.batch(1, size=64, seed=3, mask_p=1.0)
+    data = [{'input': x[0], 'transform_m': torch.eye(2, dtype=torch.float64) * 50,
+             'transform_b': torch.ones(1, 2, dtype=torch.float64)}]
+    got = oinf.generate_predictions(om, data, use_flipped=True, batch_size=1)
+    with torch.no_grad():
+        both = torch.cat([x, ref_util.reverse_tensor(x, -1)], 0)
+        hm = rm.forward_part1(both)[-1]
+        hm1, hm2 = hm.split(1)
+        hm2 = ref_util.reverse_tensor(hm2, -1).index_select(-3, oinf.HFLIP_INDICES)
+        coords = rm.compute_coords(rm.forward_part2((hm1 + hm2) / 2))
+        want = torch.baddbmm(data[0]['transform_b'][None], coords.double(), data[0]['transform_m'][None])
+    assert (got - want).abs().max().item() <= 1e-9
