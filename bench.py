@@ -5,7 +5,7 @@ A step is the reference's `bin/train.py:355-384` minus data loading, telemetry a
 forward -> forward_loss -> zero_grad -> backward (-> gradient all-reduce) -> optimiser step,
 on synthetic 256x256x3 crops already resident in HBM, 16 joints, 64x64 heat-maps.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg2_js|hg1|hg8_js] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg2_js|hg1|hg8_js|resnet34] [--batch B]
 
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
 (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.  Scaling is weak: the per-GPU batch is
@@ -34,6 +34,8 @@ WORKLOADS = {
     'hg2_js': ('hg2', 'js', 32, 53.6),
     'hg1': ('hg1', 'none', 32, 34.5),
     'hg8_js': ('hg8', 'js', 16, 168.3),
+    # BASELINE config 1 (the reference's CPU-runnable case) on the HIP path: ResNet-34 + DSNT, 8x8 heat-maps
+    'resnet34': ('resnet34', 'none', 8, 28.4),
 }
 PEAK_F32_MFMA = 157.3  # TFLOP/s, MI355X_MICROARCH.md
 
@@ -160,7 +162,8 @@ def main():
     x, target, mask = synthetic.batch(batch, size=256, seed=1 + rank, mask_p=1.0)
     x, target, mask = x.to(dev), target.to(dev), mask.to(dev)
 
-    model.hg._runner().ensure(dev)
+    runner = (model.hg if hasattr(model, 'hg') else model)._runner()
+    runner.ensure(dev)
     opt = optim.RMSprop(model, lr=2.5e-4)             # train.py:88-99 defaults for rmsprop
     if world > 1 or args.force_dp:
         if args.force_dp and not dist.is_initialized():
@@ -200,7 +203,7 @@ def main():
     out = None
     if rank == 0:
         ips = world * batch * args.steps / elapsed
-        prog = [p for p in model.hg._runner().programs.values() if p.training][0]
+        prog = [p for p in runner.programs.values() if p.training][0]
         out = {
             'metric': 'images/sec (train step, 256x256, 16 joints)',
             'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
@@ -210,9 +213,10 @@ def main():
             'dtype': 'f32', 'dtype_note': 'fp32 tensors and accumulation; large convolutions run as exact '
                                           '3-way bf16 splits on the bf16 matrix cores (bf16x6), others on fp32 MFMA',
             'data': 'synthetic',
-            'config': {'workload': '%s + DSNT%s, 256x256 -> 64x64x16, batch %d per GPU, RMSprop lr 2.5e-4, '
+            'config': {'workload': '%s + DSNT%s, 256x256 -> %s, batch %d per GPU, RMSprop lr 2.5e-4, '
                                    'train step fwd+loss+bwd%s+optim'
-                                   % (base, '' if reg == 'none' else ' + %s reg' % reg.upper(), batch,
+                                   % (base, '' if reg == 'none' else ' + %s reg' % reg.upper(),
+                                      '8x8x16' if base.startswith('resnet') else '64x64x16', batch,
                                       '+RCCL all-reduce' if world > 1 else ''),
                        'global_batch': world * batch, 'parallelism': 'dp%d' % world,
                        'launches_fwd': prog.n_fwd, 'launches_bwd': prog.n_bwd},

@@ -534,3 +534,165 @@ extern "C" int dsnt_pckh(const float* pred, const float* target, const double* m
                        target, m, b, mask, head, threshold, hits, valid, B, J);
     DSNT_CHECK_LAUNCH("dsnt_pckh");
 }
+
+// ---------------------------------------------------------------- ResNet pieces
+// 3x3 / stride 2 / pad 1 max-pool (torchvision resnet.maxpool; reference model.py:123 keeps it in `fcn`).
+// idx = winning tap 0..8 in scan order (first maximum wins, NaN propagates: ATen's max_pool2d rule).
+__global__ void maxpool3s2_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+                                      uchar4* __restrict__ idx, int N, int H, int W, int Ho, int Wo, int C4) {
+    const long total = (long)N * Ho * Wo * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        long t = i / C4;
+        const int ow = (int)(t % Wo); t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 k = make_uchar4(255, 255, 255, 255);
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int ih = 2 * oh - 1 + p / 3, iw = 2 * ow - 1 + p % 3;
+            if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+            const float4 v = x[(((long)n * H + ih) * W + iw) * C4 + cg];
+            // ATen: `if (val > maxval || isnan(val))`, maxindex starts at the window's first valid element
+            if (k.x == 255) k.x = p;
+            if (k.y == 255) k.y = p;
+            if (k.z == 255) k.z = p;
+            if (k.w == 255) k.w = p;
+            if (v.x > m.x || v.x != v.x) { m.x = v.x; k.x = p; }
+            if (v.y > m.y || v.y != v.y) { m.y = v.y; k.y = p; }
+            if (v.z > m.z || v.z != v.z) { m.z = v.z; k.z = p; }
+            if (v.w > m.w || v.w != v.w) { m.w = v.w; k.w = p; }
+        }
+        y[i] = m;
+        idx[i] = k;
+    }
+}
+
+extern "C" int dsnt_maxpool3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    DSNT_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG, "dsnt_maxpool3s2_fwd: bad argument");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && (((uintptr_t)idx) & 3) == 0,
+                 DSNT_ERR_ALIGN, "dsnt_maxpool3s2_fwd: alignment");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;        // floor((H + 2 - 3) / 2) + 1
+    const long total = (long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, (float4*)y, (uchar4*)idx, N, H, W, Ho, Wo, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_maxpool3s2_fwd");
+}
+
+// Gather form of the backward: every input pixel sums the gradients of the (at most 2 x 2) windows that
+// picked it — no atomics, deterministic.
+__global__ void maxpool3s2_bwd_kernel(const float4* __restrict__ dy, const uchar4* __restrict__ idx, float4* dx,
+                                      int accumulate, int N, int H, int W, int Ho, int Wo, int C4) {
+    const long total = (long)N * H * W * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        long t = i / C4;
+        const int iw = (int)(t % W); t /= W;
+        const int ih = (int)(t % H);
+        const int n = (int)(t / H);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        // windows with 2*oh - 1 <= ih <= 2*oh + 1
+        for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
+            if (oh >= Ho) continue;
+            const int r = ih - (2 * oh - 1);
+            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+                if (ow >= Wo) continue;
+                const int p = r * 3 + (iw - (2 * ow - 1));
+                const long o = (((long)n * Ho + oh) * Wo + ow) * C4 + cg;
+                const uchar4 k = idx[o];
+                const float4 v = dy[o];
+                if (k.x == p) g.x += v.x;
+                if (k.y == p) g.y += v.y;
+                if (k.z == p) g.z += v.z;
+                if (k.w == p) g.w += v.w;
+            }
+        }
+        if (accumulate) { const float4 c = dx[i]; g.x += c.x; g.y += c.y; g.z += c.z; g.w += c.w; }
+        dx[i] = g;
+    }
+}
+
+extern "C" int dsnt_maxpool3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int accumulate, int N, int H,
+                                   int W, int C, void* stream) {
+    DSNT_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG, "dsnt_maxpool3s2_bwd: bad argument");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dy) && dsnt_aligned16(dx), DSNT_ERR_ALIGN, "dsnt_maxpool3s2_bwd: alignment");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long total = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, N, H, W, Ho, Wo, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_maxpool3s2_bwd");
+}
+
+// y = relu?(scale * x + shift + res): the tail of a torchvision BasicBlock / Bottleneck (bn -> += identity -> relu)
+__global__ void bn_add_act_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ scale,
+                                      const float4* __restrict__ shift, const float4* __restrict__ res, int relu,
+                                      float4* __restrict__ y, long n4, int C4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        const float4 v = x[i], sc = scale[cg], sh = shift[cg], r = res[i];
+        float4 o = make_float4(fmaf(v.x, sc.x, sh.x) + r.x, fmaf(v.y, sc.y, sh.y) + r.y, fmaf(v.z, sc.z, sh.z) + r.z,
+                               fmaf(v.w, sc.w, sh.w) + r.w);
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        y[i] = o;
+    }
+}
+
+extern "C" int dsnt_bn_add_act_fwd(const float* x, const float* scale, const float* shift, const float* res,
+                                   int relu, float* y, int64_t M, int C, void* stream) {
+    DSNT_REQUIRE(x && scale && shift && res && y && M > 0 && C > 0, DSNT_ERR_ARG, "dsnt_bn_add_act_fwd: bad argument");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(res) && dsnt_aligned16(scale) &&
+                 dsnt_aligned16(shift), DSNT_ERR_ALIGN, "dsnt_bn_add_act_fwd: alignment");
+    const long n4 = (long)M * C / 4;
+    hipLaunchKernelGGL(bn_add_act_fwd_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, (const float4*)scale, (const float4*)shift, (const float4*)res, relu,
+                       (float4*)y, n4, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_bn_add_act_fwd");
+}
+
+// dz = dy where y > 0, else 0 (backward of the block-output ReLU; ATen's threshold_backward keeps dy for y > 0)
+__global__ void relu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, float4* __restrict__ dz,
+                                long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 g = dy[i], v = y[i];
+        dz[i] = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+    }
+}
+
+extern "C" int dsnt_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* stream) {
+    DSNT_REQUIRE(dy && y && dz && n > 0 && n % 4 == 0, DSNT_ERR_ARG, "dsnt_relu_bwd: bad argument");
+    DSNT_REQUIRE(dsnt_aligned16(dy) && dsnt_aligned16(y) && dsnt_aligned16(dz), DSNT_ERR_ALIGN, "dsnt_relu_bwd: alignment");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(flat_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dy, (const float4*)y, (float4*)dz, (long)(n / 4));
+    DSNT_CHECK_LAUNCH("dsnt_relu_bwd");
+}
+
+// out[n][oh*s][ow*s][c] = dy[n][oh][ow][c], zeros elsewhere (out is [N][Hs][Ws][C]): the data gradient of a
+// stride-s convolution is the stride-1 data gradient of this zero-stuffed tensor.
+__global__ void zero_insert_kernel(const float4* __restrict__ dy, float4* __restrict__ out, int N, int Ho, int Wo,
+                                   int Hs, int Ws, int s, int C4) {
+    const long total = (long)N * Hs * Ws * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % C4);
+        long t = i / C4;
+        const int w = (int)(t % Ws); t /= Ws;
+        const int h = (int)(t % Hs);
+        const int n = (int)(t / Hs);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h % s == 0 && w % s == 0 && h / s < Ho && w / s < Wo)
+            v = dy[(((long)n * Ho + h / s) * Wo + w / s) * C4 + cg];
+        out[i] = v;
+    }
+}
+
+extern "C" int dsnt_zero_insert(const float* dy, float* out, int N, int Ho, int Wo, int C, int Hs, int Ws, int stride,
+                                void* stream) {
+    DSNT_REQUIRE(dy && out && N > 0 && Ho > 0 && Wo > 0 && C > 0 && stride >= 1, DSNT_ERR_ARG, "dsnt_zero_insert: bad argument");
+    DSNT_REQUIRE(Hs >= (Ho - 1) * stride + 1 && Ws >= (Wo - 1) * stride + 1, DSNT_ERR_SHAPE,
+                 "dsnt_zero_insert: %dx%d does not hold %dx%d at stride %d", Hs, Ws, Ho, Wo, stride);
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dy) && dsnt_aligned16(out), DSNT_ERR_ALIGN, "dsnt_zero_insert: alignment");
+    const long total = (long)N * Hs * Ws * (C / 4);
+    hipLaunchKernelGGL(zero_insert_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dy, (float4*)out, N, Ho, Wo, Hs, Ws, stride, C / 4);
+    DSNT_CHECK_LAUNCH("dsnt_zero_insert");
+}

@@ -410,10 +410,20 @@ class Tape:
                        p.gw, p.gb, 0, g)
             self.lane = cur
             if need_input_grad:
-                assert p.stride == 1, 'data gradient of strided convs is not needed on this path'
                 nw = p.w.numel()
-                gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1,
-                              p.dil * (p.R - 1) - p.pad, p.dil)
+                pad_d = p.dil * (p.R - 1) - p.pad
+                assert pad_d >= 0, 'data gradient needs pad <= dil * (R - 1)'
+                if p.stride == 1:
+                    gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
+                else:
+                    # strided convolution (ResNet stage transitions): its data gradient is the stride-1 data
+                    # gradient of dY with stride-1 zeros stuffed between the pixels
+                    Hs = x.H + 2 * p.pad - p.dil * (p.R - 1)
+                    Ws = x.W + 2 * p.pad - p.dil * (p.S - 1)
+                    stuffed = self.scratch('stuffed', x.N * Hs * Ws * p.Cout).view(-1)[:x.N * Hs * Ws * p.Cout]
+                    self.b('dsnt_zero_insert', gy, stuffed, x.N, g.Ho, g.Wo, p.Cout, Hs, Ws, p.stride)
+                    gy_d = stuffed
+                    gd = ConvGeom(x.N, Hs, Ws, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
                 if slot is not None:
                     wd = self.dgrad_f32[slot:slot + nw]
                     wq, wq_stride = self.dgrad_planes[slot:slot + nw], self.dgrad_total
@@ -426,12 +436,14 @@ class Tape:
                         wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
                         self.b('dsnt_split_bf16x3', wd, wq, nw)
 
+                gsrc = gy if p.stride == 1 else gy_d
+
                 def dgrad(out, res, part=None, bnb=None):
                     if d6:
-                        self.b('dsnt_conv_fwd_bf16x6_ex', gy, wq, wq_stride, None, out, None, None, 0, res, None,
+                        self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
                                part, gd, bnb)
                     else:
-                        self.b('dsnt_conv_fwd_ex', gy, wd, None, out, None, None, 0, res, None, part, gd, bnb)
+                        self.b('dsnt_conv_fwd_ex', gsrc, wd, None, out, None, None, 0, res, None, part, gd, bnb)
                 if normed:
                     # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
                     # data-gradient epilogue; only finalise + apply remain as separate launches
@@ -477,6 +489,38 @@ class Tape:
             def backward():
                 buf, acc = self.grad_target(x)
                 self.b('dsnt_maxpool2_bwd', y.grad, idx, buf, acc, x.N, x.H, x.W, x.C)
+            self.on_backward(backward)
+        return y
+
+    def maxpool3s2(self, x, name=''):
+        """3x3 / stride 2 / pad 1 max-pool (the torchvision ResNet stem)."""
+        Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+        y = self.act(x.N, Ho, Wo, x.C, name)
+        idx = self.empty(x.N, Ho, Wo, x.C, dtype=torch.uint8)
+        self.f('dsnt_maxpool3s2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
+        if self.training:
+            def backward():
+                buf, acc = self.grad_target(x)
+                self.b('dsnt_maxpool3s2_bwd', y.grad, idx, buf, acc, x.N, x.H, x.W, x.C)
+            self.on_backward(backward)
+        return y
+
+    def bn_add_act(self, x, bn, skip, relu=True, name=''):
+        """y = relu(bn(x) + skip): the tail of a torchvision residual block (conv -> bn -> += identity -> relu)."""
+        n = self.norm(x, bn, relu=False)
+        y = self.act(x.N, x.H, x.W, x.C, name)
+        if os.environ.get('DSNT_DEBUG_NO_RELU'):
+            relu = False
+        self.f('dsnt_bn_add_act_fwd', x.buf, n.scale, n.shift, skip.buf, 1 if relu else 0, y.buf, x.M, x.C)
+        if self.training:
+            def backward():
+                if relu:
+                    dz = self.scratch('dz_tail', x.M * x.C).view(-1)[:x.M * x.C]
+                    self.b('dsnt_relu_bwd', y.grad, y.buf, dz, x.M * x.C)
+                else:
+                    dz = y.grad
+                self._norm_backward(n, dz)
+                self.grad_identity(skip, dz, donate=False)
             self.on_backward(backward)
         return y
 

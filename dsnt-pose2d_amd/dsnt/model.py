@@ -15,6 +15,7 @@ from torch import nn
 
 from . import nn as dnn
 from . import hourglass
+from . import resnet
 from .data import ImageSpecs
 
 
@@ -140,13 +141,113 @@ class HourglassHumanPoseModel(HumanPoseModel):
         raise Exception('invalid configuration')
 
 
+class ResNetHumanPoseModel(HumanPoseModel, hourglass.TapeModule):
+    """Fully-convolutional ResNet + 1x1 heat-map conv + DSNT (reference model.py:79-201).
+
+    Same constructor, attributes, quirks and `state_dict()` keys (`fcn.0.weight`, `fcn.4.0.conv1.weight`,
+    `hm_conv.weight`, ...).  `forward_part1` runs the traced HIP launch lists of the whole FCN; outputs
+    are single tensors, not lists (`:143-171`)."""
+    supports_input_grad = False
+
+    def __init__(self, resnet, n_chans=16, dilate=0, truncate=0, output_strat='dsnt',
+                 preact='softmax', reg='none', reg_coeff=1.0, hm_sigma=1.0):
+        super().__init__()
+        self.n_chans = n_chans
+        self.output_strat = output_strat
+        self.preact = preact
+        self.reg = reg
+        self.reg_coeff = reg_coeff
+        self.hm_sigma = hm_sigma
+        self.heatmap_size = 7 * 2 ** max(dilate, truncate)
+        fcn_modules = [resnet.conv1, resnet.bn1, resnet.relu, resnet.maxpool, resnet.layer1]
+        layers = [resnet.layer2, resnet.layer3, resnet.layer4]
+        # dilation surgery (model.py:112-121): in the last `dilate` groups stride-2 convs become stride 1 and
+        # every OTHER 3x3 conv is dilated (`elif`: the conv that lost its stride keeps dilation 1)
+        for i, layer in enumerate(layers[len(layers) - dilate:]):
+            d = 2 ** (i + 1)
+            for module in layer.modules():
+                if isinstance(module, nn.Conv2d):
+                    if module.stride == (2, 2):
+                        module.stride = (1, 1)
+                    elif module.kernel_size == (3, 3):
+                        module.dilation = (d, d)
+                        module.padding = ((d * 2 + 1) // 2, (d * 2 + 1) // 2)
+        fcn_modules.extend(layers[:len(layers) - truncate])
+        self.fcn = nn.Sequential(*fcn_modules)
+        if truncate > 0:
+            feats = layers[-truncate][0].conv1.in_channels
+        else:
+            feats = resnet.fc.in_features
+        self.hm_conv = nn.Conv2d(feats, self.n_chans, kernel_size=1, bias=False)
+        self.out_channels = n_chans
+        if self.output_strat == 'fc':
+            raise NotImplementedError("dsnt: output_strat='fc' is not on the DSNT hot path (SURVEY.md §8 f-4)")
+
+    @property
+    def image_specs(self):
+        return ImageSpecs(size=224, subtract_mean=False, divide_stddev=False)
+
+    def trace(self, t, x, P):
+        return resnet.trace_fcn(self.fcn, self.hm_conv, t, x, P)
+
+    def forward_part1(self, x):
+        """Forward from images to unnormalized heatmaps"""
+        return self._runner()(x)
+
+    def forward_part2(self, x):
+        """Forward from unnormalized heatmaps to output"""
+        self._fused = {}
+        if self.output_strat == 'dsnt':
+            if self.preact == 'softmax':
+                x4 = x.reshape(-1, x.size(-3), x.size(-2), x.size(-1))
+                hm, coords = dnn.head_forward(x4)
+                self._fused[id(coords)] = (x4, hm, coords)
+            else:
+                hm = self._hm_preact(x, self.preact)
+                coords = dnn.dsnt(hm)
+            self.heatmaps = hm
+            return coords
+        if self.output_strat == 'gauss':
+            self.heatmaps = x
+            return x
+        raise Exception('invalid configuration')
+
+    def forward(self, *inputs):
+        return self.forward_part2(self.forward_part1(inputs[0]))
+
+    def forward_loss(self, out_var, target_var, mask_var):
+        if self.output_strat == 'dsnt' or self.output_strat == 'fc':
+            fused = getattr(self, '_fused', {}).get(id(out_var))
+            if fused is not None and fused[2] is out_var:
+                logits, hm, coords = fused
+                sigma = 2.0 * self.hm_sigma / hm.size(-1)
+                return dnn.head_loss(logits, hm.detach(), coords.detach(), target_var, mask_var, self.reg,
+                                     sigma, self.reg_coeff)
+            loss = dnn.euclidean_loss(out_var, target_var, mask_var)
+            reg_loss = self._calculate_reg_loss(target_var, mask_var, self.reg, self.heatmaps, self.hm_sigma)
+            return loss + self.reg_coeff * reg_loss
+        if self.output_strat == 'gauss':
+            raise NotImplementedError("dsnt: output_strat='gauss' loss is not on the DSNT hot path")
+        raise Exception('invalid configuration')
+
+    def compute_coords(self, out_var):
+        if self.output_strat == 'dsnt' or self.output_strat == 'fc':
+            return out_var.detach().to('cpu', torch.float32)
+        if self.output_strat == 'gauss':
+            raise NotImplementedError("dsnt: output_strat='gauss' decoding is not on the DSNT hot path")
+        raise Exception('invalid configuration')
+
+
 def _build_resnet_pose_model(base, dilate=0, truncate=0, output_strat='dsnt', preact='softmax',
                              reg='none', reg_coeff=1.0, hm_sigma=1.0):
+    """ResNet-based pose model (reference model.py:317-343).  The reference downloads torchvision's
+    pretrained weights; there is no network here, so the backbone starts from torchvision's random
+    initialisation — load a checkpoint with `load_state_dict` for real use."""
     if base not in ('resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152'):
         raise Exception('unsupported base model type: ' + base)
-    raise NotImplementedError(
-        'dsnt: the ResNet backbone has no HIP path yet (BASELINE config 1 is the CPU reference '
-        'path; GPU ResNet is SURVEY.md §8 f-4). Use an hourglass base (hg1/hg2/hg8).')
+    net = resnet.build_resnet(base)
+    return ResNetHumanPoseModel(net, n_chans=16, dilate=dilate, truncate=truncate, output_strat=output_strat,
+                                preact=preact, reg=reg, reg_coeff=reg_coeff, hm_sigma=hm_sigma)
 
 
 def _build_hg_model(base, stacks=2, blocks=1, output_strat='gauss', preact='softmax',

@@ -18,7 +18,7 @@ def _find_arena(model):
         if r is not None and r.arena is not None:
             return r
     raise RuntimeError('dsnt.optim: no parameter arena yet — move the model to the GPU and run one '
-                       'forward pass (or call model.hg._runner().ensure(device)) before building '
+                       'forward pass (or call model.hg._runner().ensure(device); ResNet models: model._runner()) before building '
                        'the optimiser')
 
 

@@ -237,6 +237,19 @@ int dsnt_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int 
 int dsnt_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int accumulate,
                       int N, int H, int W, int C, void* stream);
 
+/* ResNet pieces (torchvision resnet consumed by model.py:79-136; third-party, restated):
+ * F.max_pool2d(x, 3, stride=2, padding=1): y [N][(H-1)/2+1][(W-1)/2+1][C], idx = winning tap 0..8;
+ * y = relu?(scale*x + shift + res) (block tail: bn -> += identity -> relu); dz = dy * [y > 0];
+ * zero-stuffing of dy for the data gradient of a strided convolution: out[n][oh*s][ow*s][c] = dy[n][oh][ow][c]. */
+int dsnt_maxpool3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int dsnt_maxpool3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int accumulate, int N, int H, int W,
+                        int C, void* stream);
+int dsnt_bn_add_act_fwd(const float* x, const float* scale, const float* shift, const float* res, int relu,
+                        float* y, int64_t M, int C, void* stream);
+int dsnt_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* stream);
+int dsnt_zero_insert(const float* dy, float* out, int N, int Ho, int Wo, int C, int Hs, int Ws, int stride,
+                     void* stream);
+
 /* out = up + nearest_upsample2x(low) (hourglass.py:58,88-89); low [N][H/2][W/2][C]. */
 int dsnt_upsample2_add_fwd(const float* up, const float* low, float* out,
                            int N, int H, int W, int C, void* stream);

@@ -18,8 +18,14 @@ def test_builder_surface_matches_reference_quirks():
     for bad in ('vgg', 'hgx'):
         with pytest.raises(Exception, match='unsupported base model type'):
             build_mpii_pose_model(base=bad)
-    with pytest.raises(NotImplementedError, match='ResNet'):
-        build_mpii_pose_model(base='resnet34')
+    r = build_mpii_pose_model(base='resnet34', truncate=1, dilate=2)    # the default base of the builder
+    o = omodel.build_mpii_pose_model(base='resnet34', truncate=1, dilate=2)
+    assert list(r.state_dict().keys()) == list(o.state_dict().keys())    # torchvision / reference key names
+    assert [tuple(v.shape) for v in r.state_dict().values()] == [tuple(v.shape) for v in o.state_dict().values()]
+    assert r.heatmap_size == 28 and r.image_specs.size == 224 and not r.image_specs.subtract_mean
+    assert r.fcn[6][0].conv1.stride == (1, 1) and r.fcn[6][0].conv2.dilation == (2, 2)   # surgery, model.py:112-121
+    with pytest.raises(RuntimeError, match='HIP device only'):           # no CPU fallback
+        r(torch.zeros(1, 3, 64, 64))
     with pytest.raises(Exception, match='unsupported base model type'):
         build_mpii_pose_model(base='resnet99')
     with pytest.raises(Exception, match='unrecognised heatmap preactivation'):

@@ -1,0 +1,180 @@
+"""ResNet backbone on the HIP path: new kernels against torch CPU ops, and
+`ResNetHumanPoseModel` end to end (coords bar 1e-4, loss, every parameter gradient) against the oracle,
+whose ResNet wrapper is pinned to the reference's in tests/test_oracle_vs_reference.py."""
+import contextlib
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dsnt import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('N,Cc,H,W', [(2, 64, 16, 16), (1, 8, 7, 9), (3, 4, 1, 5), (2, 16, 112, 112)])
+def test_maxpool3s2(N, Cc, H, W):
+    from dsnt._lib import ptr, call
+    x = synthetic.tensor('mp3', (N, Cc, H, W), seed=4).requires_grad_()
+    y_ref = F.max_pool2d(x, 3, stride=2, padding=1)
+    go = synthetic.tensor('mp3g', tuple(y_ref.shape), seed=5)
+    y_ref.backward(go)
+    Ho, Wo = y_ref.shape[-2:]
+    xd = _nhwc(x.detach()).to(DEV)
+    y = torch.empty(N, Ho, Wo, Cc, device=DEV)
+    idx = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device=DEV)
+    call('dsnt_maxpool3s2_fwd', ptr(xd), ptr(y), ptr(idx), N, H, W, Cc)
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), y_ref.detach())
+    god = _nhwc(go).to(DEV)
+    dx = torch.full((N, H, W, Cc), 7.0, device=DEV)
+    call('dsnt_maxpool3s2_bwd', ptr(god), ptr(idx), ptr(dx), 0, N, H, W, Cc)
+    assert (dx.cpu().permute(0, 3, 1, 2) - x.grad).abs().max().item() <= 1e-6
+    call('dsnt_maxpool3s2_bwd', ptr(god), ptr(idx), ptr(dx), 1, N, H, W, Cc)       # accumulate
+    assert (dx.cpu().permute(0, 3, 1, 2) - 2 * x.grad).abs().max().item() <= 2e-6
+
+
+def test_block_tail_and_zero_insert():
+    from dsnt._lib import ptr, call
+    M, Cc = 2 * 5 * 7, 32
+    x = synthetic.tensor('tx', (M, Cc), seed=1).to(DEV)
+    r = synthetic.tensor('tr', (M, Cc), seed=2).to(DEV)
+    sc = (synthetic.tensor('ts', (Cc,), seed=3, kind='uniform').abs() + 0.5).to(DEV)
+    sh = synthetic.tensor('th', (Cc,), seed=4, scale=0.3).to(DEV)
+    y = torch.empty_like(x)
+    for relu in (1, 0):
+        call('dsnt_bn_add_act_fwd', ptr(x), ptr(sc), ptr(sh), ptr(r), relu, ptr(y), M, Cc)
+        want = torch.addcmul(sh, x, sc) + r          # fma(x, sc, sh) + r
+        want = want.clamp_min(0) if relu else want
+        assert (y - want).abs().max().item() <= 1e-6
+    g = synthetic.tensor('tg', (M, Cc), seed=5).to(DEV)
+    dz = torch.empty_like(g)
+    call('dsnt_relu_bwd', ptr(g), ptr(y.clamp_min(0)), ptr(dz), M * Cc)
+    assert torch.equal(dz, torch.where(y > 0, g, torch.zeros_like(g)))
+    # zero stuffing == the scatter half of conv_transpose2d
+    N, Ho, Wo, s = 2, 3, 4, 2
+    dy = synthetic.tensor('zi', (N, Ho, Wo, 8), seed=6).to(DEV)
+    Hs, Ws = 7, 8                                    # (Ho-1)*s+1 = 5 and 7, plus slack rows/cols of zeros
+    out = torch.full((N, Hs, Ws, 8), 3.0, device=DEV)
+    call('dsnt_zero_insert', ptr(dy), ptr(out), N, Ho, Wo, 8, Hs, Ws, s)
+    want = torch.zeros(N, Hs, Ws, 8, device=DEV)
+    want[:, 0:(Ho - 1) * s + 1:s, 0:(Wo - 1) * s + 1:s] = dy
+    assert torch.equal(out, want)
+    from dsnt import _lib
+    assert _lib.fn('dsnt_zero_insert')(ptr(dy), ptr(out), N, Ho, Wo, 8, 4, 8, s, None) != 0   # too small
+
+
+class _SmoothResNet:
+    """Both implementations without ReLU (see tests/test_model_gpu.py::_NoRelu for why)."""
+
+    def __enter__(self):
+        from dsnt_oracle import resnet as ores
+        os.environ['DSNT_DEBUG_NO_RELU'] = '1'
+        self.ores, self.saved = ores, ores.F
+
+        class Shim:
+            relu = staticmethod(lambda t: t)
+        ores.F = Shim
+        return self
+
+    def __exit__(self, *a):
+        os.environ.pop('DSNT_DEBUG_NO_RELU', None)
+        self.ores.F = self.saved
+
+
+CASES = [
+    # base, dilate, truncate, size, batch, mfma
+    ('resnet18', 0, 0, 128, 4, 'f32'),
+    ('resnet18', 0, 0, 128, 4, 'bf16x6'),
+    ('resnet34', 0, 0, 256, 2, 'bf16x6'),      # BASELINE config 1's model and crop size
+    ('resnet18', 2, 0, 64, 2, 'f32'),          # dilation surgery: strides removed, 3x3 convs dilated 2 and 4
+    ('resnet18', 1, 1, 64, 2, 'bf16x6'),       # truncated + dilated
+    ('resnet50', 0, 0, 256, 2, 'f32'),         # Bottleneck blocks (128 BN samples per channel at layer4)
+]
+
+
+@pytest.mark.parametrize('base,dilate,truncate,size,batch,mfma', CASES)
+@pytest.mark.parametrize('smooth', [True, False])
+def test_resnet_pose_model_vs_oracle(base, dilate, truncate, size, batch, mfma, smooth, monkeypatch):
+    from dsnt.model import build_mpii_pose_model
+    from dsnt_oracle import model as omodel
+    import torch.nn as nn
+    monkeypatch.setenv('DSNT_MFMA', mfma)
+    if mfma == 'bf16x6':
+        monkeypatch.setenv('DSNT_BF16X6_MIN_ROWS', '0')
+    kw = dict(base=base, dilate=dilate, truncate=truncate, output_strat='dsnt', reg='js')
+    with (_SmoothResNet() if smooth else contextlib.nullcontext()):
+        m = build_mpii_pose_model(**kw)
+        o = omodel.build_mpii_pose_model(**kw)
+        if smooth:
+            o.fcn[2] = nn.Identity()
+        assert list(m.state_dict().keys()) == list(o.state_dict().keys())
+        synthetic.fill_state_dict(m, seed=4)
+        synthetic.fill_state_dict(o, seed=4)
+        m.cuda().train()
+        o.train()
+        x, target, mask = synthetic.batch(batch, size=size, seed=6, mask_p=0.8)
+        out = m(x.to(DEV))
+        loss = m.forward_loss(out, target.to(DEV), mask.to(DEV))
+        loss.backward()
+        out_o = o(x)
+        loss_o = o.forward_loss(out_o, target, mask)
+        loss_o.backward()
+    hm = size // 32 * 2 ** max(dilate, truncate)
+    assert out.shape == (batch, 16, 2) and m.heatmaps.shape == (batch, 16, hm, hm)
+    assert (out.detach().cpu() - out_o.detach()).abs().max().item() <= 1e-4          # the north-star bar
+    assert (m.heatmaps.detach().cpu() - o.heatmaps.detach()).abs().max().item() <= 1e-4
+    assert abs(loss.item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
+    coords = m.compute_coords(out)
+    assert coords.device.type == 'cpu' and coords.dtype == torch.float32
+    # every parameter gradient
+    floor = 1e-3 * max(q.grad.double().norm().item() for q in o.parameters())
+    tol = 2e-3 if smooth else 0.25
+    for (n, p), (_, q) in zip(m.named_parameters(), o.named_parameters()):
+        e = (p.grad.cpu().double() - q.grad.double()).norm().item() / max(q.grad.double().norm().item(), floor)
+        assert e <= tol, (n, e)
+    fm = torch.cat([p.grad.cpu().reshape(-1) for p in m.parameters()]).double()
+    fo = torch.cat([p.grad.reshape(-1) for p in o.parameters()]).double()
+    cos = (fm @ fo / (fm.norm() * fo.norm())).item()
+    assert cos >= (1 - 1e-6 if smooth else 0.995), cos
+    # running statistics were updated like the oracle's
+    for (n, b), (_, c) in zip(m.named_buffers(), o.named_buffers()):
+        if 'running' in n:
+            assert (b.cpu() - c).abs().max().item() <= 1e-4 * max(1.0, c.abs().max().item()), n
+    if smooth:
+        return
+    # eval mode on realistic running statistics (one more train forward with momentum 1: after a single
+    # momentum-0.1 update they are still mostly the initial 0 / 1 and the 18..50-layer eval network saturates)
+    for mod in list(m.modules()) + list(o.modules()):
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.momentum = 1.0
+    with torch.no_grad():
+        m(x.to(DEV)); o(x)
+    m.eval(); o.eval()
+    with torch.no_grad():
+        ev, ev_o = m(x.to(DEV)), o(x)
+    assert (ev.cpu() - ev_o).abs().max().item() <= 1e-4
+    from dsnt import optim
+    m.train()
+    opt = optim.RMSprop(m, lr=1e-4)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    opt.step()
+    assert all(not torch.equal(before[n], p.detach()) for n, p in m.named_parameters())   # tests/test_model.py:39-63
+
+
+def test_resnet_surface():
+    from dsnt.model import build_mpii_pose_model
+    m = build_mpii_pose_model(base='resnet34')
+    assert m.heatmap_size == 7 and m.image_specs.size == 224 and m.output_strat == 'dsnt'
+    assert m.hm_conv.in_channels == 512 and m.hm_conv.bias is None
+    assert build_mpii_pose_model(base='resnet18', dilate=2).heatmap_size == 28
+    assert build_mpii_pose_model(base='resnet50', truncate=1).hm_conv.in_channels == 1024
+    with pytest.raises(RuntimeError, match='HIP device only'):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(Exception, match='unsupported base model type'):
+        build_mpii_pose_model(base='resnet99')
