@@ -227,11 +227,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(base, reg)
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)
-        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         if world > 1:
             dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # after the process group is gone: RCCL prints its version banner late, and the JSON line must be
+        # the last line on stdout
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)       # RCCL's banner sits in the C stdio buffer until exit otherwise
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
