@@ -604,3 +604,66 @@ extern "C" int dsnt_head_bwd(const float* hm, const float* coords, const float* 
                  g_logits, h, w, sigma, gauss_k(sigma), reg_kind);
     DSNT_CHECK_LAUNCH("dsnt_head_bwd");
 }
+
+// ---------------------------------------------------------------- 'fc' output strategy
+// out[row][k] = sum_i hm[row][i] * W[k][i] + b[k], k = 0,1 — `out_fc = nn.Linear(H*W, 2)` applied to the flattened
+// heat-maps (reference model.py:222-223, 293-303; :196-198 for ResNet).  One workgroup per row.
+__global__ __launch_bounds__(256) void fc2_fwd_kernel(const float* __restrict__ hm, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ out, int hw) {
+    __shared__ float red[2][4];
+    const float* row = hm + (size_t)blockIdx.x * hw;
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+        const float v = row[i];
+        a0 = fmaf(v, w[i], a0);
+        a1 = fmaf(v, w[hw + i], a1);
+    }
+    for (int o = 32; o >= 1; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a0; red[1][threadIdx.x >> 6] = a1; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        out[(size_t)blockIdx.x * 2 + threadIdx.x] = s + (b ? b[threadIdx.x] : 0.f);
+    }
+}
+
+extern "C" int dsnt_fc2_fwd(const float* hm, const float* w, const float* b, float* out, int64_t rows, int hw,
+                            void* stream) {
+    DSNT_REQUIRE(hm && w && out && rows > 0 && rows < (1LL << 31) && hw > 0, DSNT_ERR_ARG, "dsnt_fc2_fwd: bad argument");
+    hipLaunchKernelGGL(fc2_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, hm, w, b, out, hw);
+    DSNT_CHECK_LAUNCH("dsnt_fc2_fwd");
+}
+
+// ghm[row][i] = g[row][0] W[0][i] + g[row][1] W[1][i];  gW[k][i] = sum_row g[row][k] hm[row][i];  gb[k] = sum_row g[row][k].
+// One thread per column i walks the rows in order (deterministic); rows = B * 16 is small.
+__global__ __launch_bounds__(256) void fc2_bwd_kernel(const float* __restrict__ g, const float* __restrict__ hm,
+                                                      const float* __restrict__ w, float* __restrict__ ghm,
+                                                      float* __restrict__ gw, float* __restrict__ gb, int rows, int hw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < hw) {
+        const float w0 = w[i], w1 = w[hw + i];
+        float s0 = 0.f, s1 = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const float g0 = g[2 * r], g1 = g[2 * r + 1];
+            const float v = hm[(size_t)r * hw + i];
+            if (ghm) ghm[(size_t)r * hw + i] = fmaf(g0, w0, g1 * w1);
+            s0 = fmaf(g0, v, s0);
+            s1 = fmaf(g1, v, s1);
+        }
+        gw[i] = s0;
+        gw[hw + i] = s1;
+    }
+    if (gb && blockIdx.x == 0 && threadIdx.x < 2) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += g[2 * r + threadIdx.x];
+        gb[threadIdx.x] = s;
+    }
+}
+
+extern "C" int dsnt_fc2_bwd(const float* g, const float* hm, const float* w, float* ghm, float* gw, float* gb,
+                            int64_t rows, int hw, void* stream) {
+    DSNT_REQUIRE(g && hm && w && gw && rows > 0 && rows < (1LL << 31) && hw > 0, DSNT_ERR_ARG, "dsnt_fc2_bwd: bad argument");
+    hipLaunchKernelGGL(fc2_bwd_kernel, dim3((hw + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, hm, w, ghm, gw, gb,
+                       (int)rows, hw);
+    DSNT_CHECK_LAUNCH("dsnt_fc2_bwd");
+}

@@ -37,7 +37,10 @@ class Arena:
         self.device = device
         self.publish_scale = 1.0    # 1/world_size under data parallelism
         slots, off = [], 0
-        named = list(module.named_parameters())
+        # parameters the traced launch lists never touch (e.g. the 'fc' strategy's out_fc of a ResNet pose
+        # model, whose root module is the pose model itself) stay ordinary torch parameters
+        skip = tuple(getattr(module, 'tape_exclude', ()))
+        named = [(n, p) for n, p in module.named_parameters() if not (skip and n.startswith(skip))]
         bucket_of = getattr(module, 'param_bucket', lambda name: 0)
         order = sorted(range(len(named)), key=lambda i: (bucket_of(named[i][0]), i))
         nb = 1 + max([bucket_of(n) for n, _ in named] + [0])

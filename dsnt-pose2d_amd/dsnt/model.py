@@ -102,8 +102,12 @@ class HourglassHumanPoseModel(HumanPoseModel):
                 out.append(coords)
             return out
         if self.output_strat == 'fc':
-            raise NotImplementedError("dsnt: output_strat='fc' is not on the DSNT hot path "
-                                      '(SURVEY.md §8 f-4); not implemented on the HIP path')
+            self.heatmaps_array = []
+            for x in hg_outs:
+                hm = self._hm_preact(x, self.preact)
+                self.heatmaps_array.append(hm)
+                out.append(dnn.fc_coords(hm, self.out_fc.weight, self.out_fc.bias).view(-1, self.n_chans, 2))
+            return out
         raise Exception('invalid configuration')
 
     def forward(self, *inputs):
@@ -142,6 +146,7 @@ class HourglassHumanPoseModel(HumanPoseModel):
 
 
 class ResNetHumanPoseModel(HumanPoseModel, hourglass.TapeModule):
+    tape_exclude = ('out_fc.',)      # the head's Linear is not part of the traced backbone
     """Fully-convolutional ResNet + 1x1 heat-map conv + DSNT (reference model.py:79-201).
 
     Same constructor, attributes, quirks and `state_dict()` keys (`fcn.0.weight`, `fcn.4.0.conv1.weight`,
@@ -181,7 +186,7 @@ class ResNetHumanPoseModel(HumanPoseModel, hourglass.TapeModule):
         self.hm_conv = nn.Conv2d(feats, self.n_chans, kernel_size=1, bias=False)
         self.out_channels = n_chans
         if self.output_strat == 'fc':
-            raise NotImplementedError("dsnt: output_strat='fc' is not on the DSNT hot path (SURVEY.md §8 f-4)")
+            self.out_fc = nn.Linear(self.heatmap_size * self.heatmap_size, 2)
 
     @property
     def image_specs(self):
@@ -207,6 +212,10 @@ class ResNetHumanPoseModel(HumanPoseModel, hourglass.TapeModule):
                 coords = dnn.dsnt(hm)
             self.heatmaps = hm
             return coords
+        if self.output_strat == 'fc':
+            hm = self._hm_preact(x, self.preact)
+            self.heatmaps = hm
+            return dnn.fc_coords(hm, self.out_fc.weight, self.out_fc.bias).view(-1, self.n_chans, 2)
         if self.output_strat == 'gauss':
             self.heatmaps = x
             return x

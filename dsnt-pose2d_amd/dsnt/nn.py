@@ -72,6 +72,40 @@ def dsnt(heatmaps):
     return _Dsnt.apply(heatmaps)
 
 
+# ------------------------------------------------------------------ 'fc' output strategy (model.py:222-223, 293-303)
+class _Fc2(Function):
+    @staticmethod
+    def forward(ctx, heatmaps, weight, bias):
+        hm = f32(heatmaps).contiguous()
+        hw = hm.shape[-2] * hm.shape[-1]
+        rows = _rows(hm, 2)
+        if tuple(weight.shape) != (2, hw):
+            raise RuntimeError('dsnt.nn.fc_coords: weight must be [2, %d], got %s' % (hw, tuple(weight.shape)))
+        w = f32(weight).contiguous()
+        b = None if bias is None else f32(bias).contiguous()
+        out = torch.empty(*hm.shape[:-2], 2, device=hm.device, dtype=hm.dtype)
+        call('dsnt_fc2_fwd', ptr(hm), ptr(w), ptr(b), ptr(out), rows, hw)
+        ctx.save_for_backward(hm, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hm, w = ctx.saved_tensors
+        g = g.contiguous()
+        hw = w.shape[1]
+        ghm = torch.empty_like(hm) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(2, device=w.device, dtype=w.dtype) if ctx.has_bias else None
+        call('dsnt_fc2_bwd', ptr(g), ptr(hm), ptr(w), ptr(ghm), ptr(gw), ptr(gb), _rows(hm, 2), hw)
+        return ghm, gw, gb
+
+
+def fc_coords(heatmaps, weight, bias=None):
+    """`out_fc(hm.view(-1, H*W)).view(..., 2)`: the reference's fully-connected output strategy."""
+    return _Fc2.apply(heatmaps, weight, bias)
+
+
 # ------------------------------------------------------------------ masked average (nn.py:81-94)
 class _MaskedAverage(Function):
     @staticmethod

@@ -59,6 +59,13 @@ int dsnt_expect_bwd(const float* gcoords, float* ghm, int64_t rows, int h, int w
 int dsnt_make_gauss(const float* coords, float* out, int64_t rows, int h, int w, float sigma,
                     void* stream);
 
+/* 'fc' output strategy: out_fc = nn.Linear(H*W, 2) on the flattened heat-maps (model.py:222-223, 293-303, 196-198).
+ * out[rows][2] = hm[rows][hw] . W[2][hw]^T + b[2];  backward: ghm (may be NULL), gW[2][hw], gb[2] (may be NULL),
+ * overwritten, rows summed in order (deterministic). */
+int dsnt_fc2_fwd(const float* hm, const float* w, const float* b, float* out, int64_t rows, int hw, void* stream);
+int dsnt_fc2_bwd(const float* g, const float* hm, const float* w, float* ghm, float* gw, float* gb, int64_t rows,
+                 int hw, void* stream);
+
 /* nn.py:208-298 regularisers, per-row value before masked_average.
  * kind: 0 js, 1 kl, 2 mse, 3 var.  target = mu_t [rows][2]. */
 int dsnt_reg_fwd(const float* hm, const float* target, float* per_row, int64_t rows, int h, int w,

@@ -178,3 +178,53 @@ def test_resnet_surface():
         m(torch.zeros(1, 3, 64, 64))
     with pytest.raises(Exception, match='unsupported base model type'):
         build_mpii_pose_model(base='resnet99')
+
+
+@pytest.mark.parametrize('base,size', [('resnet18', 128), ('hg1', 64)])
+def test_fc_output_strategy_vs_oracle(base, size, monkeypatch):
+    """`output_strat='fc'` (model.py:222-223, 293-303 / 196-198): heat-maps -> Linear(H*W, 2) on HIP kernels;
+    coords, loss and the gradients of out_fc and of the backbone against the oracle (smooth network)."""
+    from dsnt.model import build_mpii_pose_model
+    from dsnt_oracle import model as omodel
+    import torch.nn as nn
+    monkeypatch.setenv('DSNT_MFMA', 'f32')
+    kw = dict(base=base, output_strat='fc', reg='js', preact='sigmoid')
+    if base.startswith('resnet'):
+        kw['dilate'] = 1        # 8x8 heat-maps from a 128-px input (heatmap_size is 7 * 2^dilate = 14 at 224 px)
+    smooth = _SmoothResNet() if base.startswith('resnet') else contextlib.nullcontext()
+    with smooth:
+        m = build_mpii_pose_model(**kw)
+        o = omodel.build_mpii_pose_model(**kw)
+        if base.startswith('resnet'):
+            o.fcn[2] = nn.Identity()
+            hw = (size // 16) ** 2          # one stride removed by the surgery
+        else:
+            hw = (size // 4) ** 2
+        for mod in (m, o):                  # the constructor sizes out_fc for the canonical crop (model.py:101,217-223)
+            mod.out_fc = nn.Linear(hw, 2)
+        assert list(m.state_dict().keys()) == list(o.state_dict().keys())
+        synthetic.fill_state_dict(m, seed=8)
+        synthetic.fill_state_dict(o, seed=8)
+        m.cuda().train()
+        o.train()
+        x, target, mask = synthetic.batch(4, size=size, seed=9, mask_p=0.8)
+        out = m(x.to(DEV))
+        loss = m.forward_loss(out, target.to(DEV), mask.to(DEV))
+        loss.backward()
+        out_o = o(x)
+        loss_o = o.forward_loss(out_o, target, mask)
+        loss_o.backward()
+    a = out[-1] if isinstance(out, list) else out
+    b = out_o[-1] if isinstance(out_o, list) else out_o
+    assert a.shape == (4, 16, 2) and (a.detach().cpu() - b.detach()).abs().max().item() <= 1e-4
+    assert abs(loss.item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
+    floor = 1e-3 * max(q.grad.double().norm().item() for q in o.parameters())
+    tol = 2e-3 if base.startswith('resnet') else 0.25        # the hourglass side keeps its ReLUs here
+    for (n, p), (_, q) in zip(m.named_parameters(), o.named_parameters()):
+        assert p.grad is not None, n
+        e = (p.grad.cpu().double() - q.grad.double()).norm().item() / max(q.grad.double().norm().item(), floor)
+        assert e <= (2e-3 if n.startswith('out_fc') else tol), (n, e)
+    opt = torch.optim.RMSprop(m.parameters(), lr=1e-4)      # out_fc lives outside the flat arena: stock optimiser
+    w0 = m.out_fc.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(w0, m.out_fc.weight.detach())
