@@ -133,7 +133,6 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dp', action='store_true', help='wire the data-parallel hooks even at world size 1 (testing)')
-    ap.add_argument('--graph', type=int, default=int(os.environ.get('DSNT_BENCH_GRAPH', '0')))
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -307,3 +307,37 @@ def test_wgrad_bf16x6(case, pro):
     e32 = (dw32.cpu().double() - ref).abs().max().item()
     assert e6 <= 3e-5 * scale and e6 <= max(4 * e32, 2e-6 * scale), (e6, e32)
     assert (db6.cpu().double() - b.grad).abs().max().item() <= 3e-5 * max(1.0, b.grad.abs().max().item())
+
+
+def test_deferred_slab_reduction_is_bit_identical():
+    """dsnt_conv_wgrad(dw=NULL) + one dsnt_wgrad_reduce_all over several convolutions == the per-conv reduction."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    dev = torch.device('cuda:0')
+    cases = [(2, 16, 16, 128, 128, 3, 1, 1, 1), (2, 16, 16, 256, 128, 1, 1, 0, 1), (3, 8, 8, 16, 256, 1, 1, 0, 1)]
+    rows, keep, want = [], [], []
+    for ci, (N, H, W, Cin, Cout, k, stride, pad, dil) in enumerate(cases):
+        g = _geom(N, H, W, Cin, Cout, k, k, stride, pad, dil)
+        x = synthetic.tensor('dr%dx' % ci, (N, H, W, Cin), seed=3).to(dev)
+        gy = synthetic.tensor('dr%dg' % ci, (N, g.Ho, g.Wo, Cout), seed=4).to(dev)
+        fn = 'dsnt_conv_wgrad_bf16x6' if ci < 2 else 'dsnt_conv_wgrad'
+        nws = _lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g))
+        ws1, ws2 = torch.empty(nws, device=dev), torch.empty(nws, device=dev)
+        dw1, db1 = torch.empty(Cout, k, k, Cin, device=dev), torch.empty(Cout, device=dev)
+        dw2, db2 = torch.full((Cout, k, k, Cin), 9.0, device=dev), torch.full((Cout,), 9.0, device=dev)
+        call(fn, ptr(x), None, None, 0, ptr(gy), ptr(ws1), ptr(dw1), ptr(db1), 0, C.byref(g))
+        call(fn, ptr(x), None, None, 0, ptr(gy), ptr(ws2), None, None, 0, C.byref(g))     # slabs only
+        with_bias = ci != 1
+        rows.append([ws2.data_ptr(), dw2.data_ptr(), db2.data_ptr() if with_bias else 0,
+                     _lib.fn('dsnt_conv_wgrad_splits')(C.byref(g)), Cout * k * k * Cin, Cout, 0])
+        keep.append((x, gy, ws1, ws2))
+        want.append((dw1, db1, dw2, db2, with_bias))
+    table = torch.tensor(rows, dtype=torch.int64).to(dev)
+    blocks = max((r[4] // 4 + (r[5] + 3) // 4 + 63) // 64 for r in rows)
+    call('dsnt_wgrad_reduce_all', ptr(table), len(rows), blocks)
+    for dw1, db1, dw2, db2, with_bias in want:
+        assert torch.equal(dw1, dw2)
+        assert torch.equal(db1, db2) if with_bias else bool((db2 == 9.0).all())
+    assert _lib.fn('dsnt_wgrad_reduce_all')(None, 1, 1, None) != 0
+    assert _lib.fn('dsnt_conv_wgrad')(ptr(keep[0][0]), None, None, 0, ptr(keep[0][1]), ptr(keep[0][2]), None,
+                                       ptr(want[0][1]), 0, C.byref(_geom(*cases[0][:5], 3, 3, 1, 1, 1)), None) != 0
