@@ -32,7 +32,8 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, 'build', os.path.splitext(src)[0] + '.o')
         objs.append(o)
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
-            cmd = [hipcc] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
+            extra = ['-fno-slp-vectorize'] if src == 'conv.hip' else []     # no v_pk_*_f32 beside the MFMAs
+            cmd = [hipcc] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
             jobs.append(cmd)
     def run(cmd):
         if verbose:

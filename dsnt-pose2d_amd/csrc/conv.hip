@@ -530,7 +530,11 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
-// 4 floats -> three planes of 4 bf16 (2 dwords each): exact 3-way split
+// 4 floats -> three planes of 4 bf16 (2 dwords each): exact 3-way split, 5.5 VALU instructions per
+// element.  Deliberately NOT on packed fp32 ops: beside MFMAs a v_pk_add_f32 / v_pk_fma_f32 costs more
+// issue time than the two plain instructions it replaces (MI355X_MICROARCH.md, cycle constants), and
+// these kernels are bound by the SIMD's vector-issue port (conv.hip is built with -fno-slp-vectorize).
+typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
     p1.x = pk_bf16(v.x, v.y); p1.y = pk_bf16(v.z, v.w);
     float4 r;
@@ -635,6 +639,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
             unsigned ok;
         };
         Stage S0, S1;
+        const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
         auto gload = [&](Stage& st, int step) {
             const int kb = step * BK6;
             const int tap = kb / p.Cin, cb = kb - tap * p.Cin;
@@ -659,18 +664,20 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
                 float4 v = make_float4(__uint_as_float(st.ra[i].x), __uint_as_float(st.ra[i].y),
                                        __uint_as_float(st.ra[i].z), __uint_as_float(st.ra[i].w));
                 uint2 q1, q2, q3;
-                if (PRO) {
-                    v.x = fmaf(v.x, st.sc.x, st.sh.x); v.y = fmaf(v.y, st.sc.y, st.sh.y);
-                    v.z = fmaf(v.z, st.sc.z, st.sh.z); v.w = fmaf(v.w, st.sc.w, st.sh.w);
-                    if (p.in_relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                }
                 // branch-free zero padding (a divergent branch around the loaded registers makes hipcc
                 // drain vmcnt(0) before the next prefetch: see the fp32 loader)
                 const bool ok = (st.ok >> i) & 1u;
-                v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                if (PRO) {
+                    // BN FMAs; ReLU and the padding select as ONE median per element:
+                    // valid rows clamp to [0 or -inf, +inf), padded rows to [0, 0]
+                    const sp_f32x2 a = {fmaf(v.x, st.sc.x, st.sh.x), fmaf(v.y, st.sc.y, st.sh.y)};
+                    const sp_f32x2 b = {fmaf(v.z, st.sc.z, st.sh.z), fmaf(v.w, st.sc.w, st.sh.w)};
+                    const float lo = ok ? lo_valid : 0.f, hi = ok ? __builtin_inff() : 0.f;
+                    v.x = __builtin_amdgcn_fmed3f(a.x, lo, hi); v.y = __builtin_amdgcn_fmed3f(a.y, lo, hi);
+                    v.z = __builtin_amdgcn_fmed3f(b.x, lo, hi); v.w = __builtin_amdgcn_fmed3f(b.y, lo, hi);
+                } else {
+                    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                }
                 split4(v, q1, q2, q3);
                 __bf16* dst = A6 + ((size_t)(buf * 3) * BM + lrow + 64 * i) * PITCH6 + kc * 4;
                 *reinterpret_cast<uint2*>(dst) = q1;
@@ -963,6 +970,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
         u32x4 ra[3], rb[2][3];
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         const int lastc = nchunks - 1;
+        const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
         auto gloadA = [&](int c) {
             c = min(c, lastc);
             if (PRO) {
@@ -978,14 +986,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
                 float4 v = make_float4(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y),
                                        __uint_as_float(ra[i].z), __uint_as_float(ra[i].w));
                 if (PRO) {
-                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-                    v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-                    if (p.in_relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    const bool ok = (aok >> i) & 1u;       // zero padding is applied after BN + ReLU
-                    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+                    // BN FMAs; ReLU + zero padding (applied after BN + ReLU) as one median per element
+                    const sp_f32x2 a = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y)};
+                    const sp_f32x2 b = {fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
+                    const bool ok = (aok >> i) & 1u;
+                    const float lo = ok ? lo_valid : 0.f, hi = ok ? __builtin_inff() : 0.f;
+                    v.x = __builtin_amdgcn_fmed3f(a.x, lo, hi); v.y = __builtin_amdgcn_fmed3f(a.y, lo, hi);
+                    v.z = __builtin_amdgcn_fmed3f(b.x, lo, hi); v.w = __builtin_amdgcn_fmed3f(b.y, lo, hi);
                 }
                 uint2 q1, q2, q3;
                 split4(v, q1, q2, q3);
@@ -1268,7 +1275,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
     __shared__ __attribute__((aligned(16))) float As[2][32][WPITCH];
     __shared__ __attribute__((aligned(16))) float Gs[2][32][WPITCH];
 
-    int bid = blockIdx.x;
+    int bid;
+    xcd_remap(blockIdx.x, gridDim.x, bid);
     const int ktile = bid % p.ktiles; bid /= p.ktiles;
     const int ntile = bid % p.ntiles;
     const int split = bid / p.ntiles;
@@ -1452,14 +1460,135 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
 // block, loads four rows, applies BN+ReLU / zero padding (A only), splits and packs pairs of ROWS with
 // v_cvt_pk_bf16_f32, i.e. the transpose costs no extra instruction.  128 threads stage A, 128 stage G;
 // waves 0..3 run the MFMAs (64 x 64 of the 128 x 128 tile each), one barrier per 16 rows of m.
-template <bool PRO>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
+//
+// The kernel is bound by the loaders' VALU work (a SIMD issues either an MFMA or a VALU instruction:
+// DESIGN.md "issue starvation"), so the two loader kinds are separate straight-line instantiations:
+// the G waves only split (out-of-range buffer loads already return zeros), the A waves fold ReLU and
+// the zero-padding select into one v_med3_f32 against per-row bounds, and the split itself runs on
+// plain (unpacked) fp32 ops (split4).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool PRO, bool IS_A>
+__device__ __forceinline__ void wgrad6_loader(const WgradP& p, __bf16* T, const int ltid, const int ktile,
+                                              const int ntile, const int m_begin, const int m_end,
+                                              const int nsteps, f32x2& bs0, f32x2& bs1) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // 4-wide column chunk q, 4-row block mb.  mb varies fastest: a 16-lane store group then spans
+    // 4 chunks x 4 blocks (2-way bank conflicts; q fastest would be 8-way with the 48-byte pitch)
+    const int mb = ltid & 3, q = (ltid >> 2) & 31;
+    const unsigned OOB = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(IS_A ? p.x : p.dy), 0,
+        IS_A ? (int)((size_t)p.N * p.H * p.W * p.Cin * 4u) : (int)((size_t)p.M * p.Cout * 4u), 0x00020000);
+    // A side: fixed tap / channel chunk
+    const int k0 = ktile * 128 + q * 4;
+    const bool vk = k0 < p.K;
+    const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
+    const int r = tap / p.S, s_ = tap - r * p.S;
+    const int dh = r * p.dil - p.pad, dw = s_ * p.dil - p.pad;
+    f32x2 sc0 = {1.f, 1.f}, sc1 = {1.f, 1.f}, sh0 = {0.f, 0.f}, sh1 = {0.f, 0.f};
+    if (PRO && IS_A && vk) {
+        const float4 a = *reinterpret_cast<const float4*>(p.in_scale + c);
+        const float4 b = *reinterpret_cast<const float4*>(p.in_shift + c);
+        sc0 = (f32x2){a.x, a.y}; sc1 = (f32x2){a.z, a.w};
+        sh0 = (f32x2){b.x, b.y}; sh1 = (f32x2){b.z, b.w};
+    }
+    // ReLU and the padding select as one median: valid rows clamp to [lo, +inf) with lo = 0 (ReLU) or
+    // -inf (no ReLU), invalid rows to [0, 0]
+    const float lo_valid = (PRO && IS_A && p.in_relu) ? 0.f : -__builtin_inff();
+    // G side
+    const int n0 = ntile * 128 + q * 4;
+    const bool vn = n0 < p.Cout;
+    // first row of this thread's 4-row block (Wo % 4 == 0: the 4 rows share n and oh)
+    const int HoWo = p.Ho * p.Wo;
+    int rm = m_begin + mb * 4;
+    const int mm0 = rm < p.M ? rm : 0;
+    int rn = mm0 / HoWo;
+    int roh = (mm0 - rn * HoWo) / p.Wo;
+    int row_ = mm0 - rn * HoWo - roh * p.Wo;
+    const int adv_h = 16 / p.Wo, adv_w = 16 - adv_h * p.Wo;
+    struct Stage { u32x4 v[4]; unsigned ok; };
+    Stage S0, S1;
+    auto gload = [&](Stage& st) {
+        st.ok = 0;
+        if (IS_A) {
+            const int ih = roh * p.stride + dh;
+            const bool vrow = vk && ih >= 0 && ih < p.H;
+            const int base = ((rn * p.H + ih) * p.W) * p.Cin + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iw = (row_ + j) * p.stride + dw;
+                const bool ok = (rm + j) < m_end && vrow && iw >= 0 && iw < p.W;
+                const unsigned off = (unsigned)(base + iw * p.Cin) * 4u;
+                st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
+                st.ok |= (ok ? 1u : 0u) << j;
+            }
+            row_ += adv_w; roh += adv_h;
+            if (row_ >= p.Wo) { row_ -= p.Wo; roh += 1; }
+            while (roh >= p.Ho) { roh -= p.Ho; rn += 1; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (rm + j) < m_end && vn;
+                const unsigned off = (unsigned)((rm + j) * p.Cout + n0) * 4u;
+                st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
+            }
+        }
+        rm += 16;
+    };
+    auto lstore = [&](const Stage& st, int buf) {
+        f32x2 v0[4], v1[4];      // (x, y) and (z, w) of the four rows
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v0[j] = (f32x2){__uint_as_float(st.v[j].x), __uint_as_float(st.v[j].y)};
+            v1[j] = (f32x2){__uint_as_float(st.v[j].z), __uint_as_float(st.v[j].w)};
+            if (PRO && IS_A) {
+                v0[j].x = fmaf(v0[j].x, sc0.x, sh0.x); v0[j].y = fmaf(v0[j].y, sc0.y, sh0.y);
+                v1[j].x = fmaf(v1[j].x, sc1.x, sh1.x); v1[j].y = fmaf(v1[j].y, sc1.y, sh1.y);
+                const bool ok = (st.ok >> j) & 1u;
+                const float lo = ok ? lo_valid : 0.f, hi = ok ? __builtin_inff() : 0.f;
+                v0[j].x = __builtin_amdgcn_fmed3f(v0[j].x, lo, hi); v0[j].y = __builtin_amdgcn_fmed3f(v0[j].y, lo, hi);
+                v1[j].x = __builtin_amdgcn_fmed3f(v1[j].x, lo, hi); v1[j].y = __builtin_amdgcn_fmed3f(v1[j].y, lo, hi);
+            }
+            if (!IS_A) { bs0.x += v0[j].x; bs0.y += v0[j].y; bs1.x += v1[j].x; bs1.y += v1[j].y; }
+        }
+        __bf16* base = T + ((size_t)(buf * 3) * 128 + q * 4) * PITCH6 + mb * 4;
+        // component e of the four rows -> LDS row (q*4 + e), columns mb*4 .. mb*4+3, three planes
+#define SPLIT_COL(E, V, COMP)                                                                        \
+        {                                                                                            \
+            uint2 q1, q2, q3;                                                                        \
+            split4(make_float4(V[0].COMP, V[1].COMP, V[2].COMP, V[3].COMP), q1, q2, q3);            \
+            __bf16* d = base + (E) * PITCH6;                                                         \
+            *reinterpret_cast<uint2*>(d) = q1;                                                       \
+            *reinterpret_cast<uint2*>(d + 128 * PITCH6) = q2;                                        \
+            *reinterpret_cast<uint2*>(d + 2 * 128 * PITCH6) = q3;                                    \
+        }
+        SPLIT_COL(0, v0, x) SPLIT_COL(1, v0, y) SPLIT_COL(2, v1, x) SPLIT_COL(3, v1, y)
+#undef SPLIT_COL
+    };
+    // unconditional (see the forward loader): rows past m_end load nothing and store zeros
+    gload(S0);
+    gload(S1);
+    lstore(S0, 0);
+    gload(S0);
+    __syncthreads();
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        lstore(S1, 1);
+        gload(S1);
+        __syncthreads();
+        lstore(S0, 0);
+        gload(S0);
+        __syncthreads();
+    }
+    if (s < nsteps) __syncthreads();
+}
+
+template <bool PRO>
+__device__ __forceinline__ void wgrad6_body(const WgradP& p, int bid, float* smem) {
     __bf16* At = reinterpret_cast<__bf16*>(smem);            // [2][3][128][PITCH6]
     __bf16* Gt = At + 2 * 3 * 128 * PITCH6;                  // [2][3][128][PITCH6]
 
-    int bid = blockIdx.x;
     const int ktile = bid % p.ktiles; bid /= p.ktiles;
     const int ntile = bid % p.ntiles;
     const int split = bid / p.ntiles;
@@ -1470,128 +1599,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
     const int m_end = min(p.M, m_begin + p.rows_per_split);
     const int nsteps = (m_end - m_begin + 15) / 16;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x2 bs0 = {0.f, 0.f}, bs1 = {0.f, 0.f};
 
-    if (wave >= 4) {
-        // ------------------------------------------------------------------ loader waves
-        const int ltid = tid - 256;
-        const bool isA = __builtin_amdgcn_readfirstlane(ltid) < 128;     // wave-uniform: scalar branches
-        // 4-wide column chunk q, 4-row block mb.  mb varies fastest: a 16-lane store group then spans
-        // 4 chunks x 4 blocks (2-way bank conflicts; q fastest would be 8-way with the 48-byte pitch)
-        const int mb = ltid & 3, q = (ltid >> 2) & 31;
-        const unsigned OOB = 0xF0000000u;
-        // one descriptor per wave (x for the A waves, dy for the G waves), picked with scalar selects so
-        // that both kinds run the same straight-line load sequence
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(isA ? p.x : p.dy), 0,
-            isA ? (int)((size_t)p.N * p.H * p.W * p.Cin * 4u) : (int)((size_t)p.M * p.Cout * 4u), 0x00020000);
-        // A side: fixed tap / channel chunk
-        const int k0 = ktile * 128 + q * 4;
-        const bool vk = k0 < p.K;
-        const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
-        const int r = tap / p.S, s_ = tap - r * p.S;
-        const int dh = r * p.dil - p.pad, dw = s_ * p.dil - p.pad;
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRO && isA && vk) {
-            sc = *reinterpret_cast<const float4*>(p.in_scale + c);
-            sh = *reinterpret_cast<const float4*>(p.in_shift + c);
-        }
-        // G side
-        const int n0 = ntile * 128 + q * 4;
-        const bool vn = n0 < p.Cout;
-        // first row of this thread's 4-row block (Wo % 4 == 0: the 4 rows share n and oh)
-        const int HoWo = p.Ho * p.Wo;
-        int rm = m_begin + mb * 4;
-        const int mm0 = rm < p.M ? rm : 0;
-        int rn = mm0 / HoWo;
-        int roh = (mm0 - rn * HoWo) / p.Wo;
-        int row_ = mm0 - rn * HoWo - roh * p.Wo;
-        const int adv_h = 16 / p.Wo, adv_w = 16 - adv_h * p.Wo;
-        struct Stage { u32x4 v[4]; unsigned ok; };
-        Stage S0, S1;
-        const bool relu = PRO && isA && p.in_relu;
-        auto gload = [&](Stage& st) {
-            st.ok = 0;
-            const int ih = roh * p.stride + dh;
-            const bool vrow = vk && ih >= 0 && ih < p.H;
-            const int base = ((rn * p.H + ih) * p.W) * p.Cin + c;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int iw = (row_ + j) * p.stride + dw;
-                const bool vm = (rm + j) < m_end;
-                const bool ok = vm && (isA ? (vrow && iw >= 0 && iw < p.W) : vn);
-                const unsigned off = (unsigned)(isA ? base + iw * p.Cin : (rm + j) * p.Cout + n0) * 4u;
-                st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
-                st.ok |= (ok ? 1u : 0u) << j;
-            }
-            rm += 16;
-            row_ += adv_w; roh += adv_h;
-            if (row_ >= p.Wo) { row_ -= p.Wo; roh += 1; }
-            while (roh >= p.Ho) { roh -= p.Ho; rn += 1; }
-        };
-        auto lstore = [&](const Stage& st, int buf) {
-            float4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = make_float4(__uint_as_float(st.v[j].x), __uint_as_float(st.v[j].y),
-                                   __uint_as_float(st.v[j].z), __uint_as_float(st.v[j].w));
-                if (PRO) {      // the G waves hold scale 1 / shift 0 and relu off: same code, identity
-                    v[j].x = fmaf(v[j].x, sc.x, sh.x); v[j].y = fmaf(v[j].y, sc.y, sh.y);
-                    v[j].z = fmaf(v[j].z, sc.z, sh.z); v[j].w = fmaf(v[j].w, sc.w, sh.w);
-                    if (relu) {
-                        v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f);
-                        v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
-                    }
-                    const bool ok = (st.ok >> j) & 1u;
-                    v[j].x = ok ? v[j].x : 0.f; v[j].y = ok ? v[j].y : 0.f;
-                    v[j].z = ok ? v[j].z : 0.f; v[j].w = ok ? v[j].w : 0.f;
-                }
-            }
-            if (!isA) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bsum.x += v[j].x; bsum.y += v[j].y; bsum.z += v[j].z; bsum.w += v[j].w;
-                }
-            }
-            __bf16* base = (isA ? At : Gt) + ((size_t)(buf * 3) * 128 + q * 4) * PITCH6 + mb * 4;
-            // component e of the four rows -> LDS row (q*4 + e), columns mb*4 .. mb*4+3, three planes
-#define SPLIT_COL(E, COMP)                                                                           \
-            {                                                                                        \
-                uint2 q1, q2, q3;                                                                    \
-                split4(make_float4(v[0].COMP, v[1].COMP, v[2].COMP, v[3].COMP), q1, q2, q3);        \
-                __bf16* d = base + (E) * PITCH6;                                                     \
-                *reinterpret_cast<uint2*>(d) = q1;                                                   \
-                *reinterpret_cast<uint2*>(d + 128 * PITCH6) = q2;                                    \
-                *reinterpret_cast<uint2*>(d + 2 * 128 * PITCH6) = q3;                                \
-            }
-            SPLIT_COL(0, x) SPLIT_COL(1, y) SPLIT_COL(2, z) SPLIT_COL(3, w)
-#undef SPLIT_COL
-        };
-        // unconditional (see the forward loader): rows past m_end load nothing and store zeros
-        gload(S0);
-        gload(S1);
-        lstore(S0, 0);
-        gload(S0);
-        __syncthreads();
-        int s = 0;
-        for (; s + 1 < nsteps; s += 2) {
-            lstore(S1, 1);
-            gload(S1);
-            __syncthreads();
-            lstore(S0, 0);
-            gload(S0);
-            __syncthreads();
-        }
-        if (s < nsteps) __syncthreads();
+    if (wave >= 6) {
+        wgrad6_loader<PRO, false>(p, Gt, tid - 384, ktile, ntile, m_begin, m_end, nsteps, bs0, bs1);
+    } else if (wave >= 4) {
+        wgrad6_loader<PRO, true>(p, At, tid - 256, ktile, ntile, m_begin, m_end, nsteps, bs0, bs1);
     } else {
         // ------------------------------------------------------------------ MFMA waves
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
         const int wk = wave >> 1, wn = wave & 1;
         struct Frag { bf16x8 a[2][3], b[2][3]; };
         Frag F;
@@ -1644,7 +1666,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
         __syncthreads();
         if (wave >= 6) {
             const int ltid = tid - 384;
-            *reinterpret_cast<float4*>(red + (ltid & 3) * 128 + ((ltid >> 2) & 31) * 4) = bsum;
+            *reinterpret_cast<float4*>(red + (ltid & 3) * 128 + ((ltid >> 2) & 31) * 4) =
+                make_float4(bs0.x, bs0.y, bs1.x, bs1.y);
         }
         __syncthreads();
         if (tid < 128) {
@@ -1654,6 +1677,240 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
                     red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
         }
     }
+}
+
+template <bool PRO>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // the k-tiles (filter taps) and n-tiles of one split read the same rows of x and dy: keep them in one
+    // XCD (one L2) instead of dealing them round-robin over the eight
+    int bid;
+    xcd_remap(blockIdx.x, gridDim.x, bid);
+    wgrad6_body<PRO>(p, bid, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16x6 weight gradient without the loader / MFMA role split ("unified" waves): every wave owns a 64 x 64
+// quadrant of the 128 x 128 tile AND stages a quarter of the next step's operands (waves 0,1: A rows;
+// waves 2,3: dY rows) between its MFMAs.  256 threads, 2 workgroups per CU (same 72 KB double buffer).
+// Kept as an A/B variant (DSNT_WGRAD_KERNEL=unified): it measures the same as the role-split kernel
+// (3x3 128->128 @64^2, B=32: 259 vs 261 us).  What the experiments around it showed (round 1, MI355X):
+//   * in-kernel timeline: a step takes ~3500 cycles per wave = 2270 of fragment reads + staging + 24 MFMAs
+//     (768 cycles of matrix pipe), ~400-800 to issue four buffer loads, ~450-900 at the barrier: every
+//     instruction of the two co-resident waves of a SIMD queues at one vector-issue port;
+//   * the same kernel with ALL split arithmetic removed (raw bits permuted into LDS, wrong results) was
+//     only 10 % faster (261 -> 233 us): pre-splitting the operands in HBM would not pay;
+//   * a "ping-pong" variant (512 threads, two groups alternating matrix and staging phases, one barrier
+//     per phase, so that a SIMD always pairs an MFMA wave with a staging wave) was 14 % SLOWER (298 us):
+//     a phase took ~2000 cycles, i.e. the partner's VALU stream and the MFMAs did not overlap;
+//   * packed fp32 ops (v_pk_add_f32 / v_pk_fma_f32) in the split cost more issue time than the plain
+//     instructions they replace (MI355X_MICROARCH.md): 260 -> 230 us after un-packing them.
+template <bool PRO, bool IS_A>
+__device__ __forceinline__ void wgrad6u_wave(const WgradP& p, __bf16* At, __bf16* Gt, const int ltid,
+                                             const int wave, const int lane, const int ktile, const int ntile,
+                                             const int split, float* smem) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __bf16* T = IS_A ? At : Gt;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+    const int nsteps = (m_end - m_begin + 15) / 16;
+    // ---- staging role (see wgrad6_loader)
+    const int mb = ltid & 3, q = (ltid >> 2) & 31;
+    const unsigned OOB = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(IS_A ? p.x : p.dy), 0,
+        IS_A ? (int)((size_t)p.N * p.H * p.W * p.Cin * 4u) : (int)((size_t)p.M * p.Cout * 4u), 0x00020000);
+    const int k0 = ktile * 128 + q * 4;
+    const bool vk = k0 < p.K;
+    const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
+    const int r = tap / p.S, s_ = tap - r * p.S;
+    const int dh = r * p.dil - p.pad, dw = s_ * p.dil - p.pad;
+    f32x2 sc0 = {1.f, 1.f}, sc1 = {1.f, 1.f}, sh0 = {0.f, 0.f}, sh1 = {0.f, 0.f};
+    if (PRO && IS_A && vk) {
+        const float4 a = *reinterpret_cast<const float4*>(p.in_scale + c);
+        const float4 b = *reinterpret_cast<const float4*>(p.in_shift + c);
+        sc0 = (f32x2){a.x, a.y}; sc1 = (f32x2){a.z, a.w};
+        sh0 = (f32x2){b.x, b.y}; sh1 = (f32x2){b.z, b.w};
+    }
+    const float lo_valid = (PRO && IS_A && p.in_relu) ? 0.f : -__builtin_inff();
+    const int n0 = ntile * 128 + q * 4;
+    const bool vn = n0 < p.Cout;
+    const int HoWo = p.Ho * p.Wo;
+    int rm = m_begin + mb * 4;
+    const int mm0 = rm < p.M ? rm : 0;
+    int rn = mm0 / HoWo;
+    int roh = (mm0 - rn * HoWo) / p.Wo;
+    int row_ = mm0 - rn * HoWo - roh * p.Wo;
+    const int adv_h = 16 / p.Wo, adv_w = 16 - adv_h * p.Wo;
+    struct Stage { u32x4 v[4]; unsigned ok; };
+    Stage S0, S1;
+    f32x2 bs0 = {0.f, 0.f}, bs1 = {0.f, 0.f};
+    auto gload = [&](Stage& st) {
+        st.ok = 0;
+        if (IS_A) {
+            const int ih = roh * p.stride + dh;
+            const bool vrow = vk && ih >= 0 && ih < p.H;
+            const int base = ((rn * p.H + ih) * p.W) * p.Cin + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iw = (row_ + j) * p.stride + dw;
+                const bool ok = (rm + j) < m_end && vrow && iw >= 0 && iw < p.W;
+                const unsigned off = (unsigned)(base + iw * p.Cin) * 4u;
+                st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
+                st.ok |= (ok ? 1u : 0u) << j;
+            }
+            row_ += adv_w; roh += adv_h;
+            if (row_ >= p.Wo) { row_ -= p.Wo; roh += 1; }
+            while (roh >= p.Ho) { roh -= p.Ho; rn += 1; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (rm + j) < m_end && vn;
+                const unsigned off = (unsigned)((rm + j) * p.Cout + n0) * 4u;
+                st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
+            }
+        }
+        rm += 16;
+    };
+    auto lstore = [&](const Stage& st, int buf) {
+        f32x2 v0[4], v1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v0[j] = (f32x2){__uint_as_float(st.v[j].x), __uint_as_float(st.v[j].y)};
+            v1[j] = (f32x2){__uint_as_float(st.v[j].z), __uint_as_float(st.v[j].w)};
+            if (PRO && IS_A) {
+                v0[j].x = fmaf(v0[j].x, sc0.x, sh0.x); v0[j].y = fmaf(v0[j].y, sc0.y, sh0.y);
+                v1[j].x = fmaf(v1[j].x, sc1.x, sh1.x); v1[j].y = fmaf(v1[j].y, sc1.y, sh1.y);
+                const bool ok = (st.ok >> j) & 1u;
+                const float lo = ok ? lo_valid : 0.f, hi = ok ? __builtin_inff() : 0.f;
+                v0[j].x = __builtin_amdgcn_fmed3f(v0[j].x, lo, hi); v0[j].y = __builtin_amdgcn_fmed3f(v0[j].y, lo, hi);
+                v1[j].x = __builtin_amdgcn_fmed3f(v1[j].x, lo, hi); v1[j].y = __builtin_amdgcn_fmed3f(v1[j].y, lo, hi);
+            }
+            if (!IS_A) { bs0.x += v0[j].x; bs0.y += v0[j].y; bs1.x += v1[j].x; bs1.y += v1[j].y; }
+        }
+        __bf16* base = T + ((size_t)(buf * 3) * 128 + q * 4) * PITCH6 + mb * 4;
+#define SPLIT_COL(E, V, COMP)                                                                        \
+        {                                                                                            \
+            uint2 q1, q2, q3;                                                                        \
+            split4(make_float4(V[0].COMP, V[1].COMP, V[2].COMP, V[3].COMP), q1, q2, q3);            \
+            __bf16* d = base + (E) * PITCH6;                                                         \
+            *reinterpret_cast<uint2*>(d) = q1;                                                       \
+            *reinterpret_cast<uint2*>(d + 128 * PITCH6) = q2;                                        \
+            *reinterpret_cast<uint2*>(d + 2 * 128 * PITCH6) = q3;                                    \
+        }
+        SPLIT_COL(0, v0, x) SPLIT_COL(1, v0, y) SPLIT_COL(2, v1, x) SPLIT_COL(3, v1, y)
+#undef SPLIT_COL
+    };
+    // ---- MFMA role
+    const int wk = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    struct Frag { bf16x8 a[2][3], b[2][3]; };
+    Frag F;
+    auto rd = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                F.a[t][pl] = *reinterpret_cast<const bf16x8*>(
+                    At + ((size_t)(buf * 3 + pl) * 128 + wk * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
+                F.b[t][pl] = *reinterpret_cast<const bf16x8*>(
+                    Gt + ((size_t)(buf * 3 + pl) * 128 + wn * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
+            }
+    };
+    auto mm = [&]() {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][2], F.b[b][0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][2], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][1], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][1], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][0], acc[a][b], 0, 0, 0);
+            }
+    };
+    // one half-step: fragments of the current buffer, then the MFMAs with the staging of the next step
+    // (split + LDS stores into the other buffer) scheduled between them, then the prefetch two steps ahead
+#define WG6U_HALF(SCUR, BUFC, STEP)                                                                  \
+    DBG_STAMP(1 + 3 * (STEP));                                                                       \
+    rd(BUFC);                                                                                        \
+    lstore(SCUR, 1 - (BUFC));                                                                        \
+    mm();                                                                                            \
+    DBG_STAMP(2 + 3 * (STEP));                                                                       \
+    gload(SCUR);                                                                                     \
+    DBG_STAMP(3 + 3 * (STEP));                                                                       \
+    __syncthreads();
+    DBG_INIT();
+    DBG_STAMP(0);
+    gload(S0);
+    gload(S1);
+    lstore(S0, 0);
+    gload(S0);
+    __syncthreads();
+    int s = 0;
+    for (; s + 1 < nsteps; s += 2) {
+        WG6U_HALF(S1, 0, s)
+        WG6U_HALF(S0, 1, s + 1)
+    }
+    if (s < nsteps) { rd(0); mm(); }
+    DBG_STAMP(125);
+#undef WG6U_HALF
+    // slab store: ws[split][n][k], D row = k (regs, 4 consecutive), D col = n (lane)
+    float* slab = p.ws + (size_t)split * p.Cout * p.K;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = ntile * 128 + wn * 64 + b * 32 + lr;
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int k = ktile * 128 + wk * 64 + a * 32 + 8 * qq + 4 * lh;
+                if (k < p.K)
+                    *reinterpret_cast<float4*>(slab + (size_t)n * p.K + k) =
+                        make_float4(acc[a][b][4 * qq + 0], acc[a][b][4 * qq + 1], acc[a][b][4 * qq + 2],
+                                    acc[a][b][4 * qq + 3]);
+            }
+    }
+    // bias partial: column sums of this split's dY rows (the dY-staging waves of the ktile-0 blocks)
+    if (ktile == 0) {
+        float* red = smem;   // [4][128] floats
+        __syncthreads();
+        if (!IS_A)
+            *reinterpret_cast<float4*>(red + mb * 128 + q * 4) = make_float4(bs0.x, bs0.y, bs1.x, bs1.y);
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (tid < 128) {
+            const int n = ntile * 128 + tid;
+            if (n < p.Cout)
+                p.ws[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + n] =
+                    red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+        }
+    }
+}
+
+template <bool PRO>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x6u_kernel(WgradP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* At = reinterpret_cast<__bf16*>(smem);            // [2][3][128][PITCH6]
+    __bf16* Gt = At + 2 * 3 * 128 * PITCH6;                  // [2][3][128][PITCH6]
+    int bid;
+    xcd_remap(blockIdx.x, gridDim.x, bid);
+    const int ktile = bid % p.ktiles; bid /= p.ktiles;
+    const int ntile = bid % p.ntiles;
+    const int split = bid / p.ntiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave < 2) wgrad6u_wave<PRO, true>(p, At, Gt, tid, wave, lane, ktile, ntile, split, smem);
+    else wgrad6u_wave<PRO, false>(p, At, Gt, tid - 128, wave, lane, ktile, ntile, split, smem);
 }
 
 // Slab reduction: 64 float4 columns x 4 split-lanes per block, 8 loads in flight per thread.
@@ -1814,9 +2071,17 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
         if (!attr_done) {
             hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_done = true;
         }
-        if (in_scale) hipLaunchKernelGGL(conv_wgrad_bf16x6_kernel<true>, dim3(grid), dim3(512), lds, st, p);
+        // DSNT_WGRAD_KERNEL=unified: the variant without the loader / MFMA role split (A/B switch; same speed)
+        static int unified = -1;
+        if (unified < 0) { const char* e = getenv("DSNT_WGRAD_KERNEL"); unified = (e && e[0] == 'u') ? 1 : 0; }
+        if (unified) {
+            if (in_scale) hipLaunchKernelGGL(conv_wgrad_bf16x6u_kernel<true>, dim3(grid), dim3(256), lds, st, p);
+            else hipLaunchKernelGGL(conv_wgrad_bf16x6u_kernel<false>, dim3(grid), dim3(256), lds, st, p);
+        } else if (in_scale) hipLaunchKernelGGL(conv_wgrad_bf16x6_kernel<true>, dim3(grid), dim3(512), lds, st, p);
         else hipLaunchKernelGGL(conv_wgrad_bf16x6_kernel<false>, dim3(grid), dim3(512), lds, st, p);
     } else if (in_scale)
         hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(256), 0, st, p);

@@ -21,6 +21,8 @@ _lib.fn('dsnt_split_bf16x3')(ptr(w), ptr(planes), w.numel(), st)
 for _ in range(5):
     if which == 'fwd6':
         _lib.fn('dsnt_conv_fwd_bf16x6')(ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
+    elif which == 'wgrad6':
+        _lib.fn('dsnt_conv_wgrad_bf16x6')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, C.byref(g), st)
     elif which == 'fwd':
         _lib.fn('dsnt_conv_fwd')(ptr(x), ptr(w), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
     else:
