@@ -17,6 +17,7 @@
 // bank-conflict free.  One barrier per K-step, global loads for step s+1 in flight during the
 // MFMAs of step s (register staging: the A operand needs per-element BN/ReLU/padding).
 #include "common.h"
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1689,6 +1690,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
     wgrad6_body<PRO>(p, bid, smem);
 }
 
+// Grouped launch: blockIdx.y picks one of many convolutions from a device table of WgradP descriptors
+// (dsnt_conv_wgrad_desc), blockIdx.x is the block within it.  The ~50 weight gradients of the 16x16 ... 4x4
+// hourglass levels have 4 ... 288 workgroups each and take 25-55 us apiece as separate launches (a serial
+// chain of 16-row steps per workgroup, nothing to overlap with); nothing downstream in backward needs them,
+// so the engine defers them to the end of their parameter bucket and runs them side by side in ONE launch.
+__global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_group_kernel(const WgradP* __restrict__ table) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WgradP p = table[blockIdx.y];
+    const int nblk = p.ktiles * p.ntiles * p.splits;
+    if ((int)blockIdx.x >= nblk) return;
+    wgrad6_body<true>(p, blockIdx.x, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // bf16x6 weight gradient without the loader / MFMA role split ("unified" waves): every wave owns a 64 x 64
 // quadrant of the 128 x 128 tile AND stages a quarter of the next step's operands (waves 0,1: A rows;
@@ -2045,6 +2059,45 @@ extern "C" int dsnt_conv_wgrad_bf16x6(const float* x, const float* in_scale, con
     return conv_wgrad_impl(x, in_scale, in_shift, in_relu, dy, ws, dw, dbias, accumulate, g, stream, true);
 }
 
+static void wgrad_fill(WgradP& p, const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                       const float* dy, float* ws, const dsnt_conv_geom* g) {
+    p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.dy = dy; p.ws = ws; p.in_relu = in_relu;
+    p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
+    p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
+    p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
+    wgrad_plan(g, p.ktiles, p.ntiles, p.splits, p.rows_per_split);
+}
+
+extern "C" int dsnt_conv_wgrad_desc_bytes(void) { return (int)sizeof(WgradP); }
+
+extern "C" int dsnt_conv_wgrad_desc(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                                    const float* dy, float* ws, const dsnt_conv_geom* g, void* desc_out) {
+    if (int e = check_geom(g, "dsnt_conv_wgrad_desc")) return -e;
+    if (!x || !dy || !ws || !in_scale || !in_shift || !desc_out || !dsnt_conv_wgrad_bf16x6_ok(g) ||
+        !dsnt_aligned16(x) || !dsnt_aligned16(dy) || !dsnt_aligned16(ws)) {
+        return -dsnt_set_error(DSNT_ERR_ARG, "dsnt_conv_wgrad_desc: needs x, dy, ws (16-byte aligned), in_scale/in_shift and a "
+                                             "geometry dsnt_conv_wgrad_bf16x6_ok accepts");
+    }
+    WgradP p;
+    wgrad_fill(p, x, in_scale, in_shift, in_relu, dy, ws, g);
+    memcpy(desc_out, &p, sizeof(p));
+    return p.ktiles * p.ntiles * p.splits;
+}
+
+extern "C" int dsnt_conv_wgrad_group(const void* table, int nconv, int max_blocks, void* stream) {
+    DSNT_REQUIRE(table && nconv > 0 && nconv <= 65535 && max_blocks > 0, DSNT_ERR_ARG,
+                 "dsnt_conv_wgrad_group: bad argument");
+    const int lds = 2 * 2 * 3 * 128 * PITCH6 * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_bf16x6_group_kernel, dim3(max_blocks, nconv), dim3(512), lds, (hipStream_t)stream,
+                       (const WgradP*)table);
+    DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_group");
+}
+
 static int conv_wgrad_impl(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                            const float* dy, float* ws, float* dw, float* dbias, int accumulate,
                            const dsnt_conv_geom* g, void* stream, bool bf16x6) {
@@ -2058,11 +2111,7 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
     DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(dy) && dsnt_aligned16(ws) && (!dw || dsnt_aligned16(dw)),
                  DSNT_ERR_ALIGN, "dsnt_conv_wgrad: tensors must be 16-byte aligned");
     WgradP p;
-    p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.dy = dy; p.ws = ws; p.in_relu = in_relu;
-    p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
-    p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
-    p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
-    wgrad_plan(g, p.ktiles, p.ntiles, p.splits, p.rows_per_split);
+    wgrad_fill(p, x, in_scale, in_shift, in_relu, dy, ws, g);
     hipStream_t st = (hipStream_t)stream;
     const int grid = p.ktiles * p.ntiles * p.splits;
     if (bf16x6) {

@@ -62,6 +62,7 @@ SIGNATURES = {
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_bf16x6': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_wgrad_reduce_all': [P, I, I, P],
+    'dsnt_conv_wgrad_group': [P, I, I, P],
     'dsnt_bn_stats': [P, P, L, I, P],
     'dsnt_bn_finalize': [P, I, L, I, P, P, P, P, F, F, I, P, P, P, P, P],
     'dsnt_bn_act_fwd': [P, P, P, I, P, L, I, P],
@@ -98,6 +99,8 @@ PLAIN = {
     'dsnt_conv_wgrad_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_splits': (I, [GP]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
+    'dsnt_conv_wgrad_desc_bytes': (I, []),
+    'dsnt_conv_wgrad_desc': (I, [P, P, P, I, P, P, GP, P]),
     'dsnt_debug_set_timeline': (I, [P, I]),
 }
 

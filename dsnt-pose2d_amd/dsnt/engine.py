@@ -104,6 +104,11 @@ class Tape:
         # instead of one per convolution); DSNT_DEFER_REDUCE=0 reduces inside every dsnt_conv_wgrad call
         self.defer_reduce = os.environ.get('DSNT_DEFER_REDUCE', '1') != '0'
         self._pending_reduce = []   # table rows of the slabs written since the last flush
+        # weight gradients of the low-resolution levels (few workgroups each, nothing downstream in backward
+        # needs them) wait for the end of their parameter bucket and run side by side in one grouped launch;
+        # DSNT_WGRAD_GROUP_ROWS = largest N*Ho*Wo that is deferred (0 disables)
+        self.group_rows = int(os.environ.get('DSNT_WGRAD_GROUP_ROWS', '8192')) if self.defer_reduce else 0
+        self._pending_group = []    # (descriptor bytes, workgroups) since the last flush
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float32):
@@ -239,6 +244,13 @@ class Tape:
         if not rows:
             return
         self._pending_reduce = []
+        if self._pending_group:
+            descs, self._pending_group = self._pending_group, []
+            blob = b''.join(d for d, _ in descs)
+            gtable = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
+            self._keep.append(gtable)
+            blocks = (max(n for _, n in descs) + 7) // 8 * 8
+            self.b('dsnt_conv_wgrad_group', gtable, len(descs), blocks)
         table = torch.tensor(rows, dtype=torch.int64).to(self.device)
         self._keep.append(table)
         blocks = max((r[4] // 4 + (r[5] + 3) // 4 + 63) // 64 for r in rows)
@@ -399,8 +411,20 @@ class Tape:
             w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
             if self.defer_reduce:
                 ws = self.empty(nws)         # lives until the bucket's reduction
-                self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
-                       None, None, 0, g)
+                # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
+                # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
+                grouped = (w6 and normed and res1 is None and res2 is None and wl == cur and
+                           0 < g.N * g.Ho * g.Wo <= self.group_rows)
+                if grouped:
+                    desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
+                    nblk = self.lib.dsnt_conv_wgrad_desc(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
+                                                         _lib.ptr(gy), _lib.ptr(ws), C.byref(g), desc)
+                    if nblk <= 0:
+                        raise RuntimeError('dsnt_conv_wgrad_desc failed: %s' % self.lib.dsnt_last_error().decode())
+                    self._pending_group.append((desc.raw, nblk))
+                else:
+                    self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
+                           None, None, 0, g)
                 self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
                                              self.lib.dsnt_conv_wgrad_splits(C.byref(g)), p.Cout * g.R * g.S * g.Cin,
                                              p.Cout, 0])

@@ -198,6 +198,19 @@ int dsnt_conv_wgrad_bf16x6(const float* x, const float* in_scale, const float* i
 int dsnt_conv_wgrad_splits(const dsnt_conv_geom* g);
 int dsnt_wgrad_reduce_all(const int64_t* table, int rows, int max_blocks, void* stream);
 
+/* Grouped weight gradients: many (small) convolutions in ONE launch.  dsnt_conv_wgrad_desc writes an opaque
+ * descriptor of dsnt_conv_wgrad_desc_bytes() bytes (host memory) for one bf16x6 weight gradient with a
+ * BN(+ReLU) prologue (same arguments as dsnt_conv_wgrad_bf16x6 with dw == NULL: slabs only) and returns its
+ * number of workgroups (> 0) or -error.  The caller copies the descriptors back to back into device memory
+ * and calls dsnt_conv_wgrad_group(table, nconv, max_blocks >= the largest workgroup count); x, dy, scale/shift
+ * and ws must stay untouched until then; reduce afterwards with dsnt_wgrad_reduce_all.  Bit-identical to the
+ * per-convolution launches.  Replaces the per-layer autograd weight-gradient calls of
+ * /root/reference/src/dsnt/bin/train.py:380 (loss.backward()) for the low-resolution hourglass levels. */
+int dsnt_conv_wgrad_desc_bytes(void);
+int dsnt_conv_wgrad_desc(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                         const float* dy, float* ws, const dsnt_conv_geom* g, void* desc_out);
+int dsnt_conv_wgrad_group(const void* table, int nconv, int max_blocks, void* stream);
+
 /* ----------------------------------------------------- batch-norm, elementwise
  * x viewed as [M][C] (M = N*H*W), C % 4 == 0. */
 

@@ -341,3 +341,42 @@ def test_deferred_slab_reduction_is_bit_identical():
     assert _lib.fn('dsnt_wgrad_reduce_all')(None, 1, 1, None) != 0
     assert _lib.fn('dsnt_conv_wgrad')(ptr(keep[0][0]), None, None, 0, ptr(keep[0][1]), ptr(keep[0][2]), None,
                                        ptr(want[0][1]), 0, C.byref(_geom(*cases[0][:5], 3, 3, 1, 1, 1)), None) != 0
+
+
+def test_grouped_wgrad_is_bit_identical():
+    """Several small bf16x6 weight gradients in ONE dsnt_conv_wgrad_group launch write the same slabs as the
+    per-convolution launches (the 16x16 ... 4x4 hourglass levels)."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    dev = torch.device('cuda:0')
+    cases = [(2, 16, 16, 128, 128, 3, 1, 1, 1), (2, 16, 16, 256, 128, 1, 1, 0, 1), (3, 8, 8, 128, 256, 1, 1, 0, 1),
+             (2, 4, 4, 128, 128, 3, 1, 1, 1)]
+    nbytes = _lib.fn('dsnt_conv_wgrad_desc_bytes')()
+    assert nbytes > 0
+    blob, keep, nblk = b'', [], []
+    for ci, (N, H, W, Cin, Cout, k, stride, pad, dil) in enumerate(cases):
+        g = _geom(N, H, W, Cin, Cout, k, k, stride, pad, dil)
+        x = synthetic.tensor('gw%dx' % ci, (N, H, W, Cin), seed=5).to(dev)
+        gy = synthetic.tensor('gw%dg' % ci, (N, g.Ho, g.Wo, Cout), seed=6).to(dev)
+        sc = (synthetic.tensor('gw%ds' % ci, (Cin,), seed=7).abs() + 0.5).to(dev)
+        sh = (synthetic.tensor('gw%dh' % ci, (Cin,), seed=8) * 0.1).to(dev)
+        relu = ci % 2
+        nws = _lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g))
+        ws1, ws2 = torch.zeros(nws, device=dev), torch.full((nws,), 7.0, device=dev)
+        call('dsnt_conv_wgrad_bf16x6', ptr(x), ptr(sc), ptr(sh), relu, ptr(gy), ptr(ws1), None, None, 0, C.byref(g))
+        desc = C.create_string_buffer(nbytes)
+        n = _lib.fn('dsnt_conv_wgrad_desc')(ptr(x), ptr(sc), ptr(sh), relu, ptr(gy), ptr(ws2), C.byref(g), desc)
+        assert n > 0
+        blob += desc.raw
+        nblk.append(n)
+        keep.append((x, gy, sc, sh, ws1, ws2))
+    table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    call('dsnt_conv_wgrad_group', ptr(table), len(cases), (max(nblk) + 7) // 8 * 8)
+    torch.cuda.synchronize()
+    for x, gy, sc, sh, ws1, ws2 in keep:
+        assert torch.equal(ws1, ws2)
+    # errors: no BN vectors, null table
+    g = _geom(*cases[0][:5], 3, 3, 1, 1, 1)
+    desc = C.create_string_buffer(nbytes)
+    assert _lib.fn('dsnt_conv_wgrad_desc')(ptr(keep[0][0]), None, None, 0, ptr(keep[0][1]), ptr(keep[0][5]), C.byref(g), desc) < 0
+    assert _lib.fn('dsnt_conv_wgrad_group')(None, 1, 8, None) != 0
