@@ -18,6 +18,7 @@
 // MFMAs of step s (register staging: the A operand needs per-element BN/ReLU/padding).
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -836,6 +837,145 @@ static int check_geom(const dsnt_conv_geom* g, const char* who) {
     return DSNT_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Few output rows (the 8x8 and 4x4 hourglass levels: M = 2048 / 512 at batch 32): the tiled kernels above
+// put one 32 x 32 accumulator per wave behind the WHOLE reduction (3x3 128->128: 576 dependent
+// v_mfma_f32_32x32x2_f32 = 37 k cycles = ~18 us whatever the tile shape) on 16 ... 64 workgroups, i.e. most
+// SIMDs idle.  Here a 512-thread workgroup owns ONE 32 x 32 output tile and its eight waves split K:
+// every wave streams its K slice straight from global memory into MFMA operand registers (lane (i, h) holds
+// row i, k = 8 j + 4 h .. + 3 of the A rows and of the weight rows: one 16-byte load each per four MFMAs, no
+// LDS staging, no barrier in the loop), the eight partial tiles are summed through LDS in wave order
+// (deterministic) and the usual epilogue (bias, residuals, statistics, BN-backward masking) runs on the sum.
+// Same contract and statistics layout (32-row tiles) as conv_fwd_kernel<1, 4, 1, 1>.
+template <bool PRO>
+__global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float part[8][32][33];
+    const int nt32 = (p.Cout + 31) >> 5;
+    const int ntile = blockIdx.x % nt32, mtile = blockIdx.x / nt32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const unsigned OOB = 0xF0000000u;
+    // A row of this lane
+    const int m = mtile * 32 + i;
+    const bool vm = m < p.M;
+    const int HoWo = p.Ho * p.Wo;
+    const int mm = vm ? m : 0;
+    const int img = mm / HoWo, rem = mm - img * HoWo;
+    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+    // weight row of this lane
+    const int nb = ntile * 32 + i;
+    const unsigned boff = nb < p.Cout ? (unsigned)((size_t)nb * p.K + 4 * h) * 4u : OOB;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (int)((size_t)p.Cout * p.K * 4u), 0x00020000);
+    const int nch = p.K >> 3;                       // 8-wide k chunks; a chunk never straddles a filter tap
+    const int c0 = wave * nch / 8, c1 = (wave + 1) * nch / 8;
+    const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
+    struct Frag { u32x4 a, b; float4 sc, sh; bool ok; };
+    auto load = [&](int ch) {
+        Frag f;
+        const int kb = ch << 3;
+        const int tap = kb / p.Cin, cb = kb - tap * p.Cin;
+        const int r = tap / p.S, s_ = tap - r * p.S;
+        const int ih = ih0 + r * p.dil, iw = iw0 + s_ * p.dil;
+        f.ok = vm && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const unsigned aoff = (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + cb + 4 * h) * 4u;
+        f.a = __builtin_amdgcn_raw_buffer_load_b128(xr, f.ok ? aoff : OOB, 0, 0);
+        f.b = __builtin_amdgcn_raw_buffer_load_b128(wr, boff, kb * 4, 0);
+        if (PRO) {
+            f.sc = *reinterpret_cast<const float4*>(p.in_scale + cb + 4 * h);
+            f.sh = *reinterpret_cast<const float4*>(p.in_shift + cb + 4 * h);
+        }
+        return f;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    auto mma = [&](const Frag& f) {
+        float4 a = make_float4(__uint_as_float(f.a.x), __uint_as_float(f.a.y), __uint_as_float(f.a.z), __uint_as_float(f.a.w));
+        if (PRO) {
+            const float lo = f.ok ? lo_valid : 0.f, hi = f.ok ? __builtin_inff() : 0.f;
+            a.x = __builtin_amdgcn_fmed3f(fmaf(a.x, f.sc.x, f.sh.x), lo, hi);
+            a.y = __builtin_amdgcn_fmed3f(fmaf(a.y, f.sc.y, f.sh.y), lo, hi);
+            a.z = __builtin_amdgcn_fmed3f(fmaf(a.z, f.sc.z, f.sh.z), lo, hi);
+            a.w = __builtin_amdgcn_fmed3f(fmaf(a.w, f.sc.w, f.sh.w), lo, hi);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, __uint_as_float(f.b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, __uint_as_float(f.b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, __uint_as_float(f.b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, __uint_as_float(f.b.w), acc, 0, 0, 0);
+    };
+    if (c0 < c1) {
+        // two chunks in flight; the tail re-loads the last chunk (never used) to stay straight-line
+        Frag f0 = load(c0), f1 = load(min(c0 + 1, c1 - 1));
+        for (int ch = c0; ch < c1; ++ch) {
+            const Frag f2 = load(min(ch + 2, c1 - 1));
+            mma(f0);
+            f0 = f1; f1 = f2;
+        }
+    }
+    // partial tiles -> LDS (C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5))
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part[wave][(e & 3) + 8 * (e >> 2) + 4 * h][i] = acc[e];
+    __syncthreads();
+    const int col = tid & 31, rg = tid >> 5;        // two rows per thread: rg, rg + 16
+    const int n = ntile * 32 + col;
+    const bool vn = n < p.Cout;
+    const bool bnb = p.bnb_scale != nullptr;
+    const float bias = (p.bias && vn) ? p.bias[n] : 0.f;
+    float bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
+    if (bnb && vn) { bsc = p.bnb_scale[n]; bsh = p.bnb_shift[n]; bmu = p.bnb_mean[n]; bis = p.bnb_invstd[n]; }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = rg + 16 * j;
+        const int mo = mtile * 32 + row;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += part[w][row][col];
+        if (vn && mo < p.M) {
+            const size_t o = (size_t)mo * p.Cout + n;
+            if (bnb) {
+                const float xv = p.res1[o];
+                if (p.bnb_relu && fmaf(xv, bsc, bsh) <= 0.f) v = 0.f;
+                p.y[o] = v;
+                s1 += v;
+                s2 = fmaf(v, (xv - bmu) * bis, s2);
+            } else {
+                v += bias + (p.res1 ? p.res1[o] : 0.f) + (p.res2 ? p.res2[o] : 0.f);
+                p.y[o] = v;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();                             // every thread has read its part of `part`
+        float* red = &part[0][0][0];                 // [16][32][2]
+        red[(rg * 32 + col) * 2 + 0] = s1;
+        red[(rg * 32 + col) * 2 + 1] = s2;
+        __syncthreads();
+        if (tid < 32 && vn) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { a0 += red[(w * 32 + tid) * 2 + 0]; a1 += red[(w * 32 + tid) * 2 + 1]; }
+            p.stats[((size_t)mtile * 2 + 0) * p.Cout + n] = a0;
+            p.stats[((size_t)mtile * 2 + 1) * p.Cout + n] = a1;
+        }
+    }
+}
+
+// rows up to which the K-split kernel replaces the 32 x 128 tiling (DSNT_KSPLIT_ROWS; 0 disables)
+static long ksplit_rows() {
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("DSNT_KSPLIT_ROWS"); v = e ? atol(e) : 2048; }
+    return v;
+}
+
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, float* y,
                          const float* in_scale, const float* in_shift, int in_relu,
                          const float* res1, const float* res2, float* stats_partial,
@@ -867,7 +1007,12 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
     p.mtiles = (p.M + BM - 1) / BM; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
     const bool pro = in_scale != nullptr;
-    if (BM == 128 && BN == 128) launch_fwd<2, 2, 2, 2>(p, pro, st);
+    if (BM == 32 && p.M <= ksplit_rows() && p.Cin % 8 == 0 && (size_t)p.N * p.H * p.W * p.Cin * 4u < (1ull << 31) &&
+        (size_t)p.Cout * p.K * 4u < (1ull << 31)) {
+        const int grid = p.mtiles * ((p.Cout + 31) / 32);
+        if (pro) hipLaunchKernelGGL(conv_ksplit_kernel<true>, dim3(grid), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(conv_ksplit_kernel<false>, dim3(grid), dim3(512), 0, st, p);
+    } else if (BM == 128 && BN == 128) launch_fwd<2, 2, 2, 2>(p, pro, st);
     else if (BM == 128 && BN == 64) launch_fwd<2, 2, 2, 1>(p, pro, st);
     else if (BM == 128 && BN == 32) launch_fwd<4, 1, 1, 1>(p, pro, st);
     else launch_fwd<1, 4, 1, 1>(p, pro, st);
