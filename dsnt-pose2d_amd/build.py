@@ -16,6 +16,8 @@ FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-val
          '-Wno-unused-result']
 if os.environ.get('DSNT_TIMELINE'):      # wave timeline stamps in the conv kernels (tools/timeline*.py)
     FLAGS.append('-DDSNT_TIMELINE')
+if os.environ.get('DSNT_TIMELINE') == '2':  # loader stamps split into wait / stage (tools/timeline6.py)
+    FLAGS.append('-DDSNT_TIMELINE2')
 
 
 def _newer(a, b):

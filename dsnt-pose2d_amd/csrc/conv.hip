@@ -705,6 +705,21 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
         int s = 0;
         for (; s + 1 < nsteps; s += 2) {
             DBG_STAMP(1 + 3 * s);
+#ifdef DSNT_TIMELINE2      // stamps: start | stage's loads landed | LDS stores issued  (PRO: 7 younger loads)
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            DBG_STAMP(2 + 3 * s);
+            lstore(S1, 1);
+            DBG_STAMP(3 + 3 * s);
+            gload(S1, min(s + 3, last));
+            __syncthreads();
+            DBG_STAMP(4 + 3 * s);
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            DBG_STAMP(5 + 3 * s);
+            lstore(S0, 0);
+            DBG_STAMP(6 + 3 * s);
+            gload(S0, min(s + 4, last));
+            __syncthreads();
+#else
             lstore(S1, 1);
             DBG_STAMP(2 + 3 * s);
             gload(S1, min(s + 3, last));
@@ -716,6 +731,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
             gload(S0, min(s + 4, last));
             DBG_STAMP(6 + 3 * s);
             __syncthreads();
+#endif
         }
         if (s < nsteps) __syncthreads();
     } else {
