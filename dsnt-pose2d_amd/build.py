@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdsnt_hip.so')
-SOURCES = ['api.cpp', 'conv.hip', 'elementwise.hip', 'head.hip', 'debug.hip']
+SOURCES = ['api.cpp', 'conv.hip', 'elementwise.hip', 'head.hip', 'heatmap.hip', 'debug.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result']
 if os.environ.get('DSNT_TIMELINE'):      # wave timeline stamps in the conv kernels (tools/timeline*.py)
@@ -35,6 +35,8 @@ def build(force=False, verbose=True):
         objs.append(o)
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
             extra = ['-fno-slp-vectorize'] if src == 'conv.hip' else []     # no v_pk_*_f32 beside the MFMAs
+            if src == 'heatmap.hip':      # the reference's separately rounded fp32 coordinate steps: no FMA contraction
+                extra = ['-ffp-contract=off']
             cmd = [hipcc] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
             jobs.append(cmd)
     def run(cmd):

@@ -41,6 +41,10 @@ SIGNATURES = {
     'dsnt_expect_fwd': [P, P, L, I, I, P],
     'dsnt_expect_bwd': [P, P, L, I, I, P],
     'dsnt_make_gauss': [P, P, L, I, I, F, P],
+    'dsnt_encode_heatmaps': [P, P, L, I, I, F, P],
+    'dsnt_heatmap_mse_fwd': [P, P, P, L, I, I, F, P],
+    'dsnt_heatmap_mse_bwd': [P, P, P, P, L, I, I, F, P],
+    'dsnt_decode_heatmaps': [P, P, L, I, I, I, P],
     'dsnt_fc2_fwd': [P, P, P, P, L, I, P],
     'dsnt_fc2_bwd': [P, P, P, P, P, P, L, I, P],
     'dsnt_reg_fwd': [P, P, P, L, I, I, F, I, P],

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from . import nn as dnn
+from . import util as dutil
 from . import hourglass
 from . import resnet
 from .data import ImageSpecs
@@ -130,9 +131,8 @@ class HourglassHumanPoseModel(HumanPoseModel):
                         target_var, mask_var, self.reg, self.heatmaps_array[i], self.hm_sigma)
                     total_loss = total_loss + loss + self.reg_coeff * reg_loss
             return total_loss
-        if self.output_strat == 'gauss':
-            raise NotImplementedError("dsnt: output_strat='gauss' (heat-map MSE baseline) is not "
-                                      'on the DSNT hot path (SURVEY.md §2 #9)')
+        if self.output_strat == 'gauss':       # model.py:247-258: summed intermediate supervision, no mask
+            return sum(dutil.heatmap_mse_loss(hm, target_var, self.hm_sigma) for hm in out_vars)
         raise Exception('invalid configuration')
 
     def compute_coords(self, out_var):
@@ -140,8 +140,8 @@ class HourglassHumanPoseModel(HumanPoseModel):
             out_var = out_var[-1]
         if self.output_strat == 'dsnt' or self.output_strat == 'fc':
             return out_var.detach().to('cpu', torch.float32)
-        if self.output_strat == 'gauss':
-            raise NotImplementedError("dsnt: output_strat='gauss' decoding is not on the DSNT hot path")
+        if self.output_strat == 'gauss':       # model.py:268-269
+            return dutil.decode_heatmaps(out_var).to('cpu', torch.float32)
         raise Exception('invalid configuration')
 
 
@@ -235,15 +235,15 @@ class ResNetHumanPoseModel(HumanPoseModel, hourglass.TapeModule):
             loss = dnn.euclidean_loss(out_var, target_var, mask_var)
             reg_loss = self._calculate_reg_loss(target_var, mask_var, self.reg, self.heatmaps, self.hm_sigma)
             return loss + self.reg_coeff * reg_loss
-        if self.output_strat == 'gauss':
-            raise NotImplementedError("dsnt: output_strat='gauss' loss is not on the DSNT hot path")
+        if self.output_strat == 'gauss':       # model.py:147-156
+            return dutil.heatmap_mse_loss(out_var, target_var, self.hm_sigma)
         raise Exception('invalid configuration')
 
     def compute_coords(self, out_var):
         if self.output_strat == 'dsnt' or self.output_strat == 'fc':
             return out_var.detach().to('cpu', torch.float32)
-        if self.output_strat == 'gauss':
-            raise NotImplementedError("dsnt: output_strat='gauss' decoding is not on the DSNT hot path")
+        if self.output_strat == 'gauss':       # model.py:160-161
+            return dutil.decode_heatmaps(out_var).to('cpu', torch.float32)
         raise Exception('invalid configuration')
 
 

@@ -211,6 +211,25 @@ int dsnt_conv_wgrad_desc(const float* x, const float* in_scale, const float* in_
                          const float* dy, float* ws, const dsnt_conv_geom* g, void* desc_out);
 int dsnt_conv_wgrad_group(const void* table, int nconv, int max_blocks, void* stream);
 
+/* ----------------------------------------------------- heat-map matching ("gauss" output strategy)
+ * Rows = (image, joint) maps of h x w floats, target = normalised coordinates [rows][2].
+ * dsnt_encode_heatmaps: /root/reference/src/dsnt/util.py:129-147 (encode_heatmaps) + :70-126 (draw_gaussian with
+ *   clip_size 7, unnormalised): pixel = round_half_even((c + 1) * size/2 - 0.5), bump exp(-d^2 / (2 sigma^2)) on
+ *   the 7x7 window, nothing when the centre lies more than 3.5 px outside the map.
+ * dsnt_heatmap_mse_fwd: per_row[r] = sum_hw (hm - encode(target))^2 without materialising the target; the caller
+ *   sums the rows and divides by rows*h*w (nn.functional.mse_loss of model.py:156 / :256).
+ * dsnt_heatmap_mse_bwd: dhm = gscale[0] * 2 / (rows*h*w) * (hm - encode(target)); gscale is a device scalar.
+ * dsnt_decode_heatmaps: util.py:150-198 (get_preds + decode_heatmaps): first arg-max pixel ((0,0) when the
+ *   maximum is not positive; y = index / h as the reference), optional quarter-pixel shift towards the larger
+ *   neighbour, then (p + 0.5) * 2/size - 1.  coords [rows][2]. */
+int dsnt_encode_heatmaps(const float* target, float* out, int64_t rows, int h, int w, float sigma, void* stream);
+int dsnt_heatmap_mse_fwd(const float* hm, const float* target, float* per_row, int64_t rows, int h, int w,
+                         float sigma, void* stream);
+int dsnt_heatmap_mse_bwd(const float* hm, const float* target, const float* gscale, float* dhm, int64_t rows,
+                         int h, int w, float sigma, void* stream);
+int dsnt_decode_heatmaps(const float* hm, float* coords, int64_t rows, int h, int w, int use_neighbours,
+                         void* stream);
+
 /* ----------------------------------------------------- batch-norm, elementwise
  * x viewed as [M][C] (M = N*H*W), C % 4 == 0. */
 

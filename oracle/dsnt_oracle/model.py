@@ -2,10 +2,10 @@
 
 Follows `/root/reference/src/dsnt/model.py`: `HumanPoseModel` :21-76,
 `ResNetHumanPoseModel` :79-201, `HourglassHumanPoseModel` :204-314, builders
-:317-379.  The `gauss` output strategy's loss/decoding (`model.py:147-156,
-247-258`, `util.py:128-198`) is outside the DSNT hot path and raises here; its
-forward plumbing (heatmaps passed through) is kept because the hourglass builder
-defaults to it (`model.py:346`).
+:317-379.  The `gauss` output strategy (heat-map matching: `model.py:147-156, 247-258`) uses
+`util.encode_heatmaps` / `decode_heatmaps` (restated in `dsnt_oracle/util.py`); the
+reference hard-codes `.cuda()` for the targets there (`:154, :253`) — here they
+follow the heat-maps' device.
 """
 
 import inspect
@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from . import nn as onn
 from . import hourglass as ohg
 from . import resnet as oresnet
+from . import util as outil
 
 
 class ImageSpecs:
@@ -126,15 +127,16 @@ class ResNetHumanPoseModel(HumanPoseModel):
             reg = self._calculate_reg_loss(target_var, mask_var, self.reg, self.heatmaps,
                                            self.hm_sigma)
             return loss + self.reg_coeff * reg
-        if self.output_strat == 'gauss':
-            raise NotImplementedError('gauss strategy is outside the DSNT hot path')
+        if self.output_strat == 'gauss':     # model.py:147-156
+            target_hm = outil.encode_heatmaps(target_var, out_var.size(-1), out_var.size(-2), self.hm_sigma)
+            return F.mse_loss(out_var, target_hm.to(out_var.device, out_var.dtype))
         raise Exception('invalid configuration')
 
     def compute_coords(self, out_var):
         if self.output_strat in ('dsnt', 'fc'):
             return out_var.detach().to('cpu', torch.float32)
-        if self.output_strat == 'gauss':
-            raise NotImplementedError('gauss strategy is outside the DSNT hot path')
+        if self.output_strat == 'gauss':     # model.py:160-161
+            return outil.decode_heatmaps(out_var.detach().cpu())
         raise Exception('invalid configuration')
 
 
@@ -196,8 +198,11 @@ class HourglassHumanPoseModel(HumanPoseModel):
                                                self.heatmaps_array[i], self.hm_sigma)
                 total = total + loss + self.reg_coeff * reg
             return total
-        if self.output_strat == 'gauss':
-            raise NotImplementedError('gauss strategy is outside the DSNT hot path')
+        if self.output_strat == 'gauss':     # model.py:247-258: summed intermediate supervision, no mask
+            target_hm = outil.encode_heatmaps(target_var, out_vars[0].size(-1), out_vars[0].size(-2),
+                                              self.hm_sigma)
+            target_hm = target_hm.to(out_vars[0].device, out_vars[0].dtype)
+            return sum(F.mse_loss(hm, target_hm) for hm in out_vars)
         raise Exception('invalid configuration')
 
     def compute_coords(self, out_var):
@@ -205,8 +210,8 @@ class HourglassHumanPoseModel(HumanPoseModel):
             out_var = out_var[-1]
         if self.output_strat in ('dsnt', 'fc'):
             return out_var.detach().to('cpu', torch.float32)
-        if self.output_strat == 'gauss':
-            raise NotImplementedError('gauss strategy is outside the DSNT hot path')
+        if self.output_strat == 'gauss':     # model.py:268-269
+            return outil.decode_heatmaps(out_var.detach().cpu())
         raise Exception('invalid configuration')
 
 

@@ -127,3 +127,50 @@ def test_pckh_add():  # tests/test_evaluator.py:18-39
     ev.add(pred, target, torch.tensor([[1.0], [1], [0]]),
            torch.tensor([117.962, 44.046, 78.481]))
     assert ev.meters['all'].value()[0] == 0.5
+
+
+# ---------------------------------------------------------------- heat-map ("gauss") strategy: util.py
+from dsnt_oracle import util as outil  # noqa: E402
+
+_G = [0.00034, 0.01111, 0.13534, 0.60653, 1.00000, 0.60653, 0.13534, 0.01111, 0.00034]   # exp(-d^2/2), d=-4..4
+
+
+def test_draw_gaussian():  # tests/test_util.py:8-24
+    expected = torch.tensor([[[_G[i] * _G[j] for j in range(9)] for i in range(9)]], dtype=torch.float32)
+    actual = torch.zeros(1, 9, 9, dtype=torch.float32)
+    outil.draw_gaussian(actual, 4, 4, 1, normalize=False)
+    assert (expected - actual).abs().max().item() <= 1.5e-5     # the table is rounded to 5 decimals
+
+
+_CLIPPED = [[0.00000, 0.00000, 0.00000, 0.00000, 0.00000],
+            [0.01111, 0.00674, 0.00150, 0.00012, 0.00000],
+            [0.13534, 0.08208, 0.01832, 0.00150, 0.00000],
+            [0.60653, 0.36788, 0.08208, 0.00674, 0.00000],
+            [1.00000, 0.60653, 0.13534, 0.01111, 0.00000]]
+
+
+def test_draw_gaussian_clipped():  # tests/test_util.py:26-38
+    actual = torch.zeros(1, 5, 5, dtype=torch.float32)
+    outil.draw_gaussian(actual, 0, 4, 1, normalize=False, clip_size=7)
+    assert (torch.tensor([_CLIPPED], dtype=torch.float32) - actual).abs().max().item() <= TOL
+
+
+def test_encode_heatmaps():  # tests/test_util.py:40-53
+    coords = torch.tensor([[[-0.8, 0.8]]], dtype=torch.float32)
+    actual = outil.encode_heatmaps(coords, 5, 5)
+    assert actual.dtype == torch.float32
+    assert (torch.tensor([[_CLIPPED]], dtype=torch.float32) - actual).abs().max().item() <= TOL
+    assert torch.equal(coords, torch.tensor([[[-0.8, 0.8]]], dtype=torch.float32))   # works on a copy
+
+
+def test_decode_heatmaps():  # tests/test_util.py:55-64
+    heatmaps = torch.tensor([[[[0.0, 0.9], [0.0, 0.1]]]], dtype=torch.float32)
+    actual = outil.decode_heatmaps(heatmaps)
+    assert (torch.tensor([[[0.5, -0.5]]], dtype=torch.float32) - actual).abs().max().item() <= 1e-7
+
+
+def test_decode_heatmaps_use_neighbours():  # tests/test_util.py:66-77
+    heatmaps = torch.tensor([[[[0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0], [0.0, 0.9, 0.1, 0.0],
+                               [0.0, 0.1, 0.0, 0.0]]]], dtype=torch.float32)
+    actual = outil.decode_heatmaps(heatmaps, use_neighbours=True)
+    assert (torch.tensor([[[-0.125, 0.375]]], dtype=torch.float32) - actual).abs().max().item() <= 1e-7

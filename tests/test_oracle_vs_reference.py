@@ -175,3 +175,61 @@ def test_inference_flip_restatement_matches_reference_pieces():
         coords = rm.compute_coords(rm.forward_part2((hm1 + hm2) / 2))
         want = torch.baddbmm(data[0]['transform_b'][None], coords.double(), data[0]['transform_m'][None])
     assert (got - want).abs().max().item() <= 1e-9
+
+
+def test_heatmap_util_matches_reference():
+    """`gauss` strategy helpers (util.py:70-198).  The reference's encode_heatmaps calls Python round() on a
+    tensor element, which today's PyTorch rejects (TypeError: an API drift, not a denial), so encoding is
+    pinned through the reference's own draw_gaussian at the documented rounded pixel + its known answers."""
+    from dsnt_oracle import util as outil
+    ref_util = refimport.load_reference_module('dsnt.util')
+    g = torch.Generator().manual_seed(3)
+    hm = torch.randn(3, 5, 16, 16, generator=g)
+    hm[0, 0].zero_()                      # maximum not positive -> (0, 0) pixel
+    hm[0, 1, 0, 7] = 9.0                  # border pixel: no neighbour offset
+    hm[0, 2, 5, 5] = 9.0; hm[0, 2, 5, 4] = hm[0, 2, 5, 6] = 1.0   # equal neighbours: sign 0
+    for nb in (True, False):
+        assert torch.equal(ref_util.decode_heatmaps(hm.clone(), use_neighbours=nb),
+                           outil.decode_heatmaps(hm, use_neighbours=nb))
+    assert torch.equal(ref_util.get_preds(hm.clone()), outil.get_preds(hm))
+    for (x, y, sigma, norm, clip) in [(4, 4, 1, False, None), (0, 4, 1, False, 7), (-3, 2, 1.5, False, 7),
+                                      (-4, 2, 1, False, 7), (18, 3, 1, False, 7), (19, 3, 1, False, 7),
+                                      (7, 15, 2, True, 7), (3.7, 2.2, 1, True, None)]:
+        a = torch.zeros(16, 16); b = torch.zeros(16, 16)
+        ref_util.draw_gaussian(a, x, y, sigma, normalize=norm, clip_size=clip)
+        outil.draw_gaussian(b, x, y, sigma, normalize=norm, clip_size=clip)
+        assert torch.equal(a, b), (x, y, sigma, norm, clip)
+    coords = torch.rand(4, 6, 2, generator=g) * 2.4 - 1.2          # some joints off the map
+    enc = outil.encode_heatmaps(coords, 16, 16, 1.25)
+    px = coords.clone().add_(1); px[:, :, 0].mul_(16 / 2); px[:, :, 1].mul_(16 / 2); px.add_(-0.5)
+    for i in range(4):
+        for j in range(6):
+            want = torch.zeros(16, 16)
+            ref_util.draw_gaussian(want, round(px[i, j, 0].item()), round(px[i, j, 1].item()), 1.25,
+                                   normalize=False, clip_size=7)
+            assert torch.equal(want, enc[i, j])
+
+
+def test_gauss_strategy_model_matches_reference_pieces():
+    """HourglassHumanPoseModel with output_strat='gauss' (model.py:247-258, 268-269): the reference path
+    itself needs a CUDA device (`.cuda()` at :253) and the drifted round(); check the oracle's loss against
+    mse_loss over reference-drawn targets and the decode against the reference's decode_heatmaps."""
+    import torch.nn.functional as F
+    from dsnt_oracle import util as outil
+    ref_util = refimport.load_reference_module('dsnt.util')
+    torch.manual_seed(0)
+    m = omodel.build_mpii_pose_model(base='hg2')                    # builder default: gauss
+    assert m.output_strat == 'gauss'
+    m.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 64, 64, generator=g)
+    target = torch.rand(2, 16, 2, generator=g) * 2 - 1
+    out = m(x)
+    assert isinstance(out, list) and len(out) == 2 and out[0].shape == (2, 16, 16, 16)
+    loss = m.forward_loss(out, target, None)
+    tgt = outil.encode_heatmaps(target, 16, 16, 1.0)
+    want = sum(F.mse_loss(o, tgt) for o in out)
+    assert abs(loss.item() - want.item()) <= 1e-7
+    loss.backward()
+    assert all(p.grad is not None for p in m.parameters())
+    assert torch.equal(m.compute_coords(out), ref_util.decode_heatmaps(out[-1].detach().clone()))
