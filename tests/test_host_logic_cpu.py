@@ -89,3 +89,22 @@ def test_synthetic_is_deterministic():
     synthetic.fill_state_dict(m1, seed=0)
     synthetic.fill_state_dict(m2, seed=0)
     assert all(torch.equal(p, q) for p, q in zip(m1.parameters(), m2.parameters()))
+
+
+def test_bearpaw_checkpoint_repack_flow():
+    """`bin/convert_hg_model.py:31-44`: strip the DataParallel "module." prefix of a pytorch-pose hourglass
+    checkpoint, load it into `model.hg`, save `model.state_dict()` — works on the HIP model classes unchanged
+    (same HourglassNet keys as the reference / bearpaw: conv1, layer1..3, hg.N.hg..., fc_, score_)."""
+    from collections import OrderedDict
+    from dsnt.model import build_mpii_pose_model
+    from dsnt_oracle import hourglass as ohg
+    torch.manual_seed(0)
+    donor = ohg.HourglassNet(ohg.Bottleneck, num_stacks=2, num_blocks=1, num_classes=16)
+    old_state_dict = OrderedDict(('module.' + k, v) for k, v in donor.state_dict().items())
+    new_state_dict = OrderedDict([(k[7:], v) for (k, v) in old_state_dict.items()])
+    model = build_mpii_pose_model(base='hg', stacks=2, blocks=1)
+    model.hg.load_state_dict(new_state_dict)
+    out = model.state_dict()
+    assert list(out.keys()) == ['hg.' + k for k in donor.state_dict().keys()]
+    for k, v in donor.state_dict().items():
+        assert torch.equal(out['hg.' + k].cpu(), v), k
