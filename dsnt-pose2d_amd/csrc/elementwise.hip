@@ -86,6 +86,103 @@ extern "C" int dsnt_bn_stats(const float* x, float* partial, int64_t M, int C, v
     DSNT_CHECK_LAUNCH("dsnt_bn_stats");
 }
 
+// 2x2 max-pool / nearest-upsample + add with the BatchNorm statistics of their OUTPUT in the same pass: one
+// workgroup per 128 output rows (pixels), same thread mapping, accumulation order and partial format as
+// tile_reduce_kernel<0>, so the sums are bit-identical to a separate dsnt_bn_stats over the stored tensor (which
+// cost one more read of it: 18 launches per hg2 step).  OP 0: y = maxpool2(a) (+ arg-max byte), a is [N][2Ho][2Wo][C];
+// OP 1: y = a + upsample2(b), b is [N][Ho/2][Wo/2][C].  Ho, Wo: OUTPUT size.
+template <int OP>
+__global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ y, unsigned char* __restrict__ idx,
+                                                            float* __restrict__ partial, int N, int Ho, int Wo, int C) {
+    __shared__ float red[256 * 8];
+    const int tid = threadIdx.x;
+    const int C4 = C >> 2;
+    const int cgs = C4 < 256 ? C4 : 256;
+    const int rpar = 256 / cgs;
+    const int cg_l = tid % cgs, rl = tid / cgs;
+    const bool active = rl < rpar;
+    const long M = (long)N * Ho * Wo;
+    const long row0 = (long)blockIdx.x * TILE_ROWS;
+    const long row1 = row0 + TILE_ROWS < M ? row0 + TILE_ROWS : M;
+    for (int cg0 = 0; cg0 < C4; cg0 += cgs) {
+        const int cg = cg0 + cg_l;
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+        if (active && cg < C4) {
+            for (long r = row0 + rl; r < row1; r += rpar) {
+                const int ow = (int)(r % Wo);
+                const long t = r / Wo;
+                const int oh = (int)(t % Ho), n = (int)(t / Ho);
+                float4 v;
+                if (OP == 0) {
+                    const int W = Wo * 2;
+                    const float4* base = reinterpret_cast<const float4*>(a) + (((long)n * (Ho * 2) + 2 * oh) * W + 2 * ow) * C4 + cg;
+                    const float4 v0 = base[0], v1 = base[C4], v2 = base[(long)W * C4], v3 = base[(long)W * C4 + C4];
+                    v = v0;
+                    uchar4 k = make_uchar4(0, 0, 0, 0);
+#define POOL_STEP(V, P)                                  \
+                    if (V.x > v.x || V.x != V.x) { v.x = V.x; k.x = P; } \
+                    if (V.y > v.y || V.y != V.y) { v.y = V.y; k.y = P; } \
+                    if (V.z > v.z || V.z != V.z) { v.z = V.z; k.z = P; } \
+                    if (V.w > v.w || V.w != V.w) { v.w = V.w; k.w = P; }
+                    POOL_STEP(v1, 1) POOL_STEP(v2, 2) POOL_STEP(v3, 3)
+#undef POOL_STEP
+                    reinterpret_cast<uchar4*>(idx)[r * C4 + cg] = k;
+                } else {
+                    const float4 u = reinterpret_cast<const float4*>(a)[r * C4 + cg];
+                    const float4 l = reinterpret_cast<const float4*>(b)[(((long)n * (Ho >> 1) + (oh >> 1)) * (Wo >> 1) + (ow >> 1)) * C4 + cg];
+                    v = make_float4(u.x + l.x, u.y + l.y, u.z + l.z, u.w + l.w);
+                }
+                reinterpret_cast<float4*>(y)[r * C4 + cg] = v;
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+                s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+            }
+        }
+        __syncthreads();
+        float* mine = red + tid * 8;
+        mine[0] = s1.x; mine[1] = s1.y; mine[2] = s1.z; mine[3] = s1.w;
+        mine[4] = s2.x; mine[5] = s2.y; mine[6] = s2.z; mine[7] = s2.w;
+        __syncthreads();
+        if (tid < cgs && cg0 + tid < C4) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < rpar; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += red[(j * cgs + tid) * 8 + e];
+            float* p0 = partial + ((size_t)blockIdx.x * 2 + 0) * C + (size_t)(cg0 + tid) * 4;
+            float* p1 = partial + ((size_t)blockIdx.x * 2 + 1) * C + (size_t)(cg0 + tid) * 4;
+            *reinterpret_cast<float4*>(p0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(p1) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+}
+
+extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* partial, int N, int H, int W,
+                                       int C, void* stream) {
+    DSNT_REQUIRE(x && y && idx && partial && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
+                 "dsnt_maxpool2_fwd_stats: bad argument");
+    DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_fwd_stats: H and W must be even (got %dx%d)", H, W);
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(partial) &&
+                 (((uintptr_t)idx) & 3) == 0, DSNT_ERR_ALIGN, "dsnt_maxpool2_fwd_stats: alignment");
+    const long M = (long)N * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(tile_op_stats_kernel<0>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
+                       (hipStream_t)stream, x, nullptr, y, idx, partial, N, H / 2, W / 2, C);
+    DSNT_CHECK_LAUNCH("dsnt_maxpool2_fwd_stats");
+}
+
+extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, float* out, float* partial, int N,
+                                            int H, int W, int C, void* stream) {
+    DSNT_REQUIRE(up && low && out && partial && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
+                 "dsnt_upsample2_add_fwd_stats: bad argument");
+    DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_upsample2_add_fwd_stats: H and W must be even");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(up) && dsnt_aligned16(low) && dsnt_aligned16(out) &&
+                 dsnt_aligned16(partial), DSNT_ERR_ALIGN, "dsnt_upsample2_add_fwd_stats: alignment");
+    const long M = (long)N * H * W;
+    hipLaunchKernelGGL(tile_op_stats_kernel<1>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
+                       (hipStream_t)stream, up, low, out, nullptr, partial, N, H, W, C);
+    DSNT_CHECK_LAUNCH("dsnt_upsample2_add_fwd_stats");
+}
+
 extern "C" int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const float* scale,
                                       const float* shift, const float* mean, const float* invstd,
                                       int relu, float* partial, int64_t M, int C, void* stream) {

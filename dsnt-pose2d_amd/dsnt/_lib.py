@@ -75,6 +75,8 @@ SIGNATURES = {
     'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
     'dsnt_maxpool2_fwd': [P, P, P, I, I, I, I, P],
     'dsnt_maxpool2_bwd': [P, P, P, I, I, I, I, I, P],
+    'dsnt_maxpool2_fwd_stats': [P, P, P, P, I, I, I, I, P],
+    'dsnt_upsample2_add_fwd_stats': [P, P, P, P, I, I, I, I, P],
     'dsnt_maxpool3s2_fwd': [P, P, P, I, I, I, I, P],
     'dsnt_maxpool3s2_bwd': [P, P, P, I, I, I, I, I, P],
     'dsnt_bn_add_act_fwd': [P, P, P, P, I, P, L, I, P],

@@ -109,6 +109,9 @@ class Tape:
         # DSNT_WGRAD_GROUP_ROWS = largest N*Ho*Wo that is deferred (0 disables)
         self.group_rows = int(os.environ.get('DSNT_WGRAD_GROUP_ROWS', '8192')) if self.defer_reduce else 0
         self._pending_group = []    # (descriptor bytes, workgroups) since the last flush
+        # max-pool / upsample+add write the BatchNorm statistics of their output themselves (DSNT_FUSE_OP_STATS=0:
+        # a separate dsnt_bn_stats pass when a BatchNorm asks for them)
+        self.fuse_op_stats = os.environ.get('DSNT_FUSE_OP_STATS', '1') != '0'
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float32):
@@ -508,7 +511,14 @@ class Tape:
     def maxpool2(self, x, name=''):
         y = self.act(x.N, x.H // 2, x.W // 2, x.C, name)
         idx = self.empty(x.N, x.H // 2, x.W // 2, x.C, dtype=torch.uint8)
-        self.f('dsnt_maxpool2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
+        if self.training and self.fuse_op_stats:
+            # the consumer is a BatchNorm (hourglass.py:33): its batch statistics ride in the same pass
+            tiles = (y.M + 127) // 128
+            part = self.empty(tiles, 2, x.C)
+            self.f('dsnt_maxpool2_fwd_stats', x.buf, y.buf, idx, part, x.N, x.H, x.W, x.C)
+            y.stats = (part, tiles)
+        else:
+            self.f('dsnt_maxpool2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
         if self.training:
             def backward():
                 buf, acc = self.grad_target(x)
@@ -550,7 +560,13 @@ class Tape:
 
     def upsample2_add(self, up, low, name=''):
         out = self.act(up.N, up.H, up.W, up.C, name)
-        self.f('dsnt_upsample2_add_fwd', up.buf, low.buf, out.buf, up.N, up.H, up.W, up.C)
+        if self.training and self.fuse_op_stats:
+            tiles = (out.M + 127) // 128
+            part = self.empty(tiles, 2, up.C)
+            self.f('dsnt_upsample2_add_fwd_stats', up.buf, low.buf, out.buf, part, up.N, up.H, up.W, up.C)
+            out.stats = (part, tiles)
+        else:
+            self.f('dsnt_upsample2_add_fwd', up.buf, low.buf, out.buf, up.N, up.H, up.W, up.C)
         if self.training:
             def backward():
                 buf, acc = self.grad_target(low)

@@ -296,6 +296,14 @@ int dsnt_upsample2_add_fwd(const float* up, const float* low, float* out,
 int dsnt_upsample2_bwd(const float* dout, float* dlow, int accumulate,
                        int N, int H, int W, int C, void* stream);
 
+/* The same two forward ops with the BatchNorm statistics of their output in the same pass (the next op of the
+ * hourglass is a BatchNorm: hourglass.py:33,78-90): partial[ceil(M/128)][2][C] exactly as dsnt_bn_stats over the
+ * stored result would give (bit-identical), M = output pixels. */
+int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* partial, int N, int H, int W, int C,
+                            void* stream);
+int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, float* out, float* partial, int N, int H, int W,
+                                 int C, void* stream);
+
 /* y (+)= a*x, flat; n % 4 == 0 not required. */
 int dsnt_axpy(const float* x, float* y, float a, int accumulate, int64_t n, void* stream);
 

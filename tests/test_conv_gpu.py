@@ -210,6 +210,25 @@ def test_pool_upsample(N, H, W, Cc):
     call('dsnt_upsample2_bwd', ptr(god), ptr(dl), 0, N, H, W, Cc)
     assert (dl.cpu().permute(0, 3, 1, 2) - low.grad).abs().max().item() <= 1e-6
 
+    # the same ops with the BatchNorm statistics of their output fused in: identical tensors, and partial sums
+    # bit-identical to a separate dsnt_bn_stats pass over the stored result
+    for name, args_plain, res, shape in (
+            ('dsnt_maxpool2_fwd_stats', (ptr(xd),), y, (N, H // 2, W // 2, Cc)),
+            ('dsnt_upsample2_add_fwd_stats', (ptr(upd), ptr(lowd)), out, (N, H, W, Cc))):
+        M = shape[0] * shape[1] * shape[2]
+        tiles = (M + 127) // 128
+        res2 = torch.empty(*shape, device=dev)
+        part, want = torch.empty(tiles, 2, Cc, device=dev), torch.empty(tiles, 2, Cc, device=dev)
+        if name.startswith('dsnt_maxpool'):
+            idx2 = torch.empty_like(idx)
+            call(name, *args_plain, ptr(res2), ptr(idx2), ptr(part), N, H, W, Cc)
+            assert torch.equal(idx2, idx)
+        else:
+            call(name, *args_plain, ptr(res2), ptr(part), N, H, W, Cc)
+        call('dsnt_bn_stats', ptr(res), ptr(want), M, Cc)
+        assert torch.equal(res2, res)
+        assert torch.equal(part, want)
+
     # layout round trip with channel padding
     img = synthetic.tensor('im', (N, 3, H, W), seed=7)
     nhwc = torch.empty(N, H, W, 4, device=dev)
