@@ -1,0 +1,96 @@
+"""BASELINE config 3 at FULL size (hg2 + DSNT + JS, batch 32, 256x256 -> 64x64x16) on the production path
+(bf16x6 from 16384 rows up, grouped weight gradients, K-split kernels, two lanes): size-independent properties
+instead of an oracle run (a CPU step at this size takes ~25 s per image batch of 8 on 128 threads).
+
+* heat-maps are distributions and the coordinates are their expectation (dsnt/nn.py:49-78 of the reference);
+* the loss equals the CPU oracle's head + loss evaluated on the SAME heat-maps / coordinates;
+* the gradient is the derivative of the loss: central difference along the gradient direction;
+* a step is deterministic (no atomics anywhere: bit-identical loss and gradients when repeated);
+* eval-mode forward of the batch = forwards of its halves (replica semantics of inference).
+"""
+import pytest
+import torch
+
+from dsnt import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from dsnt.model import build_mpii_pose_model
+    m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(m, seed=0)
+    m.to(DEV).train()
+    x, t, k = synthetic.batch(32, size=256, seed=1, mask_p=0.9)
+    return m, x.to(DEV), t.to(DEV), k.to(DEV)
+
+
+def _step(m, x, t, k):
+    for p in m.parameters():
+        p.grad = None
+    out = m(x)
+    loss = m.forward_loss(out, t, k)
+    loss.backward()
+    return out, loss
+
+
+def test_heatmaps_coords_and_loss(setup):
+    from dsnt_oracle import nn as onn
+    m, x, t, k = setup
+    out, loss = _step(m, x, t, k)
+    assert len(out) == 2 and out[0].shape == (32, 16, 2)
+    total = 0.0
+    for hm, coords in zip(m.heatmaps_array, out):
+        assert hm.shape == (32, 16, 64, 64) and float(hm.detach().min()) >= 0.0
+        assert (hm.double().sum((-1, -2)) - 1).abs().max().item() <= 1e-5
+        xs = ((2 * torch.arange(64, device=DEV, dtype=torch.float64) - 63) / 64)
+        ex = (hm.double().sum(-2) * xs).sum(-1)
+        ey = (hm.double().sum(-1) * xs).sum(-1)
+        assert (torch.stack([ex, ey], -1) - coords.double()).abs().max().item() <= 2e-6
+        assert coords.abs().max().item() < 1.0
+        # the oracle's loss on the same heat-maps and coordinates (CPU, fp32)
+        hc, cc = hm.detach().cpu(), coords.detach().cpu()
+        total += (onn.euclidean_loss(cc, t.cpu(), k.cpu()) +
+                  onn.js_reg_loss(hc, t.cpu(), 2.0 / 64, k.cpu())).item()
+    assert abs(loss.item() - total) <= 1e-5 * abs(total)
+    assert torch.equal(m.compute_coords(out), out[-1].detach().cpu())
+
+
+def test_gradient_is_the_derivative_and_step_is_deterministic(setup):
+    m, x, t, k = setup
+    _, loss1 = _step(m, x, t, k)
+    g1 = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    _, loss2 = _step(m, x, t, k)
+    g2 = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert loss1.item() == loss2.item() and torch.equal(g1, g2)          # no atomics, fixed reduction orders
+    assert torch.isfinite(g1).all() and float(g1.norm()) > 0
+    # central difference along the (normalised) gradient: dL = |g| * eps.  BatchNorm running statistics move
+    # with every forward but do not enter a train-mode loss.
+    params = list(m.parameters())
+    d = [p.grad.clone() / g1.norm() for p in params]
+    eps = 2.5e-4         # small: the loss is strongly curved along its own gradient at random initialisation
+    with torch.no_grad():
+        for p, dp in zip(params, d):
+            p.add_(dp, alpha=eps)
+        lp = m.forward_loss(m(x), t, k).item()
+        for p, dp in zip(params, d):
+            p.add_(dp, alpha=-2 * eps)
+        lm = m.forward_loss(m(x), t, k).item()
+        for p, dp in zip(params, d):
+            p.add_(dp, alpha=eps)
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - float(g1.norm())) <= 0.03 * float(g1.norm()), (fd, float(g1.norm()))
+
+
+def test_eval_forward_shards_like_replicas(setup):
+    m, x, t, k = setup
+    m.eval()
+    try:
+        with torch.no_grad():
+            whole = m(x)[-1].clone()
+            halves = torch.cat([m(x[:16])[-1].clone(), m(x[16:])[-1].clone()])
+        assert (whole - halves).abs().max().item() <= 2e-6
+    finally:
+        m.train()
