@@ -36,6 +36,8 @@ struct ConvP {
     const float* bnb_scale; const float* bnb_shift; const float* bnb_mean; const float* bnb_invstd;
     int bnb_relu;
     int in_relu;
+    // fp16x3 path: device scalars >= max|A operand| and max|weights| (null on the other paths)
+    const float* a_bound; const float* w_bound;
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil;
     int M, K, mtiles, ntiles;
 };
@@ -78,6 +80,18 @@ __device__ __forceinline__ void xcd_remap(int bid, int nwg, int& out) {
     out = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
+// fp16x3 operand scale (see the fp16x3 notes further down):
+// 2^k with bound * 2^k in [2^13, 2^14)  (bound = m 2^E, 1 <= m < 2  ->  k = 13 - E); zero / tiny bounds are clamped
+__device__ __host__ __forceinline__ float pow2_scale(float bound) {
+    unsigned bits;
+    memcpy(&bits, &bound, 4);
+    int E = (int)((bits & 0x7fffffffu) >> 23) - 127;
+    E = E < -100 ? -100 : (E > 100 ? 100 : E);
+    const unsigned sb = (unsigned)(127 + 13 - E) << 23;
+    float sc;
+    memcpy(&sc, &sb, 4);
+    return sc;
+}
 // Shared epilogue of the forward / data-gradient kernels (fp32 and bf16x6 variants).
 // HALO: the tile's 128 rows are an 8 x 16 patch of output pixels starting at row `mbase` (row r of the
 // tile is output row mbase + (r >> 4) * W + (r & 15)) instead of 128 consecutive output rows.
@@ -129,6 +143,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         bmu = *reinterpret_cast<const float4*>(p.bnb_mean + n0);
         bis = *reinterpret_cast<const float4*>(p.bnb_invstd + n0);
     }
+    // fp16x3: the accumulators hold (A s_a)(W s_w); both scales are powers of two, the product is undone exactly
+    const float osc = p.a_bound ? 1.f / (pow2_scale(p.a_bound[0]) * pow2_scale(p.w_bound[0])) : 1.f;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
@@ -147,6 +163,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         const int m = rowmap(row);
         if (vn && m < p.M) {
             float4 v = *reinterpret_cast<const float4*>(Cs + row * CP + ch * 4);
+            v.x *= osc; v.y *= osc; v.z *= osc; v.w *= osc;
             if (bnb) {
                 // v = dL/d relu(bn(x)); r1[j] = x: mask by the ReLU, accumulate the BN-backward sums
                 const float4 xv = r1[j];
@@ -548,6 +565,46 @@ __device__ __forceinline__ void split4(const float4 v, uint2& p1, uint2& p2, uin
     p3.x = pk_bf16(r.x, r.y); p3.y = pk_bf16(r.z, r.w);
 }
 
+// ------------------------------------------------------------------------------------------
+// fp16x3: the same idea on TWO fp16 planes after a power-of-two scale: x * s = h1 + h2 with h1 = fp16(x * s),
+// h2 = fp16(x * s - h1) keeps 22+ significand bits, the product needs h1 g1 + h1 g2 + h2 g1 = THREE MFMAs (dropped
+// term <= 2^-24 |x g|), two thirds of the LDS traffic and about half the split arithmetic of bf16x6.  Error against
+// fp64 (K = 1152, tools/split_numerics.py): 7.7e-8 of the output scale — a plain fp32 GEMM has 2.7e-7, bf16x6 5.8e-9.
+// The price is fp16's exponent range: s = pow2_scale(bound) keeps |x * s| < 2^14 for any bound >= max|x| (a bound
+// 64x too large costs nothing measurable; overflow would be fatal, underflow only costs absolute error
+// <= 2^-40 * bound).  Bounds live in device memory: BN+ReLU operands from the BN parameters (|gamma| sqrt(M) + |beta|),
+// weights and BN-backward outputs from an amax their producer wrote.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_f16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// 4 (already scaled) floats -> two planes of 4 fp16: 3 VALU instructions per element
+__device__ __forceinline__ void split4h(const float4 v, uint2& p1, uint2& p2) {
+    p1.x = pk_f16(v.x, v.y); p1.y = pk_f16(v.z, v.w);
+    const f16x2v a0 = __builtin_bit_cast(f16x2v, p1.x), a1 = __builtin_bit_cast(f16x2v, p1.y);
+    p2.x = pk_f16(v.x - (float)a0.x, v.y - (float)a0.y);
+    p2.y = pk_f16(v.z - (float)a1.x, v.w - (float)a1.y);
+}
+// the MFMAs of one 32x32 accumulator and one 16-wide K step, smallest terms first
+template <bool F16>
+__device__ __forceinline__ void mma_split(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    if (F16) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    }
+}
+
 __global__ void split_bf16x3_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         uint2 a, b, c;
@@ -567,14 +624,15 @@ extern "C" int dsnt_split_bf16x3(const float* src, void* dst, int64_t n, void* s
     DSNT_CHECK_LAUNCH("dsnt_split_bf16x3");
 }
 
-template <int WM, int WN, int TM, int TN, bool PRO>
+template <int WM, int WN, int TM, int TN, bool PRO, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
+    constexpr int NPL = F16 ? 2 : 3;            // operand planes (fp16x3: two fp16 planes, three MFMAs)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int APASS = BM / 64;             // loader: 64 rows x 4 float4 chunks per pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* A6 = reinterpret_cast<__bf16*>(smem);          // [2][3][BM][PITCH6]
-    __bf16* B6 = A6 + 2 * 3 * BM * PITCH6;                 // [2][3][BN][PITCH6]
+    __bf16* A6 = reinterpret_cast<__bf16*>(smem);          // [2][NPL][BM][PITCH6]
+    __bf16* B6 = A6 + 2 * NPL * BM * PITCH6;               // [2][NPL][BN][PITCH6]
 
     int tile;
     xcd_remap(blockIdx.x, p.mtiles * p.ntiles, tile);
@@ -627,16 +685,18 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
         const int brow = ((ltid >> 4) << 3) + (((ltid >> 1) & 3) << 1) + ((ltid >> 3) & 1);
         const int bn = ntile * BN + brow;
         const bool bvalid = brow < BN && bn < p.Cout;
-        unsigned bpix[3];
+        unsigned bpix[NPL];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < NPL; ++j)
             bpix[j] = bvalid ? (unsigned)((size_t)j * p.wq_stride + (size_t)bn * p.K + bhalf * 8) * 2u : 0xF0000000u;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)2 * p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
+            const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)(NPL - 1) * p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
+        // fp16x3: operand scale (a power of two) from the bound the producer left in device memory
+        const float sa = F16 ? pow2_scale(p.a_bound[0]) : 1.f;
         struct Stage {
-            u32x4 ra[APASS], rb[3];
+            u32x4 ra[APASS], rb[NPL];
             float4 sc, sh;
             unsigned ok;
         };
@@ -650,6 +710,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
             if (PRO) {
                 st.sc = *reinterpret_cast<const float4*>(p.in_scale + cb + kc * 4);
                 st.sh = *reinterpret_cast<const float4*>(p.in_shift + cb + kc * 4);
+                if (F16) {      // relu(x sc + sh) s_a = relu(x (sc s_a) + sh s_a): the scale rides in the BN vectors
+                    st.sc.x *= sa; st.sc.y *= sa; st.sc.z *= sa; st.sc.w *= sa;
+                    st.sh.x *= sa; st.sh.y *= sa; st.sh.z *= sa; st.sh.w *= sa;
+                }
             }
             st.ok = vmask >> (tap * APASS);
 #pragma unroll
@@ -657,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
                 st.ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, apix[i] + toff, 0, 0);
             const unsigned koff = (unsigned)kb * 2u;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < NPL; ++j)
                 st.rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bpix[j] + koff, 0, 0);
         };
         auto lstore = [&](const Stage& st, int buf) {
@@ -680,16 +744,23 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
                 } else {
                     v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
                 }
-                split4(v, q1, q2, q3);
-                __bf16* dst = A6 + ((size_t)(buf * 3) * BM + lrow + 64 * i) * PITCH6 + kc * 4;
-                *reinterpret_cast<uint2*>(dst) = q1;
-                *reinterpret_cast<uint2*>(dst + BM * PITCH6) = q2;
-                *reinterpret_cast<uint2*>(dst + 2 * BM * PITCH6) = q3;
+                __bf16* dst = A6 + ((size_t)(buf * NPL) * BM + lrow + 64 * i) * PITCH6 + kc * 4;
+                if (F16) {
+                    if (!PRO) { v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa; }
+                    split4h(v, q1, q2);
+                    *reinterpret_cast<uint2*>(dst) = q1;
+                    *reinterpret_cast<uint2*>(dst + BM * PITCH6) = q2;
+                } else {
+                    split4(v, q1, q2, q3);
+                    *reinterpret_cast<uint2*>(dst) = q1;
+                    *reinterpret_cast<uint2*>(dst + BM * PITCH6) = q2;
+                    *reinterpret_cast<uint2*>(dst + 2 * BM * PITCH6) = q3;
+                }
             }
             if (brow < BN) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    *reinterpret_cast<u32x4*>(B6 + ((size_t)(buf * 3 + j) * BN + brow) * PITCH6 + bhalf * 8) = st.rb[j];
+                for (int j = 0; j < NPL; ++j)
+                    *reinterpret_cast<u32x4*>(B6 + ((size_t)(buf * NPL + j) * BN + brow) * PITCH6 + bhalf * 8) = st.rb[j];
             }
         };
         // No conditionals around gload/lstore: hipcc's vmcnt bookkeeping is exact only on straight-line
@@ -740,30 +811,22 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
         Frag F;
         auto rd = [&](Frag& f, int buf) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
                     f.a[a][pl] = *reinterpret_cast<const bf16x8*>(
-                        A6 + ((size_t)(buf * 3 + pl) * BM + (wm * TM + a) * 32 + lr) * PITCH6 + 8 * lh);
+                        A6 + ((size_t)(buf * NPL + pl) * BM + (wm * TM + a) * 32 + lr) * PITCH6 + 8 * lh);
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
                     f.b[b][pl] = *reinterpret_cast<const bf16x8*>(
-                        B6 + ((size_t)(buf * 3 + pl) * BN + (wn * TN + b) * 32 + lr) * PITCH6 + 8 * lh);
+                        B6 + ((size_t)(buf * NPL + pl) * BN + (wn * TN + b) * 32 + lr) * PITCH6 + 8 * lh);
             }
         };
         auto mm = [&](const Frag& f) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    // smallest terms first
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][2], f.b[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][0], f.b[b][2], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][1], f.b[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][1], f.b[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][0], f.b[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][0], f.b[b][0], acc[a][b], 0, 0, 0);
-                }
+                for (int b = 0; b < TN; ++b) mma_split<F16>(acc[a][b], f.a[a], f.b[b]);
         };
         __syncthreads();
         for (int s = 0; s < nsteps; ++s) {
@@ -1011,6 +1074,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.in_scale = in_scale; p.in_shift = in_shift;
     p.res1 = res1; p.res2 = res2; p.stats = stats_partial; p.in_relu = in_relu; p.wq = nullptr; p.wq_stride = 0;
     p.bnb_scale = p.bnb_shift = p.bnb_mean = p.bnb_invstd = nullptr; p.bnb_relu = 0;
+    p.a_bound = p.w_bound = nullptr;
     if (g_bnb) {
         p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
         p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
@@ -1069,15 +1133,16 @@ extern "C" int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bia
 //   from registers that were loaded nine steps earlier) + B [2][3][BN][24] bf16 (36.9 KB).
 // K order is (16-channel chunk, tap) instead of (tap, channel): same products, different fp32
 // summation order than the implicit-GEMM kernel (differences at the 1e-7 level).
-template <int TN, bool PRO>
+template <int TN, bool PRO, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
+    constexpr int NPL = F16 ? 2 : 3;            // operand planes (fp16x3: two fp16 planes, three MFMAs)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int WN = 2, TM = 2, BM = 128, BN = WN * TN * 32;
     constexpr int HWD = 18, HPP = 192;                 // halo row width; halo pixels (180) padded to 192
     constexpr int BROWS = BN * 2 / 256 >= 1 ? 3 : 3;   // three planes per loader thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* A6 = reinterpret_cast<__bf16*>(smem);          // [3][HPP][PITCH6]
-    __bf16* B6 = A6 + 3 * HPP * PITCH6;                    // [2][3][BN][PITCH6]
+    __bf16* A6 = reinterpret_cast<__bf16*>(smem);          // [NPL][HPP][PITCH6]
+    __bf16* B6 = A6 + NPL * HPP * PITCH6;                  // [2][NPL][BN][PITCH6]
 
     int tile;
     xcd_remap(blockIdx.x, p.mtiles * p.ntiles, tile);
@@ -1120,16 +1185,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
         const int brow = ((ltid >> 4) << 3) + (((ltid >> 1) & 3) << 1) + ((ltid >> 3) & 1);
         const int bn = ntile * BN + brow;
         const bool bvalid = brow < BN && bn < p.Cout;
-        unsigned bpix[3];
+        unsigned bpix[NPL];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < NPL; ++j)
             bpix[j] = bvalid ? (unsigned)((size_t)j * p.wq_stride + (size_t)bn * p.K + bhalf * 8) * 2u : OOB;
         const unsigned blds = (unsigned)(brow * PITCH6 + bhalf * 8);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)2 * p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
-        u32x4 ra[3], rb[2][3];
+            const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)(NPL - 1) * p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
+        const float sa = F16 ? pow2_scale(p.a_bound[0]) : 1.f;      // fp16x3 operand scale
+        u32x4 ra[3], rb[2][NPL];
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         const int lastc = nchunks - 1;
         const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
@@ -1138,6 +1204,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
             if (PRO) {
                 sc = *reinterpret_cast<const float4*>(p.in_scale + c * 16 + kc * 4);
                 sh = *reinterpret_cast<const float4*>(p.in_shift + c * 16 + kc * 4);
+                if (F16) {      // the operand scale rides in the BN vectors
+                    sc.x *= sa; sc.y *= sa; sc.z *= sa; sc.w *= sa;
+                    sh.x *= sa; sh.y *= sa; sh.z *= sa; sh.w *= sa;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoffs[i], c * 64, 0);
@@ -1157,11 +1227,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
                     v.z = __builtin_amdgcn_fmed3f(b.x, lo, hi); v.w = __builtin_amdgcn_fmed3f(b.y, lo, hi);
                 }
                 uint2 q1, q2, q3;
-                split4(v, q1, q2, q3);
                 __bf16* dst = A6 + alds[i];
-                *reinterpret_cast<uint2*>(dst) = q1;
-                *reinterpret_cast<uint2*>(dst + HPP * PITCH6) = q2;
-                *reinterpret_cast<uint2*>(dst + 2 * HPP * PITCH6) = q3;
+                if (F16) {
+                    if (!PRO) { v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa; }
+                    split4h(v, q1, q2);
+                    *reinterpret_cast<uint2*>(dst) = q1;
+                    *reinterpret_cast<uint2*>(dst + HPP * PITCH6) = q2;
+                } else {
+                    split4(v, q1, q2, q3);
+                    *reinterpret_cast<uint2*>(dst) = q1;
+                    *reinterpret_cast<uint2*>(dst + HPP * PITCH6) = q2;
+                    *reinterpret_cast<uint2*>(dst + 2 * HPP * PITCH6) = q3;
+                }
             }
         };
         // weights of K-step (chunk c, tap t): OHWI columns t*Cin + c*16 .. +16 of the three planes
@@ -1169,13 +1246,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
             c = min(c, lastc);
             const unsigned koff = (unsigned)(t * p.Cin + c * 16) * 2u;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) rb[stage][j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bpix[j], koff, 0);
+            for (int j = 0; j < NPL; ++j) rb[stage][j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bpix[j], koff, 0);
         };
         auto storeB = [&](int stage, int buf) {
             if (brow < BN) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    *reinterpret_cast<u32x4*>(B6 + (size_t)(buf * 3 + j) * BN * PITCH6 + blds) = rb[stage][j];
+                for (int j = 0; j < NPL; ++j)
+                    *reinterpret_cast<u32x4*>(B6 + (size_t)(buf * NPL + j) * BN * PITCH6 + blds) = rb[stage][j];
             }
         };
         // step s = 9 * chunk + tap reads B buffer s & 1; its weights sit in register stage s & 1
@@ -1220,26 +1297,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
                 const int t = j % 9, buf = j & 1;
                 const int toff = ((t / 3) * HWD + (t % 3)) * PITCH6;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
                     for (int a = 0; a < TM; ++a)
                         F.a[a][pl] = *reinterpret_cast<const bf16x8*>(A6 + pl * HPP * PITCH6 + aoff[a] + toff);
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        F.b[b][pl] = *reinterpret_cast<const bf16x8*>(B6 + (buf * 3 + pl) * BN * PITCH6 + boff[b]);
+                        F.b[b][pl] = *reinterpret_cast<const bf16x8*>(B6 + (buf * NPL + pl) * BN * PITCH6 + boff[b]);
                 }
                 if (t == 8) __syncthreads();         // fragments are in registers: the halo may be refilled
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int b = 0; b < TN; ++b) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][2], F.b[b][0], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][2], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][1], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][0], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][1], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][0], acc[a][b], 0, 0, 0);
-                    }
+                    for (int b = 0; b < TN; ++b) mma_split<F16>(acc[a][b], F.a[a], F.b[b]);
                 __syncthreads();
             }
         }
@@ -1248,21 +1318,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
     conv_epilogue<2, WN, TM, TN, true>(p, acc, smem, mtile, ntile, tid, wave, lane, mbase);
 }
 
-template <int TN>
+template <int TN, bool F16 = false>
 static void launch_conv3x3_6(const ConvP& p, bool pro, hipStream_t st) {
-    constexpr int BN = 64 * TN;
-    size_t lds = (size_t)(3 * 192 + 2 * 3 * BN) * PITCH6 * 2;
+    constexpr int BN = 64 * TN, NPL = F16 ? 2 : 3;
+    size_t lds = (size_t)(NPL * 192 + 2 * NPL * BN) * PITCH6 * 2;
     const size_t epi = (size_t)128 * (BN + 4) * 4;
     if (epi > lds) lds = epi;
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {
-        hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 gr(p.mtiles * p.ntiles), bl(512);
-    if (pro) hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TN, true>), gr, bl, lds, st, p);
-    else hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TN, false>), gr, bl, lds, st, p);
+    if (pro) hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TN, true, F16>), gr, bl, lds, st, p);
+    else hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TN, false, F16>), gr, bl, lds, st, p);
 }
 
 static bool conv3x3_halo_ok(const dsnt_conv_geom* g) {
@@ -1270,23 +1340,23 @@ static bool conv3x3_halo_ok(const dsnt_conv_geom* g) {
            g->H % 8 == 0 && g->W % 16 == 0 && g->Cin % 32 == 0;
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool F16 = false>
 static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    size_t lds = (size_t)2 * 3 * (BM + BN) * PITCH6 * 2;
+    size_t lds = (size_t)2 * (F16 ? 2 : 3) * (BM + BN) * PITCH6 * 2;
     const size_t epi = (size_t)BM * (BN + 4) * 4;          // the epilogue's C tile lives in the same LDS
     if (epi > lds) lds = epi;
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {
-        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true>,
+        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false>,
+        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 gr(p.mtiles * p.ntiles), bl(512);
-    if (pro) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true>), gr, bl, lds, st, p);
-    else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false>), gr, bl, lds, st, p);
+    if (pro) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16>), gr, bl, lds, st, p);
+    else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16>), gr, bl, lds, st, p);
 }
 
 static bool g_force_gemm6 = false;      // debug/bench: route 3x3 convolutions through the implicit-GEMM kernel
@@ -1295,7 +1365,8 @@ extern "C" int dsnt_debug_force_gemm6(int on) { g_force_gemm6 = on != 0; return 
 static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_stride, const float* bias, float* y,
                           const float* in_scale, const float* in_shift, int in_relu,
                           const float* res1, const float* res2, float* stats_partial,
-                          const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, void* stream) {
+                          const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, void* stream,
+                          const float* a_bound = nullptr, const float* w_bound = nullptr) {
     if (int e = check_geom(g, "dsnt_conv_fwd_bf16x6")) return e;
     DSNT_REQUIRE(!g_bnb || (g_bnb->x && g_bnb->scale && g_bnb->shift && g_bnb->mean && g_bnb->invstd &&
                             stats_partial && !res1 && !res2 && !bias), DSNT_ERR_ARG,
@@ -1316,6 +1387,7 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     p.in_scale = in_scale; p.in_shift = in_shift; p.res1 = res1; p.res2 = res2; p.stats = stats_partial;
     p.in_relu = in_relu;
     p.bnb_scale = p.bnb_shift = p.bnb_mean = p.bnb_invstd = nullptr; p.bnb_relu = 0;
+    p.a_bound = p.w_bound = nullptr;
     if (g_bnb) {
         p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
         p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
@@ -1326,7 +1398,14 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     const int BN = g->Cout <= 64 ? 64 : 128;
     p.mtiles = (p.M + 127) / 128; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
-    if (conv3x3_halo_ok(g) && !g_force_gemm6) {
+    p.a_bound = a_bound; p.w_bound = w_bound;
+    if (a_bound) {                   // fp16x3: two fp16 weight planes, operand bounds in device memory
+        if (conv3x3_halo_ok(g) && !g_force_gemm6) {
+            if (BN == 128) launch_conv3x3_6<2, true>(p, in_scale != nullptr, st);
+            else launch_conv3x3_6<1, true>(p, in_scale != nullptr, st);
+        } else if (BN == 128) launch_fwd6<2, 2, 2, 2, true>(p, in_scale != nullptr, st);
+        else launch_fwd6<2, 2, 2, 1, true>(p, in_scale != nullptr, st);
+    } else if (conv3x3_halo_ok(g) && !g_force_gemm6) {
         if (BN == 128) launch_conv3x3_6<2>(p, in_scale != nullptr, st);
         else launch_conv3x3_6<1>(p, in_scale != nullptr, st);
     } else if (BN == 128) launch_fwd6<2, 2, 2, 2>(p, in_scale != nullptr, st);
@@ -1348,6 +1427,120 @@ extern "C" int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int
                                        const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream) {
     return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
                           stats_partial, g, bnb, stream);
+}
+
+extern "C" int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
+                                      const float* a_bound, const float* bias, float* y, const float* in_scale,
+                                      const float* in_shift, int in_relu, const float* res1, const float* res2,
+                                      float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
+                                      void* stream) {
+    DSNT_REQUIRE(a_bound && w_bound, DSNT_ERR_ARG, "dsnt_conv_fwd_f16x3_ex: the operand bounds (device scalars) are required");
+    return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
+                          stats_partial, g, bnb, stream, a_bound, w_bound);
+}
+
+// max |src[i]| -> out[0] (bit pattern of a non-negative float: integer max is float max)
+__global__ void amax_kernel(const float4* __restrict__ src, unsigned* __restrict__ out, long n4) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+extern "C" int dsnt_amax(const float* src, int64_t n, float* out, void* stream) {
+    DSNT_REQUIRE(src && out && n > 0 && n % 4 == 0 && dsnt_aligned16(src), DSNT_ERR_ARG,
+                 "dsnt_amax: n must be a positive multiple of 4, src 16-byte aligned");
+    if (hipMemsetAsync(out, 0, 4, (hipStream_t)stream) != hipSuccess) return dsnt_set_error(DSNT_ERR_HIP, "dsnt_amax: memset");
+    long g = (n / 4 + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+                       (unsigned*)out, (long)(n / 4));
+    DSNT_CHECK_LAUNCH("dsnt_amax");
+}
+
+__global__ void split_f16x2_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4, long stride4,
+                                   const float* __restrict__ bound) {
+    const float sc = pow2_scale(bound[0]);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = src[i];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        uint2 a, b;
+        split4h(v, a, b);
+        dst[i] = a; dst[stride4 + i] = b;
+    }
+}
+
+extern "C" int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t plane_stride, const float* bound,
+                                void* stream) {
+    DSNT_REQUIRE(src && dst && bound && n > 0 && n % 4 == 0 && plane_stride >= n && plane_stride % 4 == 0, DSNT_ERR_ARG,
+                 "dsnt_split_f16x2: n and plane_stride must be positive multiples of 4, plane_stride >= n");
+    DSNT_REQUIRE(dsnt_aligned16(src) && (((uintptr_t)dst) & 7u) == 0, DSNT_ERR_ALIGN, "dsnt_split_f16x2: alignment");
+    const long n4 = n / 4;
+    long g = (n4 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+                       (uint2*)dst, n4, (long)(plane_stride / 4), bound);
+    DSNT_CHECK_LAUNCH("dsnt_split_f16x2");
+}
+
+// Per-step preparation of the fp16x3 operands of MANY tensors in one launch each (table rows of int64):
+//   dsnt_f16_prep_weights: row {src float*, dst fp16 plane 0*, bound float*, count (multiple of 4), plane stride}:
+//     one workgroup per row: bound = max|src|, then dst = two fp16 planes of src * pow2_scale(bound);
+//   dsnt_f16_prep_bn_bounds: row {gamma float*, beta float*, out float*, C, float bits of sqrt(M)}: out =
+//     max_c(|gamma_c| sqrt(M) + |beta_c|) >= every |relu?(bn(x))| of a train-mode BatchNorm over M samples
+//     (|(x - mean) / std| <= sqrt(M - 1) for the biased batch variance).
+__global__ __launch_bounds__(256) void f16_prep_weights_kernel(const long long* __restrict__ table) {
+    __shared__ float red[4];
+    const long long* t = table + (size_t)blockIdx.x * 5;
+    const float4* src = reinterpret_cast<const float4*>(t[0]);
+    uint2* dst = reinterpret_cast<uint2*>(t[1]);
+    float* bound = reinterpret_cast<float*>(t[2]);
+    const long n4 = (long)t[3] / 4, stride4 = (long)t[4] / 4;
+    float m = 0.f;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = src[i];
+        m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
+    }
+    m = block_max(m, red);
+    if (threadIdx.x == 0) bound[0] = m;
+    const float sc = pow2_scale(m);
+    for (long i = threadIdx.x; i < n4; i += 256) {
+        float4 v = src[i];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        uint2 a, b;
+        split4h(v, a, b);
+        dst[i] = a; dst[stride4 + i] = b;
+    }
+}
+
+extern "C" int dsnt_f16_prep_weights(const int64_t* table, int rows, void* stream) {
+    DSNT_REQUIRE(table && rows > 0, DSNT_ERR_ARG, "dsnt_f16_prep_weights: bad argument");
+    hipLaunchKernelGGL(f16_prep_weights_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)table);
+    DSNT_CHECK_LAUNCH("dsnt_f16_prep_weights");
+}
+
+__global__ __launch_bounds__(64) void f16_prep_bn_bounds_kernel(const long long* __restrict__ table) {
+    const long long* t = table + (size_t)blockIdx.x * 5;
+    const float* gamma = reinterpret_cast<const float*>(t[0]);
+    const float* beta = reinterpret_cast<const float*>(t[1]);
+    float* out = reinterpret_cast<float*>(t[2]);
+    const int C = (int)t[3];
+    const float sqrtM = __uint_as_float((unsigned)t[4]);
+    float m = 0.f;
+    for (int c = threadIdx.x; c < C; c += 64) m = fmaxf(m, fmaf(fabsf(gamma[c]), sqrtM, fabsf(beta[c])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (threadIdx.x == 0) out[0] = m;
+}
+
+extern "C" int dsnt_f16_prep_bn_bounds(const int64_t* table, int rows, void* stream) {
+    DSNT_REQUIRE(table && rows > 0, DSNT_ERR_ARG, "dsnt_f16_prep_bn_bounds: bad argument");
+    hipLaunchKernelGGL(f16_prep_bn_bounds_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, (const long long*)table);
+    DSNT_CHECK_LAUNCH("dsnt_f16_prep_bn_bounds");
 }
 
 // wd[ci][R-1-r][S-1-s][co] = w[co][r][s][ci]

@@ -63,6 +63,11 @@ SIGNATURES = {
     'dsnt_conv_pack_dgrad_all': [P, I, P, P, P, L, P],
     'dsnt_conv_fwd_bf16x6': [P, P, L, P, P, P, P, I, P, P, P, GP, P],
     'dsnt_split_bf16x3': [P, P, L, P],
+    'dsnt_conv_fwd_f16x3_ex': [P, P, L, P, P, P, P, P, P, I, P, P, P, GP, BP, P],
+    'dsnt_amax': [P, L, P, P],
+    'dsnt_split_f16x2': [P, P, L, L, P, P],
+    'dsnt_f16_prep_weights': [P, I, P],
+    'dsnt_f16_prep_bn_bounds': [P, I, P],
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_bf16x6': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_wgrad_reduce_all': [P, I, I, P],

@@ -48,11 +48,12 @@ class Act:
 
 class ConvParams:
     """Views into the parameter / gradient arenas for one convolution (weights are OHWI)."""
-    __slots__ = ('w', 'b', 'gw', 'gb', 'Cout', 'R', 'S', 'Cin', 'stride', 'pad', 'dil', 'wq', 'wq_stride')
+    __slots__ = ('w', 'b', 'gw', 'gb', 'Cout', 'R', 'S', 'Cin', 'stride', 'pad', 'dil', 'wq', 'wq_stride', 'wq16', 'wb')
 
     def __init__(self, w, b, gw, gb, stride=1, pad=0, dil=1):
         self.w, self.b, self.gw, self.gb = w, b, gw, gb
         self.wq, self.wq_stride = None, 0      # bf16x6 planes of w (plane 0 view, plane stride)
+        self.wq16, self.wb = None, None        # fp16x3: fp16 planes (same stride) and the device scalar max|w|
         self.Cout, self.R, self.S, self.Cin = w.shape
         self.stride, self.pad, self.dil = stride, pad, dil
 
@@ -70,7 +71,7 @@ class BnParams:
 
 class Normed:
     """x seen through a BatchNorm(+ReLU): what a fused conv prologue needs."""
-    __slots__ = ('x', 'bn', 'mean', 'invstd', 'scale', 'shift', 'relu')
+    __slots__ = ('x', 'bn', 'mean', 'invstd', 'scale', 'shift', 'relu', 'abound')
 
 
 class Tape:
@@ -112,6 +113,12 @@ class Tape:
         # max-pool / upsample+add write the BatchNorm statistics of their output themselves (DSNT_FUSE_OP_STATS=0:
         # a separate dsnt_bn_stats pass when a BatchNorm asks for them)
         self.fuse_op_stats = os.environ.get('DSNT_FUSE_OP_STATS', '1') != '0'
+        # fp16x3 (DSNT_SPLIT=f16x3): two fp16 planes + three MFMAs instead of three bf16 planes + six, where an operand
+        # bound is available without a host round-trip: train-mode BN+ReLU operands (bound from the BN parameters) and
+        # weights (amax in the per-step prep launch)
+        self.use_f16x3 = self.use_bf16x6 and os.environ.get('DSNT_SPLIT', 'bf16x6') == 'f16x3'
+        self._f16_w_rows, self._f16_w_seen = [], set()
+        self._f16_bn_rows = []
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float32):
@@ -144,6 +151,41 @@ class Tape:
             self.nbytes += t.numel() * 2
             self._scratch[key] = t
         return t
+
+    def f16_weights(self, p, wq16=None, wsrc=None, wb=None):
+        """Register conv weights (default: the arena's forward layout) for the per-step fp16x3 preparation."""
+        wq16 = p.wq16 if wq16 is None else wq16
+        key = wq16.data_ptr()
+        if key not in self._f16_w_seen:
+            self._f16_w_seen.add(key)
+            wsrc = p.w if wsrc is None else wsrc
+            wb = p.wb if wb is None else wb
+            n = wsrc.numel()
+            assert n % 4 == 0
+            self._f16_w_rows.append([wsrc.data_ptr(), wq16.data_ptr(), wb.data_ptr(), n, p.wq_stride])
+
+    def f16_bn_bound(self, n):
+        """Device scalar >= |relu?(bn(x))| of the train-mode BatchNorm seen through Normed n."""
+        if n.abound is None:
+            n.abound = self.empty(1)
+            import struct
+            bits = struct.unpack('<I', struct.pack('<f', float(n.x.M) ** 0.5))[0]
+            self._f16_bn_rows.append([n.bn.gamma.data_ptr(), n.bn.beta.data_ptr(), n.abound.data_ptr(), n.bn.C, bits])
+        return n.abound
+
+    def emit_f16_prep(self, pos):
+        """Insert the fp16x3 preparation launches (weights, BN bounds) at position `pos` of the forward list."""
+        saved, self.fwd = self.fwd, []
+        if self._f16_w_rows:
+            t = torch.tensor(self._f16_w_rows, dtype=torch.int64).to(self.device)
+            self._keep.append(t)
+            self.f('dsnt_f16_prep_weights', t, len(self._f16_w_rows))
+        if self._f16_bn_rows:
+            t = torch.tensor(self._f16_bn_rows, dtype=torch.int64).to(self.device)
+            self._keep.append(t)
+            self.f('dsnt_f16_prep_bn_bounds', t, len(self._f16_bn_rows))
+        prep, self.fwd = self.fwd, saved
+        self.fwd[pos:pos] = prep
 
     def _use6(self, g):
         return (self.use_bf16x6 and g.N * g.Ho * g.Wo >= self.bf16x6_min_rows and
@@ -339,6 +381,7 @@ class Tape:
             relu = False
         n = Normed()
         n.x, n.bn, n.relu = x, bn, relu
+        n.abound = None
         n.mean, n.invstd, n.scale, n.shift = (self.empty(bn.C) for _ in range(4))
         if self.training:
             part, tiles = self.ensure_stats(x)
@@ -388,7 +431,12 @@ class Tape:
             y.stats = (part, tiles)
         r1 = res1.buf if res1 is not None else None
         r2 = res2.buf if res2 is not None else None
-        if use6:
+        use16 = use6 and self.use_f16x3 and self.training and normed and p.wq16 is not None
+        if use16:
+            self.f16_weights(p)
+            self.f('dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, self.f16_bn_bound(src), p.b, y.buf,
+                   sc, sh, relu, r1, r2, part, g, None)
+        elif use6:
             self.f('dsnt_conv_fwd_bf16x6', x.buf, p.wq, p.wq_stride, p.b, y.buf, sc, sh, relu, r1, r2, part, g)
         else:
             self.f('dsnt_conv_fwd', x.buf, p.w, p.b, y.buf, sc, sh, relu, r1, r2, part, g)

@@ -70,6 +70,10 @@ class Arena:
         # bf16x6 path: the arena split into three bf16 planes, refreshed by ONE launch per step
         self.planes = torch.zeros(3 * off, device=device, dtype=torch.bfloat16)
         self.packed_planes = {}
+        # fp16x3 path: two fp16 planes of every conv weight (scaled by a power of two per conv) + the weight bounds
+        self.planes16 = torch.zeros(2 * off, device=device, dtype=torch.float16)
+        self.wbounds = torch.zeros(len(slots), device=device, dtype=torch.float32)
+        self.packed_planes16, self.packed_wbound = {}, {}
         self.slots = slots
         self.pviews, self.gviews, self.packed, self.packed_fresh = {}, {}, {}, {}
         with torch.no_grad():
@@ -82,6 +86,9 @@ class Arena:
                     store[..., :I].copy_(src.permute(0, 2, 3, 1))
                     self.packed[name] = store
                     self.packed_planes[name] = self.planes[o:o + n]
+                    self.packed_planes16[name] = self.planes16[o:o + n]
+                    k = len(self.packed_wbound)
+                    self.packed_wbound[name] = self.wbounds[k:k + 1]
                     self.packed_fresh[name] = self.fresh[o:o + n].view(O, R, S, Ip)
                     pv = store.permute(0, 3, 1, 2)[:, :I]
                     gv = self.grads[o:o + n].view(O, R, S, Ip).permute(0, 3, 1, 2)[:, :I]
@@ -155,6 +162,7 @@ class Program:
                 gb = arena.packed_fresh[key(m, 'bias')] if m.bias is not None else None
                 cp = ConvParams(w, b, gw, gb, m.stride[0], m.padding[0], m.dilation[0])
                 cp.wq, cp.wq_stride = arena.packed_planes[key(m, 'weight')], arena.numel
+                cp.wq16, cp.wb = arena.packed_planes16[key(m, 'weight')], arena.packed_wbound[key(m, 'weight')]
                 return cp
 
             _bn = {}
@@ -173,10 +181,12 @@ class Program:
         N, Cc, H, W = in_shape
         if tape.use_bf16x6:
             tape.f('dsnt_split_bf16x3', arena.params, arena.planes, arena.numel)
+        prep_pos = len(tape.fwd)
         self.in_nchw = tape.empty(N, Cc, H, W)
         x = tape.from_planar(self.in_nchw, _ceil4(Cc), 'input')
         self.in_act = x
         outs = root.trace(tape, x, P)
+        tape.emit_f16_prep(prep_pos)        # fp16x3: weight planes + operand bounds, before the first convolution
         single = not isinstance(outs, (list, tuple))
         self.single = single
         outs = [outs] if single else list(outs)

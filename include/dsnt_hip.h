@@ -163,6 +163,27 @@ int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int64_t plane_
                             const float* res1, const float* res2, float* stats_partial,
                             const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream);
 
+/* fp16x3 variant: x * s = h1 + h2 on TWO fp16 planes after a power-of-two scale, three MFMAs per product (error vs
+ * fp64 below a plain fp32 GEMM's: conv.hip, tools/split_numerics.py).  a_bound / w_bound are DEVICE scalars >= the
+ * largest |value| of the A operand AFTER its BN+ReLU prologue (or of x when there is none) and of the weights; the
+ * kernels derive the scales from them (pow2: bound * scale in [2^13, 2^14)), so a loose bound is fine and a bound
+ * that is too SMALL overflows fp16.  w_planes: two fp16 planes made by dsnt_split_f16x2 with the SAME w_bound.
+ * Same arguments otherwise as dsnt_conv_fwd_bf16x6_ex. */
+int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
+                           const float* a_bound, const float* bias, float* y, const float* in_scale,
+                           const float* in_shift, int in_relu, const float* res1, const float* res2,
+                           float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream);
+/* out[0] = max |src[i]| (device scalar); dst = two fp16 planes (plane_stride elements apart) of src * pow2(bound). */
+int dsnt_amax(const float* src, int64_t n, float* out, void* stream);
+int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t plane_stride, const float* bound, void* stream);
+/* The same for many tensors per launch (device tables of int64 rows):
+ * dsnt_f16_prep_weights: row {src float*, dst fp16 plane-0*, bound float*, count (% 4 == 0), plane stride (elements)}:
+ *   bound = max|src|, dst = the two fp16 planes of src * pow2(bound) — every conv's weights once per step;
+ * dsnt_f16_prep_bn_bounds: row {gamma float*, beta float*, out float*, C, bits of float sqrt(M)}:
+ *   out = max_c(|gamma_c| sqrt(M) + |beta_c|), an upper bound of |relu?(bn(x))| for a TRAIN-mode BatchNorm over M samples. */
+int dsnt_f16_prep_weights(const int64_t* table, int rows, void* stream);
+int dsnt_f16_prep_bn_bounds(const int64_t* table, int rows, void* stream);
+
 /* Re-pack OHWI weights for the data-gradient pass: wd[Cin][R][S][Cout] with taps flipped,
  * so that dgrad(dy) == dsnt_conv_fwd(dy, wd) with pad' = dil*(R-1) - pad (stride 1). */
 int dsnt_conv_pack_dgrad(const float* w, float* wd, int Cout, int R, int S, int Cin,

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-@pytest.fixture(params=['f32', 'bf16x6'], autouse=True)
+@pytest.fixture(params=['f32', 'bf16x6', 'f16x3'], autouse=True)
 def mfma_path(request, monkeypatch):
     """Every model-level parity test runs twice: convolutions on the fp32 MFMA, and on the
     split-bf16 (bf16x6) matrix-core path forced on for ALL eligible convolutions (in production
@@ -25,6 +25,8 @@ def mfma_path(request, monkeypatch):
     else:
         monkeypatch.setenv('DSNT_MFMA', 'bf16x6')
         monkeypatch.setenv('DSNT_BF16X6_MIN_ROWS', '0')
+        # 'f16x3': two fp16 planes / three MFMAs wherever an operand bound exists, bf16x6 elsewhere
+        monkeypatch.setenv('DSNT_SPLIT', 'f16x3' if request.param == 'f16x3' else 'bf16x6')
     return request.param
 
 
@@ -173,7 +175,13 @@ def test_end_to_end_vs_golden(base, size, reg, tag, mfma_path):
         ev = m(x)[-1].cpu().numpy()
     assert np.abs(ev - g['eval_coords']).max() <= 1e-4
     n6 = _count_launches(m.hg, 'dsnt_conv_fwd_bf16x6')
-    assert (n6 > 100) if mfma_path == 'bf16x6' else (n6 == 0)
+    n16 = _count_launches(m.hg, 'dsnt_conv_fwd_f16x3_ex')
+    if mfma_path == 'bf16x6':
+        assert n6 > 100 and n16 == 0
+    elif mfma_path == 'f16x3':
+        assert n16 > 30 and n6 > 0          # train-mode BN+ReLU operands on fp16x3; eval mode and raw operands on bf16x6
+    else:
+        assert n6 == 0 and n16 == 0
 
 
 @pytest.mark.parametrize('smooth', [True, False])
