@@ -92,6 +92,17 @@ __device__ __host__ __forceinline__ float pow2_scale(float bound) {
     memcpy(&sc, &sb, 4);
     return sc;
 }
+// A bound lives in DSNT_BOUND_SLOTS floats; its value is their maximum.  Producers that find it with atomics (the
+// BN-backward apply kernel: thousands of workgroups) spread them over the slots by workgroup index: one hot address
+// serialised the read-modify-writes and cost the apply kernel 30 %.
+#define DSNT_BOUND_SLOTS 64
+__device__ __forceinline__ float bound64(const float* __restrict__ p) {
+    float b = p[threadIdx.x & 63];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+    return b;
+}
+
 // Shared epilogue of the forward / data-gradient kernels (fp32 and bf16x6 variants).
 // HALO: the tile's 128 rows are an 8 x 16 patch of output pixels starting at row `mbase` (row r of the
 // tile is output row mbase + (r >> 4) * W + (r & 15)) instead of 128 consecutive output rows.
@@ -144,7 +155,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         bis = *reinterpret_cast<const float4*>(p.bnb_invstd + n0);
     }
     // fp16x3: the accumulators hold (A s_a)(W s_w); both scales are powers of two, the product is undone exactly
-    const float osc = p.a_bound ? 1.f / (pow2_scale(p.a_bound[0]) * pow2_scale(p.w_bound[0])) : 1.f;
+    const float osc = p.a_bound ? 1.f / (pow2_scale(bound64(p.a_bound)) * pow2_scale(bound64(p.w_bound))) : 1.f;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
@@ -694,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)(NPL - 1) * p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
         // fp16x3: operand scale (a power of two) from the bound the producer left in device memory
-        const float sa = F16 ? pow2_scale(p.a_bound[0]) : 1.f;
+        const float sa = F16 ? pow2_scale(bound64(p.a_bound)) : 1.f;
         struct Stage {
             u32x4 ra[APASS], rb[NPL];
             float4 sc, sh;
@@ -1194,7 +1205,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
             const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)(NPL - 1) * p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
-        const float sa = F16 ? pow2_scale(p.a_bound[0]) : 1.f;      // fp16x3 operand scale
+        const float sa = F16 ? pow2_scale(bound64(p.a_bound)) : 1.f;      // fp16x3 operand scale
         u32x4 ra[3], rb[2][NPL];
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         const int lastc = nchunks - 1;
@@ -1448,13 +1459,13 @@ __global__ void amax_kernel(const float4* __restrict__ src, unsigned* __restrict
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out + (blockIdx.x & (DSNT_BOUND_SLOTS - 1)), __float_as_uint(m));
 }
 
 extern "C" int dsnt_amax(const float* src, int64_t n, float* out, void* stream) {
     DSNT_REQUIRE(src && out && n > 0 && n % 4 == 0 && dsnt_aligned16(src), DSNT_ERR_ARG,
                  "dsnt_amax: n must be a positive multiple of 4, src 16-byte aligned");
-    if (hipMemsetAsync(out, 0, 4, (hipStream_t)stream) != hipSuccess) return dsnt_set_error(DSNT_ERR_HIP, "dsnt_amax: memset");
+    if (hipMemsetAsync(out, 0, 4 * DSNT_BOUND_SLOTS, (hipStream_t)stream) != hipSuccess) return dsnt_set_error(DSNT_ERR_HIP, "dsnt_amax: memset");
     long g = (n / 4 + 255) / 256;
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
@@ -1464,7 +1475,7 @@ extern "C" int dsnt_amax(const float* src, int64_t n, float* out, void* stream) 
 
 __global__ void split_f16x2_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long n4, long stride4,
                                    const float* __restrict__ bound) {
-    const float sc = pow2_scale(bound[0]);
+    const float sc = pow2_scale(bound64(bound));
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 v = src[i];
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
@@ -1506,7 +1517,7 @@ __global__ __launch_bounds__(256) void f16_prep_weights_kernel(const long long* 
         m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
     }
     m = block_max(m, red);
-    if (threadIdx.x == 0) bound[0] = m;
+    if (threadIdx.x < DSNT_BOUND_SLOTS) bound[threadIdx.x] = m;
     const float sc = pow2_scale(m);
     for (long i = threadIdx.x; i < n4; i += 256) {
         float4 v = src[i];
@@ -1534,7 +1545,7 @@ __global__ __launch_bounds__(64) void f16_prep_bn_bounds_kernel(const long long*
     for (int c = threadIdx.x; c < C; c += 64) m = fmaxf(m, fmaf(fabsf(gamma[c]), sqrtM, fabsf(beta[c])));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (threadIdx.x == 0) out[0] = m;
+    out[threadIdx.x] = m;                    // all DSNT_BOUND_SLOTS entries
 }
 
 extern "C" int dsnt_f16_prep_bn_bounds(const int64_t* table, int rows, void* stream) {

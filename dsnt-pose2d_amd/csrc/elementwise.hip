@@ -324,7 +324,8 @@ __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const flo
                                         const float4* __restrict__ scale, const float4* __restrict__ shift,
                                         const float4* __restrict__ mean, const float4* __restrict__ invstd,
                                         const float4* __restrict__ coef, int relu, float4* dx,
-                                        int accumulate, long n4, int C4) {
+                                        int accumulate, long n4, int C4, unsigned* __restrict__ amax) {
+    float am = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(i % C4);
@@ -344,13 +345,53 @@ __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const flo
         o.w = sc.w * (dz.w - c0.w - (xv.w - mu.w) * is.w * c1.w);
         if (accumulate) { const float4 p = dx[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
         dx[i] = o;
+        am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am);
     }
+    if (amax) {         // max |dx| for the fp16x3 consumers: integer max of non-negative float bits, order-independent
+        __shared__ float wmax[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            am = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+            // one fire-and-forget atomic per workgroup (no returned value to wait for)
+            if (am > 0.f) atomicMax(amax + (blockIdx.x & 63), __float_as_uint(am));      // 64 slots: see bound64 (conv.hip)
+        }
+    }
+}
+
+static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, const float* coef, int relu, float* dx,
+                                 int accumulate, int64_t M, int C, float* amax, void* stream);
+
+extern "C" int dsnt_bn_act_bwd_apply_amax(const float* da, const float* x, const float* scale,
+                                          const float* shift, const float* mean, const float* invstd,
+                                          const float* coef, int relu, float* dx, int accumulate,
+                                          int64_t M, int C, float* amax, void* stream) {
+    return bn_act_bwd_apply_impl(da, x, scale, shift, mean, invstd, coef, relu, dx, accumulate, M, C, amax, stream);
+}
+
+__global__ void fill_zero_kernel(float* p, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+extern "C" int dsnt_fill_zero(float* p, int64_t n, void* stream) {
+    DSNT_REQUIRE(p && n > 0, DSNT_ERR_ARG, "dsnt_fill_zero: bad argument");
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, (long)n);
+    DSNT_CHECK_LAUNCH("dsnt_fill_zero");
 }
 
 extern "C" int dsnt_bn_act_bwd_apply(const float* da, const float* x, const float* scale,
                                      const float* shift, const float* mean, const float* invstd,
                                      const float* coef, int relu, float* dx, int accumulate,
                                      int64_t M, int C, void* stream) {
+    return bn_act_bwd_apply_impl(da, x, scale, shift, mean, invstd, coef, relu, dx, accumulate, M, C, nullptr, stream);
+}
+
+static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, const float* coef, int relu, float* dx,
+                                 int accumulate, int64_t M, int C, float* amax, void* stream) {
     DSNT_REQUIRE(da && x && scale && shift && mean && invstd && coef && dx && M > 0 && C > 0,
                  DSNT_ERR_ARG, "dsnt_bn_act_bwd_apply: bad argument");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(da) && dsnt_aligned16(x) && dsnt_aligned16(dx) &&
@@ -359,7 +400,7 @@ extern "C" int dsnt_bn_act_bwd_apply(const float* da, const float* x, const floa
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
                        (const float4*)shift, (const float4*)mean, (const float4*)invstd,
-                       (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4);
+                       (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax);
     DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_apply");
 }
 

@@ -78,6 +78,8 @@ SIGNATURES = {
     'dsnt_bn_act_bwd_reduce': [P, P, P, P, P, P, I, P, L, I, P],
     'dsnt_bn_bwd_finalize': [P, I, L, I, P, P, I, P, P],
     'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
+    'dsnt_bn_act_bwd_apply_amax': [P, P, P, P, P, P, P, I, P, I, L, I, P, P],
+    'dsnt_fill_zero': [P, L, P],
     'dsnt_maxpool2_fwd': [P, P, P, I, I, I, I, P],
     'dsnt_maxpool2_bwd': [P, P, P, I, I, I, I, I, P],
     'dsnt_maxpool2_fwd_stats': [P, P, P, P, I, I, I, I, P],

@@ -32,13 +32,14 @@ BN_MOMENTUM = 0.1
 
 class Act:
     """An activation on the tape: NHWC buffer + lazily created gradient / batch statistics."""
-    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name')
+    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax')
 
     def __init__(self, buf, name=''):
         self.buf = buf
         self.N, self.H, self.W, self.C = buf.shape
         self.grad = None        # torch tensor once some backward op has written it
         self.stats = None       # (partial tensor, ntiles)
+        self.grad_amax = None   # fp16x3: device scalar max|grad| when ONE bn-backward apply wrote the whole gradient
         self.name = name
 
     @property
@@ -119,6 +120,9 @@ class Tape:
         self.use_f16x3 = self.use_bf16x6 and os.environ.get('DSNT_SPLIT', 'bf16x6') == 'f16x3'
         self._f16_w_rows, self._f16_w_seen = [], set()
         self._f16_bn_rows = []
+        self._amax_buf, self._amax_used = None, 0      # zeroed at the start of every backward
+        self._f16_dw_rows = []      # fp16x3 planes of the re-packed data-gradient weights
+        self.dgrad_planes16, self.dgrad_bounds = None, None
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float32):
@@ -167,11 +171,18 @@ class Tape:
     def f16_bn_bound(self, n):
         """Device scalar >= |relu?(bn(x))| of the train-mode BatchNorm seen through Normed n."""
         if n.abound is None:
-            n.abound = self.empty(1)
+            n.abound = self.empty(64)            # a bound = 64 slots (DSNT_BOUND_SLOTS)
             import struct
             bits = struct.unpack('<I', struct.pack('<f', float(n.x.M) ** 0.5))[0]
             self._f16_bn_rows.append([n.bn.gamma.data_ptr(), n.bn.beta.data_ptr(), n.abound.data_ptr(), n.bn.C, bits])
         return n.abound
+
+    def amax_slot(self):
+        if self._amax_buf is None:
+            self._amax_buf = self.empty(64 * 512)
+        assert self._amax_used + 64 <= self._amax_buf.numel()
+        self._amax_used += 64
+        return self._amax_buf[self._amax_used - 64:self._amax_used]
 
     def emit_f16_prep(self, pos):
         """Insert the fp16x3 preparation launches (weights, BN bounds) at position `pos` of the forward list."""
@@ -273,9 +284,23 @@ class Tape:
             self.b('dsnt_conv_pack_dgrad_all', table, len(rows), self.param_arena, self.dgrad_f32,
                    self.dgrad_planes, total)
             self.dgrad_total = total
+            if self.use_f16x3:
+                self.dgrad_planes16 = self.empty(2 * total, dtype=torch.float16)
+                self.dgrad_bounds = self.empty(64 * len(rows))
+        prep_pos = len(self.bwd)
         for fn in reversed(self._bwd_emitters):
             fn()
         self._bwd_emitters = []
+        # fp16x3: zero the amax slots, split the re-packed data-gradient weights that some conv asked for
+        saved, self.bwd = self.bwd, []
+        if self._amax_used:
+            self.b('dsnt_fill_zero', self._amax_buf, self._amax_used)
+        if self._f16_dw_rows:
+            t = torch.tensor(self._f16_dw_rows, dtype=torch.int64).to(self.device)
+            self._keep.append(t)
+            self.b('dsnt_f16_prep_weights', t, len(self._f16_dw_rows))
+        prep, self.bwd = self.bwd, saved
+        self.bwd[prep_pos:prep_pos] = prep
         if self._pending_reduce:          # convolutions outside every parameter bucket (stand-alone modules)
             if self.wgrad_lane is not None:
                 self.sync_bwd(self.wgrad_lane, 0)
@@ -348,6 +373,7 @@ class Tape:
         if a.grad is None:
             a.grad = self.empty(a.N, a.H, a.W, a.C)
             return a.grad, 0
+        a.grad_amax = None          # a second writer: the first one's maximum no longer bounds the tensor
         return a.grad, 1
 
     def grad_identity(self, a, g, donate):
@@ -410,8 +436,13 @@ class Tape:
         bn.uses += 1
         self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef)
         buf, acc = self.grad_target(x)
-        self.b('dsnt_bn_act_bwd_apply', da, x.buf, n.scale, n.shift, n.mean, n.invstd, coef, relu,
-               buf, acc, x.M, bn.C)
+        if self.use_f16x3 and acc == 0:
+            x.grad_amax = self.amax_slot()
+            self.b('dsnt_bn_act_bwd_apply_amax', da, x.buf, n.scale, n.shift, n.mean, n.invstd, coef, relu,
+                   buf, acc, x.M, bn.C, x.grad_amax)
+        else:
+            self.b('dsnt_bn_act_bwd_apply', da, x.buf, n.scale, n.shift, n.mean, n.invstd, coef, relu,
+                   buf, acc, x.M, bn.C)
 
     def conv(self, src, p, res1=None, res2=None, want_stats=False, need_input_grad=True, name=''):
         """y = conv(src) + bias [+ res1 + res2]; src is an Act (raw) or a Normed (BN+ReLU folded)."""
@@ -445,6 +476,7 @@ class Tape:
         slot = None
         if need_input_grad and self.param_arena is not None:
             slot = self.dgrad_total
+            slot_k = len(self.dgrad_slots)
             self.dgrad_slots.append((p, slot))
             self.dgrad_total += (p.w.numel() + 7) // 8 * 8
 
@@ -513,8 +545,18 @@ class Tape:
 
                 gsrc = gy if p.stride == 1 else gy_d
 
+                g_amax = y.grad_amax if (self.use_f16x3 and p.stride == 1) else None
+                d16 = d6 and g_amax is not None and slot is not None and self.dgrad_planes16 is not None
+                if d16:
+                    wq16 = self.dgrad_planes16[slot:slot + nw]
+                    wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
+                    self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total])
+
                 def dgrad(out, res, part=None, bnb=None):
-                    if d6:
+                    if d16:
+                        self.b('dsnt_conv_fwd_f16x3_ex', gsrc, wq16, self.dgrad_total, wbd, g_amax, None, out, None, None,
+                               0, res, None, part, gd, bnb)
+                    elif d6:
                         self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
                                part, gd, bnb)
                     else:

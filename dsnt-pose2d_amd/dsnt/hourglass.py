@@ -72,7 +72,7 @@ class Arena:
         self.packed_planes = {}
         # fp16x3 path: two fp16 planes of every conv weight (scaled by a power of two per conv) + the weight bounds
         self.planes16 = torch.zeros(2 * off, device=device, dtype=torch.float16)
-        self.wbounds = torch.zeros(len(slots), device=device, dtype=torch.float32)
+        self.wbounds = torch.zeros(64 * len(slots), device=device, dtype=torch.float32)   # 64 slots per bound
         self.packed_planes16, self.packed_wbound = {}, {}
         self.slots = slots
         self.pviews, self.gviews, self.packed, self.packed_fresh = {}, {}, {}, {}
@@ -88,7 +88,7 @@ class Arena:
                     self.packed_planes[name] = self.planes[o:o + n]
                     self.packed_planes16[name] = self.planes16[o:o + n]
                     k = len(self.packed_wbound)
-                    self.packed_wbound[name] = self.wbounds[k:k + 1]
+                    self.packed_wbound[name] = self.wbounds[64 * k:64 * k + 64]
                     self.packed_fresh[name] = self.fresh[o:o + n].view(O, R, S, Ip)
                     pv = store.permute(0, 3, 1, 2)[:, :I]
                     gv = self.grads[o:o + n].view(O, R, S, Ip).permute(0, 3, 1, 2)[:, :I]

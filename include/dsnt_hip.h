@@ -168,12 +168,14 @@ int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int64_t plane_
  * largest |value| of the A operand AFTER its BN+ReLU prologue (or of x when there is none) and of the weights; the
  * kernels derive the scales from them (pow2: bound * scale in [2^13, 2^14)), so a loose bound is fine and a bound
  * that is too SMALL overflows fp16.  w_planes: two fp16 planes made by dsnt_split_f16x2 with the SAME w_bound.
- * Same arguments otherwise as dsnt_conv_fwd_bf16x6_ex. */
+ * Same arguments otherwise as dsnt_conv_fwd_bf16x6_ex.
+ * A "device scalar" bound is DSNT_BOUND_SLOTS = 64 floats whose MAXIMUM is the bound (producers that find it with
+ * atomics spread them over the slots; the others write the same value 64 times). */
 int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
                            const float* a_bound, const float* bias, float* y, const float* in_scale,
                            const float* in_shift, int in_relu, const float* res1, const float* res2,
                            float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream);
-/* out[0] = max |src[i]| (device scalar); dst = two fp16 planes (plane_stride elements apart) of src * pow2(bound). */
+/* out[0..63] = bound slots whose maximum is max |src[i]|; dst = two fp16 planes (plane_stride elements apart) of src * pow2(bound). */
 int dsnt_amax(const float* src, int64_t n, float* out, void* stream);
 int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t plane_stride, const float* bound, void* stream);
 /* The same for many tensors per launch (device tables of int64 rows):
@@ -289,6 +291,13 @@ int dsnt_bn_act_bwd_apply(const float* da, const float* x, const float* scale,
                           const float* shift, const float* mean, const float* invstd,
                           const float* coef, int relu, float* dx, int accumulate,
                           int64_t M, int C, void* stream);
+/* The same, additionally raising amax[0] (device scalar, zeroed by the caller at the start of the step: dsnt_fill_zero)
+ * (64 bound slots, slot = workgroup index mod 64) to max |dx| with integer atomic maxima on the floats' bits (order-independent): the operand bound of the fp16x3
+ * data / weight gradient kernels that consume dx. */
+int dsnt_bn_act_bwd_apply_amax(const float* da, const float* x, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* coef, int relu, float* dx,
+                               int accumulate, int64_t M, int C, float* amax, void* stream);
+int dsnt_fill_zero(float* p, int64_t n, void* stream);
 
 /* F.max_pool2d(x, 2, stride=2) (hourglass.py:80,111,162): y [N][H/2][W/2][C],
  * idx = position (0..3) of the first maximum in scan order, for the backward. */
