@@ -1627,6 +1627,8 @@ struct WgradP {
     int in_relu;
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil;
     int M, K, ktiles, ntiles, splits, rows_per_split;
+    // fp16x3: bound slots of the A operand (after its BN+ReLU prologue) and of dy; null on the bf16x6 path
+    const float* a_bound; const float* g_bound;
 };
 
 #define WPITCH 132
@@ -1834,11 +1836,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradP p) {
 // plain (unpacked) fp32 ops (split4).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool PRO, bool IS_A>
+template <bool PRO, bool IS_A, bool F16>
 __device__ __forceinline__ void wgrad6_loader(const WgradP& p, __bf16* T, const int ltid, const int ktile,
                                               const int ntile, const int m_begin, const int m_end,
                                               const int nsteps, f32x2& bs0, f32x2& bs1) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NPL = F16 ? 2 : 3;
+    // fp16x3: power-of-two operand scale from the bound slots (A: folded into the BN vectors below; dY: one multiply)
+    const float sop = F16 ? pow2_scale(bound64(IS_A ? p.a_bound : p.g_bound)) : 1.f;
     // 4-wide column chunk q, 4-row block mb.  mb varies fastest: a 16-lane store group then spans
     // 4 chunks x 4 blocks (2-way bank conflicts; q fastest would be 8-way with the 48-byte pitch)
     const int mb = ltid & 3, q = (ltid >> 2) & 31;
@@ -1858,6 +1863,7 @@ __device__ __forceinline__ void wgrad6_loader(const WgradP& p, __bf16* T, const 
         const float4 b = *reinterpret_cast<const float4*>(p.in_shift + c);
         sc0 = (f32x2){a.x, a.y}; sc1 = (f32x2){a.z, a.w};
         sh0 = (f32x2){b.x, b.y}; sh1 = (f32x2){b.z, b.w};
+        if (F16) { sc0 *= sop; sc1 *= sop; sh0 *= sop; sh1 *= sop; }
     }
     // ReLU and the padding select as one median: valid rows clamp to [lo, +inf) with lo = 0 (ReLU) or
     // -inf (no ReLU), invalid rows to [0, 0]
@@ -1918,16 +1924,24 @@ __device__ __forceinline__ void wgrad6_loader(const WgradP& p, __bf16* T, const 
             }
             if (!IS_A) { bs0.x += v0[j].x; bs0.y += v0[j].y; bs1.x += v1[j].x; bs1.y += v1[j].y; }
         }
-        __bf16* base = T + ((size_t)(buf * 3) * 128 + q * 4) * PITCH6 + mb * 4;
+        __bf16* base = T + ((size_t)(buf * NPL) * 128 + q * 4) * PITCH6 + mb * 4;
         // component e of the four rows -> LDS row (q*4 + e), columns mb*4 .. mb*4+3, three planes
 #define SPLIT_COL(E, V, COMP)                                                                        \
         {                                                                                            \
             uint2 q1, q2, q3;                                                                        \
-            split4(make_float4(V[0].COMP, V[1].COMP, V[2].COMP, V[3].COMP), q1, q2, q3);            \
+            float4 c4 = make_float4(V[0].COMP, V[1].COMP, V[2].COMP, V[3].COMP);                     \
             __bf16* d = base + (E) * PITCH6;                                                         \
-            *reinterpret_cast<uint2*>(d) = q1;                                                       \
-            *reinterpret_cast<uint2*>(d + 128 * PITCH6) = q2;                                        \
-            *reinterpret_cast<uint2*>(d + 2 * 128 * PITCH6) = q3;                                    \
+            if (F16) {                                                                               \
+                if (!(PRO && IS_A)) { c4.x *= sop; c4.y *= sop; c4.z *= sop; c4.w *= sop; }          \
+                split4h(c4, q1, q2);                                                                 \
+                *reinterpret_cast<uint2*>(d) = q1;                                                   \
+                *reinterpret_cast<uint2*>(d + 128 * PITCH6) = q2;                                    \
+            } else {                                                                                 \
+                split4(c4, q1, q2, q3);                                                              \
+                *reinterpret_cast<uint2*>(d) = q1;                                                   \
+                *reinterpret_cast<uint2*>(d + 128 * PITCH6) = q2;                                    \
+                *reinterpret_cast<uint2*>(d + 2 * 128 * PITCH6) = q3;                                \
+            }                                                                                        \
         }
         SPLIT_COL(0, v0, x) SPLIT_COL(1, v0, y) SPLIT_COL(2, v1, x) SPLIT_COL(3, v1, y)
 #undef SPLIT_COL
@@ -1950,10 +1964,11 @@ __device__ __forceinline__ void wgrad6_loader(const WgradP& p, __bf16* T, const 
     if (s < nsteps) __syncthreads();
 }
 
-template <bool PRO>
+template <bool PRO, bool F16 = false>
 __device__ __forceinline__ void wgrad6_body(const WgradP& p, int bid, float* smem) {
-    __bf16* At = reinterpret_cast<__bf16*>(smem);            // [2][3][128][PITCH6]
-    __bf16* Gt = At + 2 * 3 * 128 * PITCH6;                  // [2][3][128][PITCH6]
+    constexpr int NPL = F16 ? 2 : 3;
+    __bf16* At = reinterpret_cast<__bf16*>(smem);            // [2][NPL][128][PITCH6]
+    __bf16* Gt = At + 2 * NPL * 128 * PITCH6;                // [2][NPL][128][PITCH6]
 
     const int ktile = bid % p.ktiles; bid /= p.ktiles;
     const int ntile = bid % p.ntiles;
@@ -1968,9 +1983,9 @@ __device__ __forceinline__ void wgrad6_body(const WgradP& p, int bid, float* sme
     f32x2 bs0 = {0.f, 0.f}, bs1 = {0.f, 0.f};
 
     if (wave >= 6) {
-        wgrad6_loader<PRO, false>(p, Gt, tid - 384, ktile, ntile, m_begin, m_end, nsteps, bs0, bs1);
+        wgrad6_loader<PRO, false, F16>(p, Gt, tid - 384, ktile, ntile, m_begin, m_end, nsteps, bs0, bs1);
     } else if (wave >= 4) {
-        wgrad6_loader<PRO, true>(p, At, tid - 256, ktile, ntile, m_begin, m_end, nsteps, bs0, bs1);
+        wgrad6_loader<PRO, true, F16>(p, At, tid - 256, ktile, ntile, m_begin, m_end, nsteps, bs0, bs1);
     } else {
         // ------------------------------------------------------------------ MFMA waves
         f32x16 acc[2][2];
@@ -1987,28 +2002,23 @@ __device__ __forceinline__ void wgrad6_body(const WgradP& p, int bid, float* sme
         for (int s = 0; s < nsteps; ++s) {
             const int buf = s & 1;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     F.a[t][pl] = *reinterpret_cast<const bf16x8*>(
-                        At + ((size_t)(buf * 3 + pl) * 128 + wk * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
+                        At + ((size_t)(buf * NPL + pl) * 128 + wk * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
                     F.b[t][pl] = *reinterpret_cast<const bf16x8*>(
-                        Gt + ((size_t)(buf * 3 + pl) * 128 + wn * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
+                        Gt + ((size_t)(buf * NPL + pl) * 128 + wn * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
                 }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][2], F.b[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][2], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][0], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][1], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][0], acc[a][b], 0, 0, 0);
-                }
+                for (int b = 0; b < 2; ++b) mma_split<F16>(acc[a][b], F.a[a], F.b[b]);
             __syncthreads();
         }
         // slab store: ws[split][n][k], D row = k (regs, 4 consecutive), D col = n (lane)
+        // (fp16x3: the accumulators hold (A s_a)^T (dY s_g); both scales are powers of two, undone exactly)
+        const float osc = F16 ? 1.f / (pow2_scale(bound64(p.a_bound)) * pow2_scale(bound64(p.g_bound))) : 1.f;
         float* slab = p.ws + (size_t)split * p.Cout * p.K;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -2021,8 +2031,8 @@ __device__ __forceinline__ void wgrad6_body(const WgradP& p, int bid, float* sme
                     const int k = ktile * 128 + wk * 64 + a * 32 + 8 * qq + 4 * lh;
                     if (k < p.K)
                         *reinterpret_cast<float4*>(slab + (size_t)n * p.K + k) =
-                            make_float4(acc[a][b][4 * qq + 0], acc[a][b][4 * qq + 1], acc[a][b][4 * qq + 2],
-                                        acc[a][b][4 * qq + 3]);
+                            make_float4(acc[a][b][4 * qq + 0] * osc, acc[a][b][4 * qq + 1] * osc,
+                                        acc[a][b][4 * qq + 2] * osc, acc[a][b][4 * qq + 3] * osc);
                 }
         }
     }
@@ -2045,14 +2055,14 @@ __device__ __forceinline__ void wgrad6_body(const WgradP& p, int bid, float* sme
     }
 }
 
-template <bool PRO>
+template <bool PRO, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_kernel(WgradP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // the k-tiles (filter taps) and n-tiles of one split read the same rows of x and dy: keep them in one
     // XCD (one L2) instead of dealing them round-robin over the eight
     int bid;
     xcd_remap(blockIdx.x, gridDim.x, bid);
-    wgrad6_body<PRO>(p, bid, smem);
+    wgrad6_body<PRO, F16>(p, bid, smem);
 }
 
 // Grouped launch: blockIdx.y picks one of many convolutions from a device table of WgradP descriptors
@@ -2065,7 +2075,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_group_kernel(const W
     const WgradP p = table[blockIdx.y];
     const int nblk = p.ktiles * p.ntiles * p.splits;
     if ((int)blockIdx.x >= nblk) return;
-    wgrad6_body<true>(p, blockIdx.x, smem);
+    if (p.a_bound) wgrad6_body<true, true>(p, blockIdx.x, smem);        // workgroup-uniform: fp16x3 descriptors
+    else wgrad6_body<true, false>(p, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2401,7 +2412,8 @@ extern "C" int dsnt_conv_wgrad_splits(const dsnt_conv_geom* g) {
 
 static int conv_wgrad_impl(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                            const float* dy, float* ws, float* dw, float* dbias, int accumulate,
-                           const dsnt_conv_geom* g, void* stream, bool bf16x6);
+                           const dsnt_conv_geom* g, void* stream, bool bf16x6, const float* a_bound = nullptr,
+                           const float* g_bound = nullptr);
 
 extern "C" int dsnt_conv_wgrad(const float* x, const float* in_scale, const float* in_shift,
                                int in_relu, const float* dy, float* ws, float* dw, float* dbias,
@@ -2425,7 +2437,10 @@ extern "C" int dsnt_conv_wgrad_bf16x6(const float* x, const float* in_scale, con
 }
 
 static void wgrad_fill(WgradP& p, const float* x, const float* in_scale, const float* in_shift, int in_relu,
-                       const float* dy, float* ws, const dsnt_conv_geom* g) {
+                       const float* dy, float* ws, const dsnt_conv_geom* g, const float* a_bound = nullptr,
+                       const float* g_bound = nullptr) {
+    memset(&p, 0, sizeof(p));
+    p.a_bound = a_bound; p.g_bound = g_bound;
     p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.dy = dy; p.ws = ws; p.in_relu = in_relu;
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
@@ -2449,6 +2464,21 @@ extern "C" int dsnt_conv_wgrad_desc(const float* x, const float* in_scale, const
     return p.ktiles * p.ntiles * p.splits;
 }
 
+extern "C" int dsnt_conv_wgrad_desc_f16x3(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                                          const float* dy, float* ws, const float* a_bound, const float* g_bound,
+                                          const dsnt_conv_geom* g, void* desc_out) {
+    if (int e = check_geom(g, "dsnt_conv_wgrad_desc_f16x3")) return -e;
+    if (!x || !dy || !ws || !in_scale || !in_shift || !desc_out || !a_bound || !g_bound || !dsnt_conv_wgrad_bf16x6_ok(g) ||
+        !dsnt_aligned16(x) || !dsnt_aligned16(dy) || !dsnt_aligned16(ws)) {
+        return -dsnt_set_error(DSNT_ERR_ARG, "dsnt_conv_wgrad_desc_f16x3: needs x, dy, ws (16-byte aligned), in_scale/in_shift, "
+                                             "both operand bounds and a geometry dsnt_conv_wgrad_bf16x6_ok accepts");
+    }
+    WgradP p;
+    wgrad_fill(p, x, in_scale, in_shift, in_relu, dy, ws, g, a_bound, g_bound);
+    memcpy(desc_out, &p, sizeof(p));
+    return p.ktiles * p.ntiles * p.splits;
+}
+
 extern "C" int dsnt_conv_wgrad_group(const void* table, int nconv, int max_blocks, void* stream) {
     DSNT_REQUIRE(table && nconv > 0 && nconv <= 65535 && max_blocks > 0, DSNT_ERR_ARG,
                  "dsnt_conv_wgrad_group: bad argument");
@@ -2463,9 +2493,19 @@ extern "C" int dsnt_conv_wgrad_group(const void* table, int nconv, int max_block
     DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_group");
 }
 
+extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                                     const float* dy, float* ws, float* dw, float* dbias, int accumulate,
+                                     const float* a_bound, const float* g_bound, const dsnt_conv_geom* g, void* stream) {
+    DSNT_REQUIRE(dsnt_conv_wgrad_bf16x6_ok(g), DSNT_ERR_SHAPE,
+                 "dsnt_conv_wgrad_f16x3: geometry not supported (need Wo %% 4 == 0, tensors < 2 GiB)");
+    DSNT_REQUIRE(a_bound && g_bound, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: both operand bounds are required");
+    return conv_wgrad_impl(x, in_scale, in_shift, in_relu, dy, ws, dw, dbias, accumulate, g, stream, true, a_bound, g_bound);
+}
+
 static int conv_wgrad_impl(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                            const float* dy, float* ws, float* dw, float* dbias, int accumulate,
-                           const dsnt_conv_geom* g, void* stream, bool bf16x6) {
+                           const dsnt_conv_geom* g, void* stream, bool bf16x6, const float* a_bound,
+                           const float* g_bound) {
     if (int e = check_geom(g, "dsnt_conv_wgrad")) return e;
     DSNT_REQUIRE(x && dy && ws, DSNT_ERR_ARG, "dsnt_conv_wgrad: null tensor");
     DSNT_REQUIRE(dw || !dbias, DSNT_ERR_ARG, "dsnt_conv_wgrad: dbias without dw");
@@ -2476,15 +2516,15 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
     DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(dy) && dsnt_aligned16(ws) && (!dw || dsnt_aligned16(dw)),
                  DSNT_ERR_ALIGN, "dsnt_conv_wgrad: tensors must be 16-byte aligned");
     WgradP p;
-    wgrad_fill(p, x, in_scale, in_shift, in_relu, dy, ws, g);
+    wgrad_fill(p, x, in_scale, in_shift, in_relu, dy, ws, g, a_bound, g_bound);
     hipStream_t st = (hipStream_t)stream;
     const int grid = p.ktiles * p.ntiles * p.splits;
     if (bf16x6) {
         const int lds = 2 * 2 * 3 * 128 * PITCH6 * 2;
         static bool attr_done = false;
         if (!attr_done) {
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             attr_done = true;
@@ -2492,11 +2532,21 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
         // DSNT_WGRAD_KERNEL=unified: the variant without the loader / MFMA role split (A/B switch; same speed)
         static int unified = -1;
         if (unified < 0) { const char* e = getenv("DSNT_WGRAD_KERNEL"); unified = (e && e[0] == 'u') ? 1 : 0; }
-        if (unified) {
+        if (a_bound) {              // fp16x3 (role-split kernel; its two fp16 planes need 2/3 of the LDS)
+            static bool attr16 = false;
+            if (!attr16) {
+                hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                attr16 = true;
+            }
+            const int lds16 = 2 * 2 * 2 * 128 * PITCH6 * 2;
+            if (in_scale) hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<true, true>), dim3(grid), dim3(512), lds16, st, p);
+            else hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<false, true>), dim3(grid), dim3(512), lds16, st, p);
+        } else if (unified) {
             if (in_scale) hipLaunchKernelGGL(conv_wgrad_bf16x6u_kernel<true>, dim3(grid), dim3(256), lds, st, p);
             else hipLaunchKernelGGL(conv_wgrad_bf16x6u_kernel<false>, dim3(grid), dim3(256), lds, st, p);
-        } else if (in_scale) hipLaunchKernelGGL(conv_wgrad_bf16x6_kernel<true>, dim3(grid), dim3(512), lds, st, p);
-        else hipLaunchKernelGGL(conv_wgrad_bf16x6_kernel<false>, dim3(grid), dim3(512), lds, st, p);
+        } else if (in_scale) hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<true, false>), dim3(grid), dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<false, false>), dim3(grid), dim3(512), lds, st, p);
     } else if (in_scale)
         hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(256), 0, st, p);
     else

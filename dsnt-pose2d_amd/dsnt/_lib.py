@@ -70,6 +70,7 @@ SIGNATURES = {
     'dsnt_f16_prep_bn_bounds': [P, I, P],
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_bf16x6': [P, P, P, I, P, P, P, P, I, GP, P],
+    'dsnt_conv_wgrad_f16x3': [P, P, P, I, P, P, P, P, I, P, P, GP, P],
     'dsnt_wgrad_reduce_all': [P, I, I, P],
     'dsnt_conv_wgrad_group': [P, I, I, P],
     'dsnt_bn_stats': [P, P, L, I, P],
@@ -114,6 +115,7 @@ PLAIN = {
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
     'dsnt_conv_wgrad_desc_bytes': (I, []),
     'dsnt_conv_wgrad_desc': (I, [P, P, P, I, P, P, GP, P]),
+    'dsnt_conv_wgrad_desc_f16x3': (I, [P, P, P, I, P, P, P, P, GP, P]),
     'dsnt_debug_set_timeline': (I, [P, I]),
 }
 

@@ -184,6 +184,12 @@ class Tape:
         self._amax_used += 64
         return self._amax_buf[self._amax_used - 64:self._amax_used]
 
+    def f16_bn_bound_bwd(self, n):
+        """The same bound for a backward consumer.  The forward list computes it every step (emit_f16_prep) only if
+        some forward conv asked for it before the list was closed; rows added later would be lost."""
+        assert n.abound is not None, 'fp16x3 backward needs the BN bound its forward conv registered'
+        return n.abound
+
     def emit_f16_prep(self, pos):
         """Insert the fp16x3 preparation launches (weights, BN bounds) at position `pos` of the forward list."""
         saved, self.fwd = self.fwd, []
@@ -462,6 +468,8 @@ class Tape:
             y.stats = (part, tiles)
         r1 = res1.buf if res1 is not None else None
         r2 = res2.buf if res2 is not None else None
+        if self.use_f16x3 and self.training and normed:
+            self.f16_bn_bound(src)              # also for the weight gradient of convs whose forward is not fp16x3
         use16 = use6 and self.use_f16x3 and self.training and normed and p.wq16 is not None
         if use16:
             self.f16_weights(p)
@@ -498,13 +506,23 @@ class Tape:
                 # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
                 grouped = (w6 and normed and res1 is None and res2 is None and wl == cur and
                            0 < g.N * g.Ho * g.Wo <= self.group_rows)
+                # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
+                w16 = w6 and self.use_f16x3 and normed and y.grad_amax is not None
+                ab = self.f16_bn_bound_bwd(src) if w16 else None
                 if grouped:
                     desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
-                    nblk = self.lib.dsnt_conv_wgrad_desc(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
-                                                         _lib.ptr(gy), _lib.ptr(ws), C.byref(g), desc)
+                    if w16:
+                        nblk = self.lib.dsnt_conv_wgrad_desc_f16x3(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
+                                                                   _lib.ptr(gy), _lib.ptr(ws), _lib.ptr(ab),
+                                                                   _lib.ptr(y.grad_amax), C.byref(g), desc)
+                    else:
+                        nblk = self.lib.dsnt_conv_wgrad_desc(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
+                                                             _lib.ptr(gy), _lib.ptr(ws), C.byref(g), desc)
                     if nblk <= 0:
                         raise RuntimeError('dsnt_conv_wgrad_desc failed: %s' % self.lib.dsnt_last_error().decode())
                     self._pending_group.append((desc.raw, nblk))
+                elif w16:
+                    self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, 0, ab, y.grad_amax, g)
                 else:
                     self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
                            None, None, 0, g)

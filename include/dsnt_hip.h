@@ -234,6 +234,17 @@ int dsnt_conv_wgrad_desc(const float* x, const float* in_scale, const float* in_
                          const float* dy, float* ws, const dsnt_conv_geom* g, void* desc_out);
 int dsnt_conv_wgrad_group(const void* table, int nconv, int max_blocks, void* stream);
 
+/* fp16x3 weight gradient (two fp16 planes per operand, three MFMAs per product, scales from the 64-slot bounds
+ * a_bound >= max|act(x)| and g_bound >= max|dy|; the slabs are written already unscaled).  Same arguments otherwise as
+ * dsnt_conv_wgrad_bf16x6; dsnt_conv_wgrad_desc_f16x3 is the descriptor form for dsnt_conv_wgrad_group (descriptors of
+ * both kinds may share one table). */
+int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                          const float* dy, float* ws, float* dw, float* dbias, int accumulate,
+                          const float* a_bound, const float* g_bound, const dsnt_conv_geom* g, void* stream);
+int dsnt_conv_wgrad_desc_f16x3(const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                               const float* dy, float* ws, const float* a_bound, const float* g_bound,
+                               const dsnt_conv_geom* g, void* desc_out);
+
 /* ----------------------------------------------------- heat-map matching ("gauss" output strategy)
  * Rows = (image, joint) maps of h x w floats, target = normalised coordinates [rows][2].
  * dsnt_encode_heatmaps: /root/reference/src/dsnt/util.py:129-147 (encode_heatmaps) + :70-126 (draw_gaussian with
