@@ -79,23 +79,42 @@ def dominant_kernel_roofline(batch, iters=20):
     ms6 = timed(_lib.fn('dsnt_conv_fwd_bf16x6'), (ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y)) + common)
     ms32 = timed(_lib.fn('dsnt_conv_fwd'), (ptr(x), ptr(w), ptr(b), ptr(y)) + common)
     flops = 2.0 * M * (3 * 3 * 128) * 128
-    achieved = flops / (ms6 * 1e-3) / 1e12
     traffic = None
     tj = os.path.join(ROOT, 'profiles', 'traffic.json')
     if batch == 32 and os.path.exists(tj):      # PMC passes of this exact launch (profiles/)
         traffic = json.load(open(tj)).get('traffic_bytes_per_launch')
-    peak = PEAK_BF16_MFMA / 6.0
-    return {
-        'bound': 'mfma',
-        'kernel': 'conv3x3_bf16x6_kernel<2,true> 3x3 128->128 @64x64 B=%d' % batch,
+    f16 = os.environ.get('DSNT_SPLIT', 'f16x3') == 'f16x3' and os.environ.get('DSNT_MFMA', 'bf16x6') != 'f32'
+    twins = {'fp32_mfma_kernel': {'achieved': round(flops / (ms32 * 1e-3) / 1e12, 2), 'peak': PEAK_F32_MFMA,
+                                  'us_per_launch': round(ms32 * 1e3, 1)}}
+    if f16:
+        # the kernel the train step runs for this shape: fp16x3 (two fp16 planes, 3 MFMAs per product); the operand
+        # bounds are what the step's producers leave in device memory (weights: amax; activations: here the amax x 4)
+        planes16 = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+        wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+        assert _lib.fn('dsnt_amax')(ptr(w), w.numel(), ptr(wb), stream) == 0
+        assert _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(planes16), w.numel(), w.numel(), ptr(wb), stream) == 0
+        ab.fill_(float(torch.relu(x * sc + sh).max()) * 4.0)
+        ms16 = timed(_lib.fn('dsnt_conv_fwd_f16x3_ex'),
+                     (ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y)) + common + (None,))
+        achieved, peak, ms = flops / (ms16 * 1e-3) / 1e12, PEAK_BF16_MFMA / 3.0, ms16
+        twins['bf16x6_kernel'] = {'achieved': round(flops / (ms6 * 1e-3) / 1e12, 2), 'peak': round(PEAK_BF16_MFMA / 6.0, 1),
+                                  'us_per_launch': round(ms6 * 1e3, 1)}
+        kernel = 'conv3x3_bf16x6_kernel<2,true,F16> (fp16x3) 3x3 128->128 @64x64 B=%d' % batch
+        note = ('algorithmic fp32 FLOPs; peak = 2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per product '
+                '(= %.0f fp16 TFLOP/s executed)' % (3 * achieved))
+    else:
+        achieved, peak, ms = flops / (ms6 * 1e-3) / 1e12, PEAK_BF16_MFMA / 6.0, ms6
+        kernel = 'conv3x3_bf16x6_kernel<2,true> 3x3 128->128 @64x64 B=%d' % batch
+        note = ('algorithmic fp32 FLOPs; peak = 2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per product '
+                '(= %.0f bf16 TFLOP/s executed)' % (6 * achieved))
+    out = {
+        'bound': 'mfma', 'kernel': kernel,
         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-        'frac': round(achieved / peak, 4), 'traffic': traffic,
-        'peak_note': 'algorithmic fp32 FLOPs; peak = 2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per product '
-                     '(= %.0f bf16 TFLOP/s executed)' % (6 * achieved),
-        'flops_per_launch': flops, 'us_per_launch': round(ms6 * 1e3, 1),
-        'fp32_mfma_kernel': {'achieved': round(flops / (ms32 * 1e-3) / 1e12, 2), 'peak': PEAK_F32_MFMA,
-                             'us_per_launch': round(ms32 * 1e3, 1)},
+        'frac': round(achieved / peak, 4), 'traffic': traffic, 'peak_note': note,
+        'flops_per_launch': flops, 'us_per_launch': round(ms * 1e3, 1),
     }
+    out.update(twins)
+    return out
 
 
 def cpu_baseline(base, reg, batch=8, steps=2):
@@ -209,8 +228,10 @@ def main():
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'dtype_note': 'fp32 tensors and accumulation; large convolutions run as exact '
-                                          '3-way bf16 splits on the bf16 matrix cores (bf16x6), others on fp32 MFMA',
+            'dtype': 'f32', 'dtype_note': 'fp32 tensors and accumulation; large convolutions run as split-precision '
+                                          'products on the 16-bit matrix cores with fp32-GEMM-grade error: two fp16 planes '
+                                          'after a power-of-two scale + 3 MFMAs (fp16x3) where an operand bound exists, '
+                                          'three bf16 planes + 6 MFMAs (bf16x6) elsewhere; small ones on fp32 MFMA',
             'data': 'synthetic',
             'config': {'workload': '%s + DSNT%s, 256x256 -> %s, batch %d per GPU, RMSprop lr 2.5e-4, '
                                    'train step fwd+loss+bwd%s+optim'

@@ -114,10 +114,10 @@ class Tape:
         # max-pool / upsample+add write the BatchNorm statistics of their output themselves (DSNT_FUSE_OP_STATS=0:
         # a separate dsnt_bn_stats pass when a BatchNorm asks for them)
         self.fuse_op_stats = os.environ.get('DSNT_FUSE_OP_STATS', '1') != '0'
-        # fp16x3 (DSNT_SPLIT=f16x3): two fp16 planes + three MFMAs instead of three bf16 planes + six, where an operand
+        # fp16x3 (default; DSNT_SPLIT=bf16x6 turns it off): two fp16 planes + three MFMAs instead of three bf16 planes + six, where an operand
         # bound is available without a host round-trip: train-mode BN+ReLU operands (bound from the BN parameters) and
         # weights (amax in the per-step prep launch)
-        self.use_f16x3 = self.use_bf16x6 and os.environ.get('DSNT_SPLIT', 'bf16x6') == 'f16x3'
+        self.use_f16x3 = self.use_bf16x6 and os.environ.get('DSNT_SPLIT', 'f16x3') == 'f16x3'
         self._f16_w_rows, self._f16_w_seen = [], set()
         self._f16_bn_rows = []
         self._amax_buf, self._amax_used = None, 0      # zeroed at the start of every backward

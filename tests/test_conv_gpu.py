@@ -399,3 +399,95 @@ def test_grouped_wgrad_is_bit_identical():
     desc = C.create_string_buffer(nbytes)
     assert _lib.fn('dsnt_conv_wgrad_desc')(ptr(keep[0][0]), None, None, 0, ptr(keep[0][1]), ptr(keep[0][5]), C.byref(g), desc) < 0
     assert _lib.fn('dsnt_conv_wgrad_group')(None, 1, 8, None) != 0
+
+
+@pytest.mark.parametrize('case', BF16X6_CASES)
+@pytest.mark.parametrize('pro', [False, True])
+@pytest.mark.parametrize('loose', [1.0, 64.0])
+def test_conv_f16x3_matches_fp32_accuracy(case, pro, loose):
+    """fp16x3 (two fp16 planes after a power-of-two scale, three MFMAs): the same bars as bf16x6 — 2e-5 of the output
+    scale vs torch fp32 and an fp64 check that its error is of fp32 size — with the exact operand bound and with a
+    bound 64x too large (what the analytic BatchNorm bound typically is)."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    dev = torch.device('cuda:0')
+    tag = 'c' + '_'.join(map(str, case))
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=1)
+    w = synthetic.tensor(tag + 'w', (Cout, Cin, k, k), seed=1, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = synthetic.tensor(tag + 'b', (Cout,), seed=1, scale=0.1)
+    sc = synthetic.tensor(tag + 's', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'h', (Cin,), seed=1, scale=0.3)
+    g = _geom(N, H, W, Cin, Cout, k, k, stride, pad, dil)
+    act = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if pro else x
+    y32 = F.conv2d(act, w, b, stride=stride, padding=pad, dilation=dil)
+    y64 = F.conv2d(act.double(), w.double(), b.double(), stride=stride, padding=pad, dilation=dil)
+    res = synthetic.tensor(tag + 'r', tuple(y32.shape), seed=1)
+    xd = _nhwc(x).to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    call('dsnt_amax', ptr(wd), wd.numel(), ptr(wb))
+    assert wb.max().item() == wd.abs().max().item()
+    planes = torch.empty(2 * wd.numel(), dtype=torch.float16, device=dev)
+    call('dsnt_split_f16x2', ptr(wd), ptr(planes), wd.numel(), wd.numel(), ptr(wb))
+    # the two planes carry the scaled weights to ~2^-23 of the largest
+    import math
+    s_w = 2.0 ** (13 - math.floor(math.log2(wb.max().item())))
+    back = planes.view(2, -1).double().sum(0) / s_w
+    assert (back - wd.reshape(-1).double()).abs().max().item() <= 2.0 ** -22 * wd.abs().max().item()
+    ab[7] = act.abs().max().item() * loose            # any slot may hold the maximum
+    bd, scd, shd, resd = b.to(dev), sc.to(dev), sh.to(dev), _nhwc(res).to(dev)
+    y = torch.empty(N, g.Ho, g.Wo, Cout, device=dev)
+    M = N * g.Ho * g.Wo
+    stats = torch.zeros((M + 127) // 128, 2, Cout, device=dev)
+    call('dsnt_conv_fwd_f16x3_ex', ptr(xd), ptr(planes), wd.numel(), ptr(wb), ptr(ab), ptr(bd), ptr(y),
+         ptr(scd) if pro else None, ptr(shd) if pro else None, 1, ptr(resd), None, ptr(stats), C.byref(g), None)
+    got = y.cpu().permute(0, 3, 1, 2)
+    scale = y32.abs().max().item()
+    assert (got - (y32 + res)).abs().max().item() <= 2e-5 * scale
+    err16 = (got.double() - (y64 + res.double())).abs().max().item()
+    err32 = ((y32 + res).double() - (y64 + res.double())).abs().max().item()
+    assert err16 <= max(4 * err32, 2e-6 * scale), (err16, err32)
+    yd = (y32 + res).permute(0, 2, 3, 1).reshape(M, Cout).double()
+    s = stats.cpu().double().sum(0)
+    assert (s[0] - yd.sum(0)).abs().max().item() <= 1e-4 * max(1.0, yd.sum(0).abs().max().item())
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[3] % 4 == 0 and c[4] % 4 == 0])
+@pytest.mark.parametrize('pro', [False, True])
+def test_wgrad_f16x3(case, pro):
+    """fp16x3 weight gradient vs fp64, same bars as test_wgrad_bf16x6; gradient-sized dy (1e-4) so that the scale
+    matters; the bound of dy is found by dsnt_amax, the one of the A operand is 16x loose."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    N, H, W, Cin, Cout, k, stride, pad, dil = case
+    dev = torch.device('cuda:0')
+    tag = 'c' + '_'.join(map(str, case))
+    g = _geom(N, H, W, Cin, Cout, k, k, stride, pad, dil)
+    if not _lib.fn('dsnt_conv_wgrad_bf16x6_ok')(C.byref(g)):
+        pytest.skip('geometry not supported by the split-precision weight gradient (Wo % 4 != 0)')
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=1)
+    sc = synthetic.tensor(tag + 's', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'h', (Cin,), seed=1, scale=0.3)
+    act = (F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if pro else x).double()
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(act, w, b, stride=stride, padding=pad, dilation=dil)
+    gy = synthetic.tensor(tag + 'g', tuple(y.shape), seed=2) * 1e-4
+    y.backward(gy.double())
+    xd, gyd, scd, shd = _nhwc(x).to(dev), _nhwc(gy).to(dev), sc.to(dev), sh.to(dev)
+    ab, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ab.fill_(act.abs().max().item() * 16.0)
+    call('dsnt_amax', ptr(gyd), gyd.numel(), ptr(gb))
+    ws = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev)
+    dw16, dw32 = torch.empty(Cout, k, k, Cin, device=dev), torch.empty(Cout, k, k, Cin, device=dev)
+    db16, db32 = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+    args = (ptr(xd), ptr(scd) if pro else None, ptr(shd) if pro else None, 1, ptr(gyd), ptr(ws))
+    call('dsnt_conv_wgrad_f16x3', *args, ptr(dw16), ptr(db16), 0, ptr(ab), ptr(gb), C.byref(g))
+    call('dsnt_conv_wgrad', *args, ptr(dw32), ptr(db32), 0, C.byref(g))
+    ref = w.grad.permute(0, 2, 3, 1)
+    scale = ref.abs().max().item()
+    e16 = (dw16.cpu().double() - ref).abs().max().item()
+    e32 = (dw32.cpu().double() - ref).abs().max().item()
+    assert e16 <= 3e-5 * scale and e16 <= max(4 * e32, 2e-6 * scale), (e16, e32)
+    assert (db16.cpu().double() - b.grad).abs().max().item() <= 3e-5 * b.grad.abs().max().item()
