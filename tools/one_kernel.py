@@ -18,9 +18,19 @@ st = torch.cuda.current_stream().cuda_stream
 ws = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev); dw = torch.empty_like(w); db = torch.empty(Cout, device=dev)
 planes = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=dev)
 _lib.fn('dsnt_split_bf16x3')(ptr(w), ptr(planes), w.numel(), st)
+planes16 = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+wb, ab, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+_lib.fn('dsnt_amax')(ptr(w), w.numel(), ptr(wb), st)
+_lib.fn('dsnt_split_f16x2')(ptr(w), ptr(planes16), w.numel(), w.numel(), ptr(wb), st)
+_lib.fn('dsnt_amax')(ptr(gy), gy.numel(), ptr(gb), st)
+ab.fill_(float(torch.relu(x * sc + sh).max()) * 4.0)
 for _ in range(5):
     if which == 'fwd6':
         _lib.fn('dsnt_conv_fwd_bf16x6')(ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
+    elif which == 'fwd16':
+        _lib.fn('dsnt_conv_fwd_f16x3_ex')(ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None, st)
+    elif which == 'wgrad16':
+        _lib.fn('dsnt_conv_wgrad_f16x3')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g), st)
     elif which == 'wgrad6':
         _lib.fn('dsnt_conv_wgrad_bf16x6')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, C.byref(g), st)
     elif which == 'fwd':
