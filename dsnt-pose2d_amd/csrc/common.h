@@ -58,6 +58,21 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
         v[i] = s;
     }
 }
+// fp16x3 operand bounds: raise the 64-slot bound `amax` (see bound64 in conv.hip) to this 256-thread workgroup's
+// max |value|: wave shuffles, four LDS floats, ONE fire-and-forget integer atomic on the float bits per workgroup,
+// slot = workgroup index mod 64 (order-independent: the result is bit-reproducible).
+__device__ __forceinline__ void amax_commit(float am, unsigned* amax) {
+    __shared__ float amax_w[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0) amax_w[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nw; ++w) am = fmaxf(am, amax_w[w]);
+        if (am > 0.f) atomicMax(amax + (blockIdx.x & 63), __float_as_uint(am));
+    }
+}
 __device__ __forceinline__ float block_max(float v, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = blockDim.x >> 6;

@@ -347,18 +347,7 @@ __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const flo
         dx[i] = o;
         am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am);
     }
-    if (amax) {         // max |dx| for the fp16x3 consumers: integer max of non-negative float bits, order-independent
-        __shared__ float wmax[4];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            am = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-            // one fire-and-forget atomic per workgroup (no returned value to wait for)
-            if (am > 0.f) atomicMax(amax + (blockIdx.x & 63), __float_as_uint(am));      // 64 slots: see bound64 (conv.hip)
-        }
-    }
+    if (amax) amax_commit(am, amax);      // max |dx| for the fp16x3 consumers
 }
 
 static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* scale, const float* shift,
@@ -445,9 +434,10 @@ extern "C" int dsnt_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int N, 
 }
 
 __global__ void maxpool2_bwd_kernel(const float4* __restrict__ dy, const uchar4* __restrict__ idx,
-                                    float4* dx, int accumulate, int N, int H, int W, int C4) {
+                                    float4* dx, int accumulate, int N, int H, int W, int C4, unsigned* amax) {
     const int Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * Ho * Wo * C4;
+    float am = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(i % C4);
@@ -465,18 +455,30 @@ __global__ void maxpool2_bwd_kernel(const float4* __restrict__ dy, const uchar4*
                                    k.w == p ? g.w : 0.f);
             if (accumulate) { const float4 c = *q; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
             *q = o;
+            am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am);
         }
     }
+    if (amax) amax_commit(am, amax);
 }
 
+static int maxpool2_bwd_impl(const float* dy, const uint8_t* idx, float* dx, int accumulate, int N, int H, int W,
+                             int C, float* amax, void* stream);
 extern "C" int dsnt_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int accumulate,
                                  int N, int H, int W, int C, void* stream) {
+    return maxpool2_bwd_impl(dy, idx, dx, accumulate, N, H, W, C, nullptr, stream);
+}
+extern "C" int dsnt_maxpool2_bwd_amax(const float* dy, const uint8_t* idx, float* dx, int accumulate,
+                                      int N, int H, int W, int C, float* amax, void* stream) {
+    return maxpool2_bwd_impl(dy, idx, dx, accumulate, N, H, W, C, amax, stream);
+}
+static int maxpool2_bwd_impl(const float* dy, const uint8_t* idx, float* dx, int accumulate, int N, int H, int W,
+                             int C, float* amax, void* stream) {
     DSNT_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG, "dsnt_maxpool2_bwd: bad argument");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_bwd: H and W must be even");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dy) && dsnt_aligned16(dx), DSNT_ERR_ALIGN, "dsnt_maxpool2_bwd: alignment");
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, N, H, W, C / 4);
+                       (const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, N, H, W, C / 4, (unsigned*)amax);
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_bwd");
 }
 
@@ -509,9 +511,10 @@ extern "C" int dsnt_upsample2_add_fwd(const float* up, const float* low, float* 
 }
 
 __global__ void upsample2_bwd_kernel(const float4* __restrict__ dout, float4* dlow, int accumulate,
-                                     int N, int H, int W, int C4) {
+                                     int N, int H, int W, int C4, unsigned* amax) {
     const int Hl = H >> 1, Wl = W >> 1;
     const long total = (long)N * Hl * Wl * C4;
+    float am = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(i % C4);
@@ -525,22 +528,35 @@ __global__ void upsample2_bwd_kernel(const float4* __restrict__ dout, float4* dl
                                (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w));
         if (accumulate) { const float4 c = dlow[i]; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
         dlow[i] = o;
+        am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am);
     }
+    if (amax) amax_commit(am, amax);
 }
 
+static int upsample2_bwd_impl(const float* dout, float* dlow, int accumulate, int N, int H, int W, int C, float* amax,
+                              void* stream);
 extern "C" int dsnt_upsample2_bwd(const float* dout, float* dlow, int accumulate, int N, int H, int W,
                                   int C, void* stream) {
+    return upsample2_bwd_impl(dout, dlow, accumulate, N, H, W, C, nullptr, stream);
+}
+extern "C" int dsnt_upsample2_bwd_amax(const float* dout, float* dlow, int accumulate, int N, int H, int W,
+                                       int C, float* amax, void* stream) {
+    return upsample2_bwd_impl(dout, dlow, accumulate, N, H, W, C, amax, stream);
+}
+static int upsample2_bwd_impl(const float* dout, float* dlow, int accumulate, int N, int H, int W, int C, float* amax,
+                              void* stream) {
     DSNT_REQUIRE(dout && dlow && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG, "dsnt_upsample2_bwd: bad argument");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_upsample2_bwd: H and W must be even");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dout) && dsnt_aligned16(dlow), DSNT_ERR_ALIGN, "dsnt_upsample2_bwd: alignment");
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)dout, (float4*)dlow, accumulate, N, H, W, C / 4);
+                       (const float4*)dout, (float4*)dlow, accumulate, N, H, W, C / 4, (unsigned*)amax);
     DSNT_CHECK_LAUNCH("dsnt_upsample2_bwd");
 }
 
-__global__ void axpy_kernel(const float* __restrict__ x, float* y, float a, int accumulate, long n) {
+__global__ void axpy_kernel(const float* __restrict__ x, float* y, float a, int accumulate, long n, unsigned* amax) {
     const long n4 = n >> 2;
+    float am = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -550,18 +566,29 @@ __global__ void axpy_kernel(const float* __restrict__ x, float* y, float a, int 
             o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
         }
         reinterpret_cast<float4*>(y)[i] = o;
+        am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am);
     }
     for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long)gridDim.x * blockDim.x)
-        y[i] = accumulate ? y[i] + a * x[i] : a * x[i];
+         i += (long)gridDim.x * blockDim.x) {
+        const float o = accumulate ? y[i] + a * x[i] : a * x[i];
+        y[i] = o;
+        am = fmaxf(am, fabsf(o));
+    }
+    if (amax) amax_commit(am, amax);
 }
 
-extern "C" int dsnt_axpy(const float* x, float* y, float a, int accumulate, int64_t n, void* stream) {
+static int axpy_impl(const float* x, float* y, float a, int accumulate, int64_t n, float* amax, void* stream) {
     DSNT_REQUIRE(x && y && n > 0, DSNT_ERR_ARG, "dsnt_axpy: bad argument");
     DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(y), DSNT_ERR_ALIGN, "dsnt_axpy: alignment");
     hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
-                       a, accumulate, (long)n);
+                       a, accumulate, (long)n, (unsigned*)amax);
     DSNT_CHECK_LAUNCH("dsnt_axpy");
+}
+extern "C" int dsnt_axpy(const float* x, float* y, float a, int accumulate, int64_t n, void* stream) {
+    return axpy_impl(x, y, a, accumulate, n, nullptr, stream);
+}
+extern "C" int dsnt_axpy_amax(const float* x, float* y, float a, int accumulate, int64_t n, float* amax, void* stream) {
+    return axpy_impl(x, y, a, accumulate, n, amax, stream);
 }
 
 // ---------------------------------------------------------------- layout changes

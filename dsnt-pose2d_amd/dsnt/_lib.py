@@ -81,6 +81,9 @@ SIGNATURES = {
     'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
     'dsnt_bn_act_bwd_apply_amax': [P, P, P, P, P, P, P, I, P, I, L, I, P, P],
     'dsnt_fill_zero': [P, L, P],
+    'dsnt_axpy_amax': [P, P, F, I, L, P, P],
+    'dsnt_maxpool2_bwd_amax': [P, P, P, I, I, I, I, I, P, P],
+    'dsnt_upsample2_bwd_amax': [P, P, I, I, I, I, I, P, P],
     'dsnt_maxpool2_fwd': [P, P, P, I, I, I, I, P],
     'dsnt_maxpool2_bwd': [P, P, P, I, I, I, I, I, P],
     'dsnt_maxpool2_fwd_stats': [P, P, P, P, I, I, I, I, P],

@@ -121,6 +121,9 @@ class Tape:
         self._f16_w_rows, self._f16_w_seen = [], set()
         self._f16_bn_rows = []
         self._amax_buf, self._amax_used = None, 0      # zeroed at the start of every backward
+        # DSNT_AMAX_ALL=0: only single-writer BN-backward outputs get a bound (A/B switch); default: bounds follow the
+        # gradient through every writer that can report one (apply, axpy, pool / upsample backward) and through donations
+        self.amax_all = os.environ.get('DSNT_AMAX_ALL', '1') != '0'
         self._f16_dw_rows = []      # fp16x3 planes of the re-packed data-gradient weights
         self.dgrad_planes16, self.dgrad_bounds = None, None
 
@@ -179,7 +182,7 @@ class Tape:
 
     def amax_slot(self):
         if self._amax_buf is None:
-            self._amax_buf = self.empty(64 * 512)
+            self._amax_buf = self.empty(64 * 2048)
         assert self._amax_used + 64 <= self._amax_buf.numel()
         self._amax_used += 64
         return self._amax_buf[self._amax_used - 64:self._amax_used]
@@ -270,7 +273,7 @@ class Tape:
         if self.training:
             def join_grad():
                 if xb.grad is not None:
-                    self.grad_identity(x, xb.grad, donate=False)
+                    self.grad_identity(x, xb.grad, donate=False, g_amax=xb.grad_amax)
             self.on_backward(join_grad)        # registered first -> runs after the branch's backward
         return xb
 
@@ -374,22 +377,34 @@ class Tape:
             main.wait_stream(self.wgrad_stream)
 
     # ------------------------------------------------------------------ gradient plumbing
-    def grad_target(self, a):
-        """(buffer, accumulate flag) for a kernel about to write a's gradient."""
+    def grad_target(self, a, amax=False):
+        """(buffer, accumulate flag) for a kernel about to write a's gradient.  `amax`: the kernel leaves max|written|
+        in a.grad_amax (fp16x3 operand bound).  Every writer rewrites the whole tensor, so the slot stays a valid bound
+        while all writers since its creation report into it; a writer that cannot invalidates it."""
+        acc = 1
         if a.grad is None:
             a.grad = self.empty(a.N, a.H, a.W, a.C)
-            return a.grad, 0
-        a.grad_amax = None          # a second writer: the first one's maximum no longer bounds the tensor
-        return a.grad, 1
+            acc = 0
+        if self.use_f16x3 and amax and (self.amax_all or (amax == 'apply' and acc == 0)):
+            if a.grad_amax is None:
+                a.grad_amax = self.amax_slot()
+        else:
+            a.grad_amax = None
+        return a.grad, acc
 
-    def grad_identity(self, a, g, donate):
+    def grad_identity(self, a, g, donate, g_amax=None):
         """a.grad (+)= g.  With `donate`, g's buffer is handed over when a has no gradient yet
-        (the caller guarantees g is dead after its own launches).  Returns True if donated."""
+        (the caller guarantees g is dead after its own launches).  Returns True if donated.
+        g_amax: the bound slot of g, if it has one (it moves with a donated buffer)."""
         if a.grad is None and donate and not os.environ.get('DSNT_NO_DONATE'):
             a.grad = g
+            a.grad_amax = g_amax if self.amax_all else None
             return True
-        buf, acc = self.grad_target(a)
-        self.b('dsnt_axpy', g, buf, 1.0, acc, g.numel())
+        buf, acc = self.grad_target(a, amax=True)
+        if a.grad_amax is not None:
+            self.b('dsnt_axpy_amax', g, buf, 1.0, acc, g.numel(), a.grad_amax)
+        else:
+            self.b('dsnt_axpy', g, buf, 1.0, acc, g.numel())
         return False
 
     # ------------------------------------------------------------------ ops
@@ -441,9 +456,8 @@ class Tape:
         acc_p = 1 if bn.uses > 0 else 0
         bn.uses += 1
         self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef)
-        buf, acc = self.grad_target(x)
-        if self.use_f16x3 and acc == 0:
-            x.grad_amax = self.amax_slot()
+        buf, acc = self.grad_target(x, amax='apply')
+        if x.grad_amax is not None:
             self.b('dsnt_bn_act_bwd_apply_amax', da, x.buf, n.scale, n.shift, n.mean, n.invstd, coef, relu,
                    buf, acc, x.M, bn.C, x.grad_amax)
         else:
@@ -600,7 +614,7 @@ class Tape:
             donated = False
             for r in (res1, res2):
                 if r is not None:
-                    donated = self.grad_identity(r, gy, donate=not donated) or donated
+                    donated = self.grad_identity(r, gy, donate=not donated, g_amax=y.grad_amax) or donated
 
         self.on_backward(backward)
         return y
@@ -629,8 +643,11 @@ class Tape:
             self.f('dsnt_maxpool2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
         if self.training:
             def backward():
-                buf, acc = self.grad_target(x)
-                self.b('dsnt_maxpool2_bwd', y.grad, idx, buf, acc, x.N, x.H, x.W, x.C)
+                buf, acc = self.grad_target(x, amax=True)
+                if x.grad_amax is not None:
+                    self.b('dsnt_maxpool2_bwd_amax', y.grad, idx, buf, acc, x.N, x.H, x.W, x.C, x.grad_amax)
+                else:
+                    self.b('dsnt_maxpool2_bwd', y.grad, idx, buf, acc, x.N, x.H, x.W, x.C)
             self.on_backward(backward)
         return y
 
@@ -677,9 +694,12 @@ class Tape:
             self.f('dsnt_upsample2_add_fwd', up.buf, low.buf, out.buf, up.N, up.H, up.W, up.C)
         if self.training:
             def backward():
-                buf, acc = self.grad_target(low)
-                self.b('dsnt_upsample2_bwd', out.grad, buf, acc, up.N, up.H, up.W, up.C)
-                self.grad_identity(up, out.grad, donate=True)
+                buf, acc = self.grad_target(low, amax=True)
+                if low.grad_amax is not None:
+                    self.b('dsnt_upsample2_bwd_amax', out.grad, buf, acc, up.N, up.H, up.W, up.C, low.grad_amax)
+                else:
+                    self.b('dsnt_upsample2_bwd', out.grad, buf, acc, up.N, up.H, up.W, up.C)
+                self.grad_identity(up, out.grad, donate=True, g_amax=out.grad_amax)
             self.on_backward(backward)
         return out
 

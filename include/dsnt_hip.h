@@ -309,6 +309,14 @@ int dsnt_bn_act_bwd_apply_amax(const float* da, const float* x, const float* sca
                                const float* mean, const float* invstd, const float* coef, int relu, float* dx,
                                int accumulate, int64_t M, int C, float* amax, void* stream);
 int dsnt_fill_zero(float* p, int64_t n, void* stream);
+/* The other kernels that (re)write a whole gradient tensor, with the same amax side output: a tensor written by several
+ * of them in turn is bounded by the maximum over their amaxes (each rewrites all of it), so gradients accumulated along
+ * the residual stream keep a valid fp16x3 bound. */
+int dsnt_axpy_amax(const float* x, float* y, float a, int accumulate, int64_t n, float* amax, void* stream);
+int dsnt_maxpool2_bwd_amax(const float* dy, const uint8_t* idx, float* dx, int accumulate, int N, int H, int W, int C,
+                           float* amax, void* stream);
+int dsnt_upsample2_bwd_amax(const float* dout, float* dlow, int accumulate, int N, int H, int W, int C, float* amax,
+                            void* stream);
 
 /* F.max_pool2d(x, 2, stride=2) (hourglass.py:80,111,162): y [N][H/2][W/2][C],
  * idx = position (0..3) of the first maximum in scan order, for the backward. */
