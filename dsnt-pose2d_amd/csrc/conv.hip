@@ -1147,13 +1147,17 @@ extern "C" int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bia
 template <int TN, bool PRO, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
     constexpr int NPL = F16 ? 2 : 3;            // operand planes (fp16x3: two fp16 planes, three MFMAs)
+    // fp16x3: the two-plane halo is small enough to be DOUBLE-buffered (2 x 18 KB + 24 KB of weights < the 66 KB the
+    // epilogue's C tile needs anyway): the next chunk's halo is staged while this chunk's taps run, instead of in an
+    // extra barrier-bracketed stage between chunks (which, with half the MFMAs per tap, had become 10 % of the kernel)
+    constexpr int ABUF = F16 ? 2 : 1;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int WN = 2, TM = 2, BM = 128, BN = WN * TN * 32;
     constexpr int HWD = 18, HPP = 192;                 // halo row width; halo pixels (180) padded to 192
     constexpr int BROWS = BN * 2 / 256 >= 1 ? 3 : 3;   // three planes per loader thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* A6 = reinterpret_cast<__bf16*>(smem);          // [NPL][HPP][PITCH6]
-    __bf16* B6 = A6 + NPL * HPP * PITCH6;                  // [2][NPL][BN][PITCH6]
+    __bf16* A6 = reinterpret_cast<__bf16*>(smem);          // [ABUF][NPL][HPP][PITCH6]
+    __bf16* B6 = A6 + ABUF * NPL * HPP * PITCH6;           // [2][NPL][BN][PITCH6]
 
     int tile;
     xcd_remap(blockIdx.x, p.mtiles * p.ntiles, tile);
@@ -1223,7 +1227,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoffs[i], c * 64, 0);
         };
-        auto storeA = [&]() {
+        auto storeA = [&](int abuf) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 float4 v = make_float4(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y),
@@ -1238,7 +1242,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
                     v.z = __builtin_amdgcn_fmed3f(b.x, lo, hi); v.w = __builtin_amdgcn_fmed3f(b.y, lo, hi);
                 }
                 uint2 q1, q2, q3;
-                __bf16* dst = A6 + alds[i];
+                __bf16* dst = A6 + abuf * NPL * HPP * PITCH6 + alds[i];
                 if (F16) {
                     if (!PRO) { v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa; }
                     split4h(v, q1, q2);
@@ -1270,7 +1274,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
         gloadA(0);
         gloadB(0, 0, 0);
         gloadB(1, 0, 1);
-        storeA();
+        storeA(0);
         storeB(0, 0);
         gloadA(1);
         gloadB(0, 0, 2);
@@ -1281,9 +1285,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
                 // while the MFMA waves work on step j: stage step j+1, fetch step j+3
                 storeB((j + 1) & 1, (j + 1) & 1);
                 gloadB((j + 1) & 1, c2 + (j + 3) / 9, (j + 3) % 9);
-                if (j % 9 == 8) {
+                if (ABUF == 2) {
+                    if (j % 9 == 0) {                // the other halo buffer is free since the last barrier
+                        storeA(1 - (j / 9));
+                        gloadA(c2 + j / 9 + 2);
+                    }
+                } else if (j % 9 == 8) {
                     __syncthreads();                 // the MFMA waves hold the last fragments of this chunk
-                    storeA();
+                    storeA(0);
                     gloadA(c2 + j / 9 + 2);
                 }
                 __syncthreads();
@@ -1306,7 +1315,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
 #pragma unroll
             for (int j = 0; j < 18; ++j) {
                 const int t = j % 9, buf = j & 1;
-                const int toff = ((t / 3) * HWD + (t % 3)) * PITCH6;
+                const int toff = ((t / 3) * HWD + (t % 3)) * PITCH6 + (ABUF == 2 ? (j / 9) * NPL * HPP * PITCH6 : 0);
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
@@ -1316,7 +1325,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
                     for (int b = 0; b < TN; ++b)
                         F.b[b][pl] = *reinterpret_cast<const bf16x8*>(B6 + (buf * NPL + pl) * BN * PITCH6 + boff[b]);
                 }
-                if (t == 8) __syncthreads();         // fragments are in registers: the halo may be refilled
+                if (ABUF == 1 && t == 8) __syncthreads();   // fragments are in registers: the halo may be refilled
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -1332,7 +1341,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
 template <int TN, bool F16 = false>
 static void launch_conv3x3_6(const ConvP& p, bool pro, hipStream_t st) {
     constexpr int BN = 64 * TN, NPL = F16 ? 2 : 3;
-    size_t lds = (size_t)(NPL * 192 + 2 * NPL * BN) * PITCH6 * 2;
+    size_t lds = (size_t)((F16 ? 2 : 1) * NPL * 192 + 2 * NPL * BN) * PITCH6 * 2;
     const size_t epi = (size_t)128 * (BN + 4) * 4;
     if (epi > lds) lds = epi;
     static bool attr_done = false;
