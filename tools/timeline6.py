@@ -27,8 +27,17 @@ stats = torch.empty((M + 127) // 128, 2, Cout, device=dev)
 wq = torch.empty(3 * w.numel(), dtype=torch.int16, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 assert _lib.fn('dsnt_split_bf16x3')(ptr(w), ptr(wq), w.numel(), st) == 0
-fn = _lib.fn('dsnt_conv_fwd_bf16x6')
-args = (ptr(x), ptr(wq), w.numel(), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g))
+if os.environ.get('TL_F16'):      # fp16x3 form of the same kernel
+    wq16 = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+    wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    assert _lib.fn('dsnt_amax')(ptr(w), w.numel(), ptr(wb), st) == 0
+    assert _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(wq16), w.numel(), w.numel(), ptr(wb), st) == 0
+    ab.fill_(float(torch.relu(x * sc + sh).max()) * 4.0)
+    fn = _lib.fn('dsnt_conv_fwd_f16x3_ex')
+    args = (ptr(x), ptr(wq16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None)
+else:
+    fn = _lib.fn('dsnt_conv_fwd_bf16x6')
+    args = (ptr(x), ptr(wq), w.numel(), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g))
 for _ in range(3):
     assert fn(*args, st) == 0
 torch.cuda.synchronize()
