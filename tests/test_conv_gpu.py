@@ -491,3 +491,51 @@ def test_wgrad_f16x3(case, pro):
     e32 = (dw32.cpu().double() - ref).abs().max().item()
     assert e16 <= 3e-5 * scale and e16 <= max(4 * e32, 2e-6 * scale), (e16, e32)
     assert (db16.cpu().double() - b.grad).abs().max().item() <= 3e-5 * b.grad.abs().max().item()
+
+
+def test_f16x3_preparation_launches():
+    """The per-step table-driven launches of the fp16x3 path: weight planes + bounds of several tensors at once equal
+    the single-tensor entry points; the BatchNorm bound is max_c(|gamma_c| sqrt(M) + |beta_c|) in all 64 slots; the
+    gradient-tensor writers leave max|written| in their slot (spread over the 64 slots, order-independent)."""
+    import struct
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    dev = torch.device('cuda:0')
+    ws = [synthetic.tensor('prep.w%d' % i, (n,), seed=30 + i, scale=sc).to(dev)
+          for i, (n, sc) in enumerate([(128 * 9 * 128, 0.03), (256 * 128, 0.5), (64,  1e-4)])]
+    rows, outs, bounds = [], [], []
+    for w in ws:
+        planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+        bound = torch.zeros(64, device=dev)
+        rows.append([w.data_ptr(), planes.data_ptr(), bound.data_ptr(), w.numel(), w.numel()])
+        outs.append(planes); bounds.append(bound)
+    table = torch.tensor(rows, dtype=torch.int64).to(dev)
+    call('dsnt_f16_prep_weights', ptr(table), len(rows))
+    for w, planes, bound in zip(ws, outs, bounds):
+        assert bool((bound == w.abs().max()).all())
+        ref_b = torch.zeros(64, device=dev)
+        ref_p = torch.empty_like(planes)
+        call('dsnt_amax', ptr(w), w.numel(), ptr(ref_b))
+        call('dsnt_split_f16x2', ptr(w), ptr(ref_p), w.numel(), w.numel(), ptr(ref_b))
+        assert ref_b.max().item() == bound.max().item()
+        assert torch.equal(ref_p.view(torch.int16), planes.view(torch.int16))
+    gamma = synthetic.tensor('prep.g', (128,), seed=40).to(dev)
+    beta = synthetic.tensor('prep.b', (128,), seed=41).to(dev)
+    out = torch.zeros(64, device=dev)
+    sqrt_m = float(2048) ** 0.5
+    bits = struct.unpack('<I', struct.pack('<f', sqrt_m))[0]
+    t2 = torch.tensor([[gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), 128, bits]], dtype=torch.int64).to(dev)
+    call('dsnt_f16_prep_bn_bounds', ptr(t2), 1)
+    want = (gamma.abs() * torch.tensor(sqrt_m, device=dev) + beta.abs()).max()
+    assert bool(((out - want).abs() <= 1e-6 * want).all())
+    # writers with an amax side output
+    x = synthetic.tensor('prep.x', (2, 8, 8, 64), seed=42).to(dev)
+    y = synthetic.tensor('prep.y', (2, 8, 8, 64), seed=43).to(dev)
+    slot = torch.zeros(64, device=dev)
+    call('dsnt_axpy_amax', ptr(x), ptr(y), 1.0, 1, x.numel(), ptr(slot))
+    assert slot.max().item() == y.abs().max().item()
+    call('dsnt_fill_zero', ptr(slot), 64)
+    assert float(slot.abs().max()) == 0.0
+    low = torch.empty(2, 4, 4, 64, device=dev)
+    call('dsnt_upsample2_bwd_amax', ptr(x), ptr(low), 0, 2, 8, 8, 64, ptr(slot))
+    assert slot.max().item() == low.abs().max().item()
