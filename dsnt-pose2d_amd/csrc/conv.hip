@@ -2393,7 +2393,9 @@ static void wgrad_plan(const dsnt_conv_geom* g, int& ktiles, int& ntiles, int& s
     const int K = g->R * g->S * g->Cin;
     ktiles = (K + 127) / 128;
     ntiles = (g->Cout + 127) / 128;
-    long want = 512 / (ktiles * ntiles);      // ~2 workgroups per CU; more only inflates the slabs
+    static long target = -1;                  // DSNT_WGRAD_WGS: workgroups aimed at per launch (tuning switch)
+    if (target < 0) { const char* e = getenv("DSNT_WGRAD_WGS"); target = e ? atol(e) : 512; }
+    long want = target / (ktiles * ntiles);   // ~2 workgroups per CU; more only inflates the slabs
     if (want < 1) want = 1;
     long max_splits = (M + 255) / 256;         // at least 8 steps of 32 rows per split
     if (max_splits < 1) max_splits = 1;
