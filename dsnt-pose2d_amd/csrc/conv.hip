@@ -1906,7 +1906,9 @@ __device__ __forceinline__ void wgrad6_loader(const WgradP& p, __bf16* T, const 
             }
             row_ += adv_w; roh += adv_h;
             if (row_ >= p.Wo) { row_ -= p.Wo; roh += 1; }
-            while (roh >= p.Ho) { roh -= p.Ho; rn += 1; }
+            // 16 rows cross at most one image boundary when an image has >= 16 pixels (branch-free); tiny maps loop
+            if (HoWo >= 16) { const bool wrap = roh >= p.Ho; roh = wrap ? roh - p.Ho : roh; rn = wrap ? rn + 1 : rn; }
+            else while (roh >= p.Ho) { roh -= p.Ho; rn += 1; }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -2161,7 +2163,9 @@ __device__ __forceinline__ void wgrad6u_wave(const WgradP& p, __bf16* At, __bf16
             }
             row_ += adv_w; roh += adv_h;
             if (row_ >= p.Wo) { row_ -= p.Wo; roh += 1; }
-            while (roh >= p.Ho) { roh -= p.Ho; rn += 1; }
+            // 16 rows cross at most one image boundary when an image has >= 16 pixels (branch-free); tiny maps loop
+            if (HoWo >= 16) { const bool wrap = roh >= p.Ho; roh = wrap ? roh - p.Ho : roh; rn = wrap ? rn + 1 : rn; }
+            else while (roh >= p.Ho) { roh -= p.Ho; rn += 1; }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -1,4 +1,4 @@
-"""Time the bf16x6 weight-gradient kernel alone (slabs only, no reduction) on the hourglass shapes."""
+"""Time the bf16x6 and fp16x3 weight-gradient kernels alone (slabs only, no reduction) on the hourglass shapes."""
 import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,4 +24,9 @@ for (H, Cin, Cout, k) in shapes:
     ws = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev)
     flops = 2.0 * M * K * Cout
     t6 = timeit(_lib.fn('dsnt_conv_wgrad_bf16x6'), (ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, C.byref(g)))
-    print('H%3d %3d->%3d k%d | wgrad bf16x6 %7.1f us %6.1f TF-equiv (%.0f%% of 416.7)' % (H, Cin, Cout, k, t6 * 1e6, flops / t6 / 1e12, flops / t6 / 4.167e12))
+    ab, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ab.fill_(float(torch.relu(x * sc + sh).max()) * 4.0)
+    assert _lib.fn('dsnt_amax')(ptr(gy), gy.numel(), ptr(gb), torch.cuda.current_stream().cuda_stream) == 0
+    t16 = timeit(_lib.fn('dsnt_conv_wgrad_f16x3'), (ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g)))
+    print('H%3d %3d->%3d k%d | wgrad bf16x6 %7.1f us %6.1f TF-equiv (%.0f%% of 416.7) | fp16x3 %7.1f us %6.1f TF-equiv (%.0f%% of 833.3)' % (
+        H, Cin, Cout, k, t6 * 1e6, flops / t6 / 1e12, flops / t6 / 4.167e12, t16 * 1e6, flops / t16 / 1e12, flops / t16 / 8.333e12))
