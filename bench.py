@@ -79,10 +79,11 @@ def dominant_kernel_roofline(batch, iters=20):
     ms6 = timed(_lib.fn('dsnt_conv_fwd_bf16x6'), (ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y)) + common)
     ms32 = timed(_lib.fn('dsnt_conv_fwd'), (ptr(x), ptr(w), ptr(b), ptr(y)) + common)
     flops = 2.0 * M * (3 * 3 * 128) * 128
-    traffic = None
+    traffic, pmc = None, {}
     tj = os.path.join(ROOT, 'profiles', 'traffic.json')
     if batch == 32 and os.path.exists(tj):      # PMC passes of this exact launch (profiles/)
-        traffic = json.load(open(tj)).get('traffic_bytes_per_launch')
+        pmc = json.load(open(tj))
+        traffic = pmc.get('traffic_bytes_per_launch')
     f16 = os.environ.get('DSNT_SPLIT', 'f16x3') == 'f16x3' and os.environ.get('DSNT_MFMA', 'bf16x6') != 'f32'
     twins = {'fp32_mfma_kernel': {'achieved': round(flops / (ms32 * 1e-3) / 1e12, 2), 'peak': PEAK_F32_MFMA,
                                   'us_per_launch': round(ms32 * 1e3, 1)}}
@@ -113,6 +114,8 @@ def dominant_kernel_roofline(batch, iters=20):
         'frac': round(achieved / peak, 4), 'traffic': traffic, 'peak_note': note,
         'flops_per_launch': flops, 'us_per_launch': round(ms * 1e3, 1),
     }
+    if f16 and pmc.get('matrix_pipe_busy_frac') is not None:      # PMC passes of this launch (profiles/): SQ_VALU_MFMA_BUSY_CYCLES
+        out['matrix_pipe_busy_frac_pmc'] = pmc['matrix_pipe_busy_frac']
     out.update(twins)
     return out
 
