@@ -100,15 +100,36 @@ class Arena:
                     pv, gv = store, self.grads[o:o + n].view(p.shape)
                 p.data = pv
                 self.pviews[name], self.gviews[name] = pv, gv
+                if p.grad is not None:          # an arena rebuilt under live gradients keeps them (as its own views)
+                    gv.copy_(p.grad.to(device=device, dtype=torch.float32))
+                    p.grad = gv
         # running statistics: plain contiguous float buffers on the device
         for name, b in module.named_buffers():
             if b.dtype.is_floating_point and (b.device != device or b.dtype != torch.float32
                                               or not b.is_contiguous()):
                 b.data = b.detach().to(device=device, dtype=torch.float32).contiguous()
-        self.ptr_check = [(p, p.data_ptr()) for _, p, _, _ in slots[:1] + slots[-1:]]
+        self.ptr_all = [(p, p.data_ptr()) for _, p, _, _ in slots]
+        self.ptr_check = self.ptr_all[:1] + self.ptr_all[-1:]
+        self._pg = [(p, self.gviews[name]) for name, p, _, _ in slots]
+        self._by_name = {name: (p, o, n) for name, p, o, n in slots}
 
-    def valid(self):
-        return all(p.data_ptr() == ptr and p.device == self.device for p, ptr in self.ptr_check)
+    def valid(self, full=False):
+        """The parameters still live in this arena (first and last slot; `full`: every slot)."""
+        return all(p.data_ptr() == ptr and p.device == self.device
+                   for p, ptr in (self.ptr_all if full else self.ptr_check))
+
+    def logical(self, flat, name):
+        """View of parameter `name` inside any flat buffer laid out like the arena, in the parameter's logical
+        (OIHW) shape — optimiser state, gradients."""
+        p, o, n = self._by_name[name]
+        if p.dim() == 4:
+            O, I, R, S = p.shape
+            return flat[o:o + n].view(O, R, S, _ceil4(I)).permute(0, 3, 1, 2)[:, :I]
+        return flat[o:o + n].view(p.shape)
+
+    def grads_published(self):
+        """Every p.grad is this arena's own gradient view (what publish_grads leaves behind)."""
+        return all(p.grad is gv for p, gv in self._pg)
 
     def publish_grads(self, params):
         """Make p.grad reflect this backward (torch semantics: accumulate unless p.grad is None)."""
@@ -247,6 +268,7 @@ class Runner:
         self.arena = None
         self.programs = {}
         self.params = []
+        self._bns = None
         self.bucket_hook = None       # called with k when gradient bucket k is complete (DP)
         self.before_publish = None    # called after the backward list (DP: wait for all-reduce)
 
@@ -257,9 +279,10 @@ class Runner:
             self.params = [p for _, p, _, _ in self.arena.slots]
 
     def _bn_signature(self):
-        # momentum / eps are baked into the launch lists; re-trace if a caller changes them
-        return tuple((m.momentum, m.eps) for m in self.root.modules()
-                     if isinstance(m, nn.BatchNorm2d))[:4]
+        # momentum / eps of EVERY BatchNorm are baked into the launch lists; re-trace if a caller changes one
+        if self._bns is None:
+            self._bns = [m for m in self.root.modules() if isinstance(m, nn.BatchNorm2d)]
+        return tuple((m.momentum, m.eps) for m in self._bns)
 
     def __call__(self, x):
         if not x.is_cuda:
@@ -303,7 +326,9 @@ class TapeModule(nn.Module):
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         r = self.__dict__.get('_tape_runner')
-        if r is not None:
+        # a no-op .cuda() / .float() (inference.generate_predictions calls model.cuda() every time) keeps the
+        # arena and the traced programs; anything that really moved or retyped a parameter drops them
+        if r is not None and r.arena is not None and not r.arena.valid(full=True):
             r.arena = None
             r.programs = {}
         return out

@@ -3,8 +3,13 @@
 `RMSprop(lr=2.5e-4)` (torch defaults alpha=0.99, eps=1e-8) and `SGD(momentum=0.9)` as ONE
 kernel launch over the whole arena instead of one launch chain per parameter tensor (hg2 has 396
 tensors).  Both subclass `torch.optim.Optimizer`, so `param_groups` / lr schedulers /
-`zero_grad()` / `state_dict()` behave as callers expect.  If the gradients are not the arena's
-own views (someone replaced p.grad) they are gathered into the arena first.
+`zero_grad()` behave as callers expect, and `state_dict()` / `load_state_dict()` speak
+`torch.optim.RMSprop` / `torch.optim.SGD`'s own format (per-parameter `square_avg` / `momentum_buffer`
+in the logical OIHW shapes + `step`): the reference checkpoints `optimizer.state_dict()`
+(`bin/train.py:364,492`), and such a checkpoint loads into the stock optimiser and back.
+If the gradients are not the arena's own views (someone replaced p.grad) they are gathered into the
+arena first.  Parameters the arena does not hold (the `fc` strategy's `out_fc`) are updated tensor by
+tensor with the same arithmetic.
 """
 import torch
 
@@ -23,19 +28,23 @@ def _find_arena(model):
 
 
 class _FlatOptimizer(torch.optim.Optimizer):
+    STATE_KEY = None        # name of the per-parameter state tensor in torch's format
+
     def __init__(self, model, defaults):
         self.runner = _find_arena(model)
         arena = self.runner.arena
         arena_params = {id(p) for _, p, _, _ in arena.slots}
-        extra = [p for p in model.parameters() if id(p) not in arena_params]
-        if extra:
-            raise RuntimeError('dsnt.optim: %d parameters live outside the arena' % len(extra))
-        super().__init__([p for _, p, _, _ in arena.slots], defaults)
+        self.extra = [p for p in model.parameters() if id(p) not in arena_params]
+        super().__init__([p for _, p, _, _ in arena.slots] + self.extra, defaults)
         self.grad_scale = 1.0
         self._steps = 0
+        self.flat_state = torch.zeros_like(arena.params)
+        self.extra_state = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.extra]
 
     def _gather_grads(self):
         arena = self.runner.arena
+        if arena.grads_published():           # the common case: every p.grad is the arena's own view
+            return
         for name, p, o, n in arena.slots:
             gv = arena.gviews[name]
             if p.grad is None:
@@ -43,37 +52,133 @@ class _FlatOptimizer(torch.optim.Optimizer):
             elif p.grad.data_ptr() != gv.data_ptr():
                 gv.copy_(p.grad)
 
-    def zero_grad(self, set_to_none=True):
-        super().zero_grad(set_to_none=set_to_none)
+    # ------------------------------------------------------------------ torch-format state
+    def state_dict(self):
+        arena = self.runner.arena
+        n_arena = len(arena.slots)
+        step = torch.tensor(float(self._steps))
+        state = {}
+        if self._has_state():
+            for i, (name, p, o, n) in enumerate(arena.slots):
+                state[i] = self._entry(arena.logical(self.flat_state, name).clone(), step)
+            for j, s in enumerate(self.extra_state):
+                state[n_arena + j] = self._entry(s.clone(), step)
+        groups = []
+        for g in self.param_groups:
+            pg = {k: v for k, v in g.items() if k != 'params'}
+            pg['params'] = list(range(len(g['params'])))
+            groups.append(pg)
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, state_dict):
+        arena = self.runner.arena
+        n_arena = len(arena.slots)
+        groups = state_dict['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != n_arena + len(self.extra):
+            raise ValueError('dsnt.optim: loaded state dict has a different number of parameters')
+        for k, v in groups[0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
+        st = state_dict['state']
+        steps = 0
+        for i, (name, p, o, n) in enumerate(arena.slots):
+            e = st.get(i, st.get(str(i)))
+            dst = arena.logical(self.flat_state, name)
+            if e is None or e.get(self.STATE_KEY) is None:
+                dst.zero_()
+                continue
+            dst.copy_(e[self.STATE_KEY].to(dst.device, dst.dtype))
+            steps = max(steps, int(float(e.get('step', 1))))
+        for j, s in enumerate(self.extra_state):
+            e = st.get(n_arena + j, st.get(str(n_arena + j)))
+            if e is None or e.get(self.STATE_KEY) is None:
+                s.zero_()
+            else:
+                s.copy_(e[self.STATE_KEY].to(s.device, s.dtype))
+                steps = max(steps, int(float(e.get('step', 1))))
+        self._steps = steps
 
 
 class RMSprop(_FlatOptimizer):
+    STATE_KEY = 'square_avg'
+
     def __init__(self, model, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0):
-        super().__init__(model, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay))
-        self.square_avg = torch.zeros_like(self.runner.arena.params)
+        super().__init__(model, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay, momentum=0,
+                                     centered=False))
+
+    @property
+    def square_avg(self):
+        return self.flat_state
+
+    def _has_state(self):
+        return self._steps > 0
+
+    @staticmethod
+    def _entry(t, step):
+        return {'step': step.clone(), 'square_avg': t}
 
     @torch.no_grad()
     def step(self, closure=None):
         arena = self.runner.arena
         self._gather_grads()
         g = self.param_groups[0]
-        call('dsnt_rmsprop_step', ptr(arena.params), ptr(arena.grads), ptr(self.square_avg),
+        call('dsnt_rmsprop_step', ptr(arena.params), ptr(arena.grads), ptr(self.flat_state),
              arena.numel, float(g['lr']), float(g['alpha']), float(g['eps']),
              float(g['weight_decay']), float(self.grad_scale))
+        for p, sq in zip(self.extra, self.extra_state):      # torch.optim.RMSprop's arithmetic, tensor by tensor
+            if p.grad is None:
+                continue
+            gr = p.grad * self.grad_scale
+            if g['weight_decay'] != 0:
+                gr = gr.add(p, alpha=g['weight_decay'])
+            sq.mul_(g['alpha']).addcmul_(gr, gr, value=1 - g['alpha'])
+            p.addcdiv_(gr, sq.sqrt().add_(g['eps']), value=-g['lr'])
         self._steps += 1
 
 
 class SGD(_FlatOptimizer):
+    STATE_KEY = 'momentum_buffer'
+
     def __init__(self, model, lr=1e-3, momentum=0.0, weight_decay=0.0):
-        super().__init__(model, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
-        self.momentum_buf = torch.zeros_like(self.runner.arena.params)
+        super().__init__(model, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, dampening=0,
+                                     nesterov=False))
+
+    @property
+    def momentum_buf(self):
+        return self.flat_state
+
+    def _has_state(self):
+        return self._steps > 0 and self.param_groups[0]['momentum'] != 0
+
+    @staticmethod
+    def _entry(t, step):
+        return {'momentum_buffer': t}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # torch's SGD keeps no step count: a loaded momentum buffer means "not the first step"
+        self._steps = 1 if any(e.get('momentum_buffer') is not None for e in state_dict['state'].values()) else 0
 
     @torch.no_grad()
     def step(self, closure=None):
         arena = self.runner.arena
         self._gather_grads()
         g = self.param_groups[0]
-        call('dsnt_sgd_step', ptr(arena.params), ptr(arena.grads), ptr(self.momentum_buf),
+        first = 1 if self._steps == 0 else 0
+        call('dsnt_sgd_step', ptr(arena.params), ptr(arena.grads), ptr(self.flat_state),
              arena.numel, float(g['lr']), float(g['momentum']), float(g['weight_decay']),
-             float(self.grad_scale), 1 if self._steps == 0 else 0)
+             float(self.grad_scale), first)
+        for p, buf in zip(self.extra, self.extra_state):
+            if p.grad is None:
+                continue
+            gr = p.grad * self.grad_scale
+            if g['weight_decay'] != 0:
+                gr = gr.add(p, alpha=g['weight_decay'])
+            if g['momentum'] != 0:
+                if first:
+                    buf.copy_(gr)
+                else:
+                    buf.mul_(g['momentum']).add_(gr)
+                gr = buf
+            p.add_(gr, alpha=-g['lr'])
         self._steps += 1

@@ -11,7 +11,18 @@ backward list carries a marker after the last launch that writes into each bucke
 all-reduce of bucket k is enqueued (async, on RCCL's own stream) while the backward kernels of
 bucket k-1 are still being launched — communication overlaps the rest of backward.  xGMI is
 point-to-point (7 links x ~153 GB/s); hg2's 27 MB of gradients are ~0.3 ms of ring time, so a
-handful of large buckets is the right granularity.
+handful of large buckets is the right granularity.  A bucket whose marker never fired (a
+backbone traced without markers) is reduced before the gradients are published, so no model can
+silently step on its local gradient.
+
+Parameters outside the arena (the `fc` output strategy's `out_fc`) are broadcast at attach time
+and their gradients averaged by a post-accumulate hook.
+
+BatchNorm running statistics: every rank keeps the running statistics of
+its own shard; they are buffers, not gradients, and are never exchanged during training.  A
+checkpoint takes RANK 0's (what `model.state_dict()` returns there — the reference's
+`train.py:488-496` saves from its single process), or, after `sync_running_stats()`, the mean
+over ranks (mean of running means / running variances; `num_batches_tracked` is identical).
 
 Works with any `torch.distributed` backend: "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests
 (which exercise this host logic on flat CPU tensors).
@@ -28,9 +39,16 @@ class GradientAllReducer:
         self.bounds = list(bounds)          # [(start, end)] element ranges, one per bucket
         self.group = group
         self.pending = []
+        self.fired = set()                  # buckets enqueued since the last wait()
+        self.last_late = []                 # buckets of the last backward that no marker announced (diagnostic)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
-    def bucket_ready(self, k):
+    def bucket_ready(self, k, late=False):
+        if k in self.fired:
+            return
+        self.fired.add(k)
+        if late:
+            self.last_late.append(k)
         if self.world == 1:
             return
         s, e = self.bounds[k]
@@ -38,14 +56,18 @@ class GradientAllReducer:
             self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
                                                 group=self.group, async_op=True))
 
-    def reduce_all(self):
+    def reduce_all(self, late=False):
         for k in range(len(self.bounds)):
-            self.bucket_ready(k)
+            self.bucket_ready(k, late)
 
     def wait(self):
+        """Every bucket is reduced when this returns: the ones no marker announced are enqueued here."""
+        self.last_late = []
+        self.reduce_all(late=True)
         for w in self.pending:
             w.wait()
         self.pending = []
+        self.fired = set()
 
 
 def broadcast_flat(flat, src=0, group=None):
@@ -60,6 +82,7 @@ class DataParallel:
 
     def __init__(self, model, optimizer=None, group=None):
         from .optim import _find_arena
+        self.model = model
         self.runner = _find_arena(model)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -73,12 +96,46 @@ class DataParallel:
         self.runner.before_publish = self.reducer.wait
         # gradients are published as the MEAN over ranks (works with any optimiser)
         arena.publish_scale = 1.0 / self.world
+        # parameters the arena does not hold: same start on every rank, mean gradient after every backward
+        in_arena = {id(p) for _, p, _, _ in arena.slots}
+        self.extra = [p for p in model.parameters() if id(p) not in in_arena]
+        self._hooks = []
+        for p in self.extra:
+            broadcast_flat(p.data, 0, group)
+            if p.requires_grad:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._average_extra))
+
+    def _average_extra(self, p):
+        # earlier (already averaged, rank-identical) contributions in p.grad are a fixed point of the mean
+        if self.world > 1:
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+            p.grad.div_(self.world)
+
+    def detach(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.runner.bucket_hook = None
+        self.runner.before_publish = None
+        self.runner.arena.publish_scale = 1.0
+
+    def sync_running_stats(self):
+        """Replace every rank's BatchNorm running statistics by their mean over ranks (checkpoint time)."""
+        if self.world == 1:
+            return
+        for name, b in self.model.named_buffers():
+            if b.dtype.is_floating_point:
+                dist.all_reduce(b.data, op=dist.ReduceOp.SUM, group=self.group)
+                b.data.div_(self.world)
 
     def shard(self, *tensors):
         """This rank's contiguous slice of a global batch (dim 0)."""
         rank = dist.get_rank(self.group) if dist.is_initialized() else 0
         out = []
         for t in tensors:
+            if t.shape[0] % self.world != 0:
+                raise ValueError('dsnt.parallel: global batch %d is not divisible by the world size %d '
+                                 '(the tail would never be trained on)' % (t.shape[0], self.world))
             per = t.shape[0] // self.world
             out.append(t[rank * per:(rank + 1) * per])
         return out if len(out) > 1 else out[0]

@@ -108,3 +108,70 @@ def test_bearpaw_checkpoint_repack_flow():
     assert list(out.keys()) == ['hg.' + k for k in donor.state_dict().keys()]
     for k, v in donor.state_dict().items():
         assert torch.equal(out['hg.' + k].cpu(), v), k
+
+
+def test_optimizer_state_dict_is_torch_format():
+    """`optimizer.state_dict()` is what the reference checkpoints (bin/train.py:364,492): it must carry the flat
+    second moments / momentum buffers, in torch.optim's own per-parameter format, and load back."""
+    from dsnt import optim
+    m = build_mpii_pose_model(base='hg1', output_strat='fc')
+    synthetic.fill_state_dict(m, seed=1)
+    m.hg._runner().ensure(torch.device('cpu'))
+    arena = m.hg.arena
+    for cls, stock, key in ((optim.RMSprop, torch.optim.RMSprop, 'square_avg'),
+                            (optim.SGD, torch.optim.SGD, 'momentum_buffer')):
+        kw = dict(lr=2.5e-4) if cls is optim.RMSprop else dict(lr=0.2, momentum=0.9)
+        opt = cls(m, **kw)
+        assert opt.state_dict()['state'] == {}                        # nothing before the first step
+        opt._steps = 3
+        opt.flat_state.copy_(torch.rand(arena.numel))
+        for s in opt.extra_state:
+            s.copy_(torch.rand_like(s))
+        assert len(opt.extra) == 2                                    # out_fc lives outside the arena
+        sd = opt.state_dict()
+        params = [p for _, p, _, _ in arena.slots] + opt.extra
+        assert len(sd['state']) == len(params) and sd['param_groups'][0]['params'] == list(range(len(params)))
+        # the stock optimiser over the same parameters accepts it ...
+        ref = stock(params, **kw)
+        ref.load_state_dict(sd)
+        for i, p in enumerate(params):
+            assert ref.state[p][key].shape == p.shape
+            assert torch.equal(ref.state[p][key], sd['state'][i][key])
+        w = 'layer1.0.conv2.weight'
+        i = [n for n, _, _, _ in arena.slots].index(w)
+        O, I, R, S = params[i].shape
+        o = arena.slots[i][2]
+        assert torch.equal(sd['state'][i][key], opt.flat_state[o:o + O * I * R * S].view(O, R, S, I).permute(0, 3, 1, 2))
+        # ... and its own state_dict loads back bit-exactly into a fresh flat optimiser
+        opt2 = cls(m, **kw)
+        opt2.load_state_dict(ref.state_dict())
+        # (the stem's channel padding and the 16-byte slot alignment are not parameters: compare the logical views)
+        assert all(torch.equal(arena.logical(opt2.flat_state, n), arena.logical(opt.flat_state, n))
+                   for n, _, _, _ in arena.slots) and opt2._steps >= 1
+        assert all(torch.equal(a, b) for a, b in zip(opt2.extra_state, opt.extra_state))
+        if cls is optim.RMSprop:
+            assert opt2._steps == 3 and opt2.param_groups[0]['lr'] == 2.5e-4
+
+
+def test_arena_survives_noop_apply_and_keeps_gradients():
+    m = build_mpii_pose_model(base='hg1', output_strat='dsnt')
+    r = m.hg._runner()
+    r.ensure(torch.device('cpu'))
+    arena = r.arena
+    r.programs['sentinel'] = object()
+    m.float()
+    m.to('cpu')
+    assert r.arena is arena and 'sentinel' in r.programs             # nothing moved: nothing dropped
+    p = dict(m.hg.named_parameters())['conv1.weight']
+    p.grad = torch.ones_like(p)
+    m.double()                                                        # a real change re-builds on the next use
+    assert r.arena is None and r.programs == {}
+    r.ensure(torch.device('cpu'))
+    assert r.arena is not arena and p.dtype == torch.float32
+    assert p.grad is r.arena.gviews['conv1.weight'] and float(p.grad.sum()) == p.numel()
+    # every BatchNorm's (momentum, eps) is part of the program key
+    sig = r._bn_signature()
+    bns = [x for x in m.hg.modules() if isinstance(x, torch.nn.BatchNorm2d)]
+    assert len(sig) == len(bns) == 53
+    bns[-1].momentum = 0.5
+    assert r._bn_signature() != sig

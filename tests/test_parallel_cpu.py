@@ -78,6 +78,75 @@ def test_bucketed_allreduce_world2():
     assert all(r[1] and r[2] and r[3] for r in results), results
 
 
+def _dp_worker(rank, world, port, q):
+    """DataParallel attached to real (CPU-resident) model arenas: markers that never fire, parameters outside
+    the arena, weight broadcast, shard()."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from dsnt import parallel, synthetic
+        from dsnt.model import build_mpii_pose_model
+        res = {}
+        for base, strat in (('hg2', 'fc'), ('resnet18', 'dsnt')):
+            m = build_mpii_pose_model(base=base, output_strat=strat)
+            synthetic.fill_state_dict(m, seed=rank)                 # ranks start from DIFFERENT weights
+            runner = (m.hg if hasattr(m, 'hg') else m)._runner()
+            runner.ensure(torch.device('cpu'))
+            arena = runner.arena
+            dp = parallel.DataParallel(m)
+            ref = build_mpii_pose_model(base=base, output_strat=strat)
+            synthetic.fill_state_dict(ref, seed=0)
+            same = all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), ref.state_dict().values()))
+            # a backward whose list announces only the LAST bucket (or none at all, as ResNet models did):
+            arena.fresh.copy_(torch.arange(arena.numel, dtype=torch.float32) % 97 * (rank + 1))
+            nb = len(arena.bucket_bounds)
+            if nb > 1:
+                runner.bucket_hook(nb - 1)
+            runner.before_publish()
+            want = torch.arange(arena.numel, dtype=torch.float32) % 97 * sum(r + 1 for r in range(world))
+            late = list(dp.reducer.last_late)
+            ok_sum = torch.equal(arena.fresh, want) and arena.publish_scale == 1.0 / world
+            # parameters outside the arena get the mean gradient from the hook
+            ok_extra = True
+            if dp.extra:
+                inp = torch.ones(3, m.out_fc.in_features)
+                (m.out_fc(inp).sum() * (rank + 1)).backward()
+                mean = sum(r + 1 for r in range(world)) / world
+                ok_extra = bool(torch.allclose(m.out_fc.weight.grad, torch.full_like(m.out_fc.weight, 3.0 * mean)) and
+                                torch.allclose(m.out_fc.bias.grad, torch.full_like(m.out_fc.bias, 3.0 * mean)))
+            res[base] = (same, ok_sum, late, len(dp.extra), ok_extra, nb)
+        x = torch.arange(8.0).view(8, 1)
+        shard_ok = torch.equal(dp.shard(x), x[rank * 4:(rank + 1) * 4])
+        try:
+            dp.shard(torch.zeros(7, 1))
+            shard_ok = False
+        except ValueError:
+            pass
+        q.put((rank, res, shard_ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dataparallel_host_logic_world2():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res, shard_ok in results:
+        assert shard_ok
+        same, ok_sum, late, n_extra, ok_extra, nb = res['hg2']
+        assert same and ok_sum and ok_extra and n_extra == 2 and nb == 3 and late == [0, 1], res
+        same, ok_sum, late, n_extra, ok_extra, nb = res['resnet18']
+        assert same and ok_sum and n_extra == 0 and nb == 1 and late == [0], res
+
+
 def test_single_process_is_a_noop():
     from dsnt import parallel
     flat = torch.ones(10)
