@@ -6,15 +6,22 @@ forward -> forward_loss -> zero_grad -> backward (-> gradient all-reduce) -> opt
 on synthetic 256x256x3 crops already resident in HBM, 16 joints, 64x64 heat-maps.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg2_js|hg1|hg8_js|resnet34] [--batch B]
+                  [--global-batch G]
 
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
-(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.  Scaling is weak: the per-GPU batch is
-fixed (32; hg8: 16) as N grows.  Besides the whole-job throughput the line carries
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.  Default scaling is weak: the per-GPU batch is
+fixed (32; hg8: 16) as N grows.  `--global-batch G` fixes the TOTAL batch instead (per-GPU batch G / N,
+"scaling": "strong") — north_star quotes efficiency at global batch 256: `--global-batch 256` at N = 1 and 8.
+Besides the whole-job throughput the line carries
   roofline     — the dominant kernel (3x3 128->128 implicit-GEMM conv at 64x64, the shape that
                  holds ~half of the backbone FLOPs) timed live with HIP events on its stream:
                  algorithmic FLOPs / launch time vs the 157.3 TFLOP/s fp32-MFMA peak;
   cpu_baseline — the CPU oracle (plain PyTorch ops, proven equal to the reference) timed on this
-                 node's host cores on a bounded sample of the same workload (rank 0, N = 1).
+                 node's host cores on a bounded sample of the same workload (rank 0, N = 1): thread-count
+                 sweep, then 2 warm-up + 5 timed steps at the best count;
+  parity       — max |dcoord| and PCKh@0.5 of the HIP path vs the CPU oracle on a small fixed batch with
+                 the weights the timed steps ended on (outside the timed region);
+  head_roofline — the DSNT head kernels alone on a B = 1024 batch: achieved HBM GB/s.
 """
 import argparse
 import ctypes as C
@@ -113,6 +120,9 @@ def dominant_kernel_roofline(batch, iters=20):
         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4), 'traffic': traffic, 'peak_note': note,
         'flops_per_launch': flops, 'us_per_launch': round(ms * 1e3, 1),
+        # achieved / us_per_launch are measured in THIS run (HIP events); traffic and the matrix-pipe figure are
+        # NOT: they are copied from the committed rocprofv3 PMC passes of this launch
+        'traffic_source': ('profiles/traffic.json <- ' + str(pmc.get('source'))) if traffic is not None else None,
     }
     if f16 and pmc.get('matrix_pipe_busy_frac') is not None:      # PMC passes of this launch (profiles/): SQ_VALU_MFMA_BUSY_CYCLES
         out['matrix_pipe_busy_frac_pmc'] = pmc['matrix_pipe_busy_frac']
@@ -120,30 +130,145 @@ def dominant_kernel_roofline(batch, iters=20):
     return out
 
 
-def cpu_baseline(base, reg, batch=8, steps=2):
-    """The CPU oracle on the same workload at a bounded batch (images/sec on the host cores)."""
+def _host_cpus():
+    """(usable logical CPUs, physical cores among them, model string) of this process's CPU share."""
+    usable = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
+    try:                                     # cgroup v2 quota (a GPU box hands out a share of the node)
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            usable = usable[:max(1, int(float(q) / float(per)))]
+    except (OSError, ValueError):
+        pass
+    model, cores = 'unknown', set()
+    try:
+        cpu, phys, core = None, 0, None
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'processor':
+                cpu = int(v)
+            elif k == 'model name':
+                model = v
+            elif k == 'physical id':
+                phys = int(v)
+            elif k == 'core id':
+                core = int(v)
+            elif not k and cpu is not None:
+                if cpu in usable:
+                    cores.add((phys, core if core is not None else cpu))
+                cpu, core = None, None
+    except OSError:
+        pass
+    return len(usable), (len(cores) or len(usable)), model
+
+
+def cpu_baseline(base, reg, batch=8, timed=5, warm=2):
+    """The CPU oracle on the same workload at a bounded batch (images/sec on the host cores).  BASELINE.md §3:
+    physical-core count and CPU model stated, 2 warm-up + >= 5 timed steps, median; the thread count is swept first
+    (1 warm-up + 1 timed step each) because an oversubscribed intra-op pool is several times slower."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     from dsnt_oracle import model as omodel
     from dsnt import synthetic
-    cores = torch.get_num_threads()
+    logical, physical, cpu_model = _host_cpus()
     m = omodel.build_mpii_pose_model(base=base, output_strat='dsnt', reg=reg)
     synthetic.fill_state_dict(m, seed=0)
     m.train()
     opt = torch.optim.RMSprop(m.parameters(), lr=2.5e-4)
     x, t, k = synthetic.batch(batch, size=256, seed=1)
-    times = []
-    for i in range(steps + 1):
+
+    def step():
         t0 = time.perf_counter()
         out = m(x)
         loss = m.forward_loss(out, t, k)
         opt.zero_grad()
         loss.backward()
         opt.step()
-        times.append(time.perf_counter() - t0)
-    best = sorted(times[1:])[len(times[1:]) // 2]
-    return {'value': round(batch / best, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%s+dsnt reg=%s, batch %d, 256x256, %d timed steps after 1 warm-up (median), '
-                      'torch %s CPU ops' % (base, reg, batch, steps, torch.__version__)}
+        return time.perf_counter() - t0
+
+    saved = torch.get_num_threads()
+    cands = sorted({n for n in (8, 16, 32, 64, physical, logical) if 1 <= n <= logical})
+    sweep = {}
+    for n in cands:
+        torch.set_num_threads(n)
+        step()
+        sweep[n] = step()
+    best_n = min(sweep, key=sweep.get)
+    torch.set_num_threads(best_n)
+    for _ in range(warm):
+        step()
+    times = sorted(step() for _ in range(timed))
+    torch.set_num_threads(saved)
+    med = times[len(times) // 2]
+    return {'value': round(batch / med, 3), 'unit': 'images/sec', 'cores': best_n, 'kind': 'port',
+            'physical_cores': physical, 'logical_cpus': logical, 'cpu_model': cpu_model,
+            'thread_sweep_images_per_sec': {str(n): round(batch / v, 3) for n, v in sweep.items()},
+            'sample': '%s+dsnt reg=%s, batch %d, 256x256, RMSprop train step; thread sweep %s (1 warm-up + 1 timed '
+                      'each), then %d warm-up + %d timed steps at %d threads (median); torch %s CPU ops'
+                      % (base, reg, batch, cands, warm, timed, best_n, torch.__version__)}
+
+
+def parity_vs_oracle(model, base, reg, batch=4):
+    """max |dcoord| and PCKh@0.5 of the HIP path vs the CPU oracle: the weights the timed steps ended on, one fixed
+    batch, train-mode forward (the path being timed), outside the timed region (SURVEY.md 8(d) "Metric")."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    from dsnt_oracle import model as omodel
+    from dsnt_oracle.evaluator import PCKhEvaluator as OracleEval
+    from dsnt import synthetic
+    from dsnt.evaluator import PCKhEvaluator
+    o = omodel.build_mpii_pose_model(base=base, output_strat='dsnt', reg=reg)
+    o.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    o.train()
+    size = 256
+    x, t, k = synthetic.batch(batch, size=size, seed=5, mask_p=0.9)
+    dev = next(model.parameters()).device
+    with torch.no_grad():
+        got = model.compute_coords(model(x.to(dev)))
+        want = o.compute_coords(o(x))
+    head, tm, tb = synthetic.pckh_inputs(batch)
+    ev = PCKhEvaluator()
+    ev.add_normalized(got.to(dev), t, k, head, tm, tb)
+    oe = OracleEval()
+    pred = torch.baddbmm(tb.double(), want.double(), tm.double())
+    targ = torch.baddbmm(tb.double(), t.double(), tm.double())
+    oe.add(pred, targ, k, head)
+    a, b = ev.meters['all'].value()[0], oe.meters['all'].value()[0]
+    return {'max_abs_dcoord': float((got - want).abs().max()), 'bar': 1e-4,
+            'pckh_hip': round(a, 6), 'pckh_cpu_oracle': round(b, 6), 'pckh_equal': bool(a == b),
+            'sample': 'batch %d, %dx%d, train-mode forward, weights after the timed steps' % (batch, size, size)}
+
+
+def head_roofline(batch=1024, iters=10):
+    """The DSNT head alone (softmax + expectation + Euclidean + JS, forward and backward) on a large batch:
+    algorithmic HBM bytes = 4 passes x rows x 64 x 64 x 4 B (read logits, write heat-maps, read heat-maps, write
+    d logits: SURVEY.md 8(d)) over the HIP-event time of the launches of one stack's head."""
+    import dsnt.nn as dn
+    dev = torch.device('cuda', torch.cuda.current_device())
+    rows = batch * 16
+    logits = torch.randn(batch, 16, 64, 64, device=dev) * 3
+    target = torch.rand(batch, 16, 2, device=dev) * 2 - 1
+    mask = torch.ones(batch, 16, device=dev)
+
+    def once():
+        lg = logits.requires_grad_()
+        hm, coords = dn.head_forward(lg)
+        loss = dn.head_loss(lg, hm.detach(), coords.detach(), target, mask, 'js', 2.0 / 64, 1.0)
+        loss.backward()
+        lg.grad = None
+    for _ in range(2):
+        once()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = 4.0 * rows * 64 * 64 * 4
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernels': 'head_fwd + head_loss_rows + head_bwd (+ masked averages)', 'batch': batch,
+            'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
+            'frac_of_measured_copy_peak_6290': round(gbs / 6290.0, 4), 'algorithmic_bytes': nbytes,
+            'ms_fwd_loss_bwd': round(ms, 4)}
 
 
 def main():
@@ -153,7 +278,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='hg2_js', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the workload\'s)')
+    ap.add_argument('--global-batch', type=int, default=None,
+                    help='strong scaling: total batch over all GPUs (per-GPU batch = this / N)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the parity / head / dominant-kernel legs (profiling)')
     ap.add_argument('--force-dp', action='store_true', help='wire the data-parallel hooks even at world size 1 (testing)')
     args = ap.parse_args()
 
@@ -177,6 +305,10 @@ def main():
     base, reg, batch, gflop = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit('--global-batch %d is not divisible by %d GPUs' % (args.global_batch, world))
+        batch = args.global_batch // world
     model = build_mpii_pose_model(base=base, output_strat='dsnt', reg=reg)
     synthetic.fill_state_dict(model, seed=0)          # identical weights on every rank
     model.cuda().train()
@@ -185,7 +317,9 @@ def main():
 
     runner = (model.hg if hasattr(model, 'hg') else model)._runner()
     runner.ensure(dev)
-    opt = optim.RMSprop(model, lr=2.5e-4)             # train.py:88-99 defaults for rmsprop
+    from dsnt.guard import NanGuard
+    guard = NanGuard(dev)                             # train.py:360-371 as a device-side flag, polled asynchronously
+    opt = optim.RMSprop(model, lr=2.5e-4, guard=guard)   # train.py:88-99 defaults for rmsprop
     if world > 1 or args.force_dp:
         if args.force_dp and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -196,9 +330,11 @@ def main():
     def step():
         out = model(x)
         loss = model.forward_loss(out, target, mask)
+        guard.check(loss)
         opt.zero_grad()
         loss.backward()
         opt.step()
+        guard.poll()
         return loss
 
     for _ in range(args.warmup):
@@ -220,6 +356,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.item())
+    guard.sync()
 
     out = None
     if rank == 0:
@@ -230,7 +367,7 @@ def main():
             'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'dtype_note': 'fp32 tensors and accumulation; large convolutions run as split-precision '
                                           'products on the 16-bit matrix cores with fp32-GEMM-grade error: two fp16 planes '
                                           'after a power-of-two scale + 3 MFMAs (fp16x3) where an operand bound exists, '
@@ -246,7 +383,11 @@ def main():
             'final_loss': final_loss,
             'step_mfma_frac': round(ips / world * gflop * 1e9 / (PEAK_F32_MFMA * 1e12), 4),
         }
-        out['roofline'] = dominant_kernel_roofline(batch)
+        if not args.no_extras:
+            out['roofline'] = dominant_kernel_roofline(batch)
+            out['head_roofline'] = head_roofline()
+            if hasattr(model, 'hg'):
+                out['parity'] = parity_vs_oracle(model, base, reg)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(base, reg)
             out['speedup_vs_cpu'] = round(out['value'] / out['cpu_baseline']['value'], 1)

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include "../../include/dsnt_hip.h"
+#include "../../include/dsnt_hip_debug.h"
 
 #define DSNT_WAVE 64
 

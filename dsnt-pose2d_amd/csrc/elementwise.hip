@@ -628,29 +628,51 @@ extern "C" int dsnt_nhwc_to_nchw(const float* src, float* dst, int N, int C, int
 }
 
 // ---------------------------------------------------------------- optimiser (flat arena)
+// `flag` (nullable, int[2]): the step's non-finite guard.  flag[0] != 0 at kernel start = an earlier check on this
+// stream fired (non-finite loss): nothing is updated.  A non-finite gradient element is skipped and raises
+// DSNT_FLAG_GRAD in flag[1] (a second word, so that workgroups starting later do not see a half-raised flag[0]:
+// the update stays an element-wise, order-independent function of its inputs).
+__device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
+
 __global__ void rmsprop_kernel(float* p, const float* __restrict__ g, float* sq, long n, float lr,
-                               float alpha, float eps, float wd, float gscale) {
+                               float alpha, float eps, float wd, float gscale, int* flag) {
+    if (flag && __builtin_nontemporal_load(flag) != 0) return;
+    bool bad = false;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float gi = g[i] * gscale;
+        if (flag && !finite_f(gi)) { bad = true; continue; }
         const float pi = p[i];
         if (wd != 0.f) gi = fmaf(wd, pi, gi);
         const float s = alpha * sq[i] + (1.f - alpha) * gi * gi;
         sq[i] = s;
         p[i] = pi - lr * gi / (sqrtf(s) + eps);
     }
+    if (bad) atomicOr(flag + 1, DSNT_FLAG_GRAD);
+}
+static int rmsprop_impl(float* p, const float* g, float* square_avg, int64_t n, float lr, float alpha, float eps,
+                        float weight_decay, float grad_scale, int* flag, void* stream) {
+    DSNT_REQUIRE(p && g && square_avg && n > 0, DSNT_ERR_ARG, "dsnt_rmsprop_step: bad argument");
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
+                       square_avg, (long)n, lr, alpha, eps, weight_decay, grad_scale, flag);
+    DSNT_CHECK_LAUNCH("dsnt_rmsprop_step");
 }
 extern "C" int dsnt_rmsprop_step(float* p, const float* g, float* square_avg, int64_t n, float lr,
                                  float alpha, float eps, float weight_decay, float grad_scale, void* stream) {
-    DSNT_REQUIRE(p && g && square_avg && n > 0, DSNT_ERR_ARG, "dsnt_rmsprop_step: bad argument");
-    hipLaunchKernelGGL(rmsprop_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
-                       square_avg, (long)n, lr, alpha, eps, weight_decay, grad_scale);
-    DSNT_CHECK_LAUNCH("dsnt_rmsprop_step");
+    return rmsprop_impl(p, g, square_avg, n, lr, alpha, eps, weight_decay, grad_scale, nullptr, stream);
+}
+extern "C" int dsnt_rmsprop_step_guarded(float* p, const float* g, float* square_avg, int64_t n, float lr, float alpha,
+                                         float eps, float weight_decay, float grad_scale, int* flag, void* stream) {
+    DSNT_REQUIRE(flag, DSNT_ERR_ARG, "dsnt_rmsprop_step_guarded: null flag");
+    return rmsprop_impl(p, g, square_avg, n, lr, alpha, eps, weight_decay, grad_scale, flag, stream);
 }
 
 __global__ void sgd_kernel(float* p, const float* __restrict__ g, float* buf, long n, float lr,
-                           float momentum, float wd, float gscale, int first) {
+                           float momentum, float wd, float gscale, int first, int* flag) {
+    if (flag && __builtin_nontemporal_load(flag) != 0) return;
+    bool bad = false;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float gi = g[i] * gscale;
+        if (flag && !finite_f(gi)) { bad = true; continue; }
         const float pi = p[i];
         if (wd != 0.f) gi = fmaf(wd, pi, gi);
         if (buf) {
@@ -660,15 +682,40 @@ __global__ void sgd_kernel(float* p, const float* __restrict__ g, float* buf, lo
         }
         p[i] = pi - lr * gi;
     }
+    if (bad) atomicOr(flag + 1, DSNT_FLAG_GRAD);
+}
+static int sgd_impl(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                    float weight_decay, float grad_scale, int first_step, int* flag, void* stream) {
+    DSNT_REQUIRE(p && g && n > 0, DSNT_ERR_ARG, "dsnt_sgd_step: bad argument");
+    hipLaunchKernelGGL(sgd_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
+                       momentum != 0.f ? momentum_buf : nullptr, (long)n, lr, momentum, weight_decay,
+                       grad_scale, first_step, flag);
+    DSNT_CHECK_LAUNCH("dsnt_sgd_step");
 }
 extern "C" int dsnt_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr,
                              float momentum, float weight_decay, float grad_scale, int first_step,
                              void* stream) {
-    DSNT_REQUIRE(p && g && n > 0, DSNT_ERR_ARG, "dsnt_sgd_step: bad argument");
-    hipLaunchKernelGGL(sgd_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
-                       momentum != 0.f ? momentum_buf : nullptr, (long)n, lr, momentum, weight_decay,
-                       grad_scale, first_step);
-    DSNT_CHECK_LAUNCH("dsnt_sgd_step");
+    return sgd_impl(p, g, momentum_buf, n, lr, momentum, weight_decay, grad_scale, first_step, nullptr, stream);
+}
+extern "C" int dsnt_sgd_step_guarded(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                                     float weight_decay, float grad_scale, int first_step, int* flag, void* stream) {
+    DSNT_REQUIRE(flag, DSNT_ERR_ARG, "dsnt_sgd_step_guarded: null flag");
+    return sgd_impl(p, g, momentum_buf, n, lr, momentum, weight_decay, grad_scale, first_step, flag, stream);
+}
+
+__global__ void nonfinite_flag_kernel(const float* __restrict__ x, long n, int* flag, int code) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        bad |= !finite_f(x[i]);
+    if (bad) atomicOr(flag, code);
+    // a gradient flag left by the previous step's optimiser becomes blocking from this step on
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flag[1] != 0) atomicOr(flag, flag[1]);
+}
+extern "C" int dsnt_nonfinite_flag(const float* x, int64_t n, int* flag, int code, void* stream) {
+    DSNT_REQUIRE(x && flag && n > 0 && code != 0, DSNT_ERR_ARG, "dsnt_nonfinite_flag: bad argument");
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n,
+                       flag, code);
+    DSNT_CHECK_LAUNCH("dsnt_nonfinite_flag");
 }
 
 // ---------------------------------------------------------------- PCKh hits

@@ -197,6 +197,41 @@ __global__ __launch_bounds__(HB) void make_gauss_kernel(const float* __restrict_
     }
 }
 
+// d/d(mu) of the above (the reference's make_gauss is differentiable in `coords`, nn.py:180-203):
+//   g_i = e_i / Z,  d g_i / d mu_x = g_i ((x_i - mu_x) - sum_j g_j (x_j - mu_x)) / sigma^2
+//   dL/d mu_x = (sum_i G_i g_i (x_i - mu_x) - m_x sum_i G_i g_i) / sigma^2,  m_x = sum_j g_j (x_j - mu_x)
+// The Gaussian is re-evaluated in registers (one pass for Z, one over the incoming gradient G): one HBM read.
+__global__ __launch_bounds__(HB) void make_gauss_bwd_kernel(const float* __restrict__ coords, const float* __restrict__ gout,
+                                                             float* __restrict__ gcoords, int h, int w, float k) {
+    __shared__ float red[32];
+    const int hw = h * w;
+    const float mx = coords[2 * (size_t)blockIdx.x], my = coords[2 * (size_t)blockIdx.x + 1];
+    const float* G = gout + (size_t)blockIdx.x * hw;
+    const Grid2 g(h, w);
+    float z[1] = {0.f};
+    for (int i = threadIdx.x; i < hw; i += HB) {
+        float x, y; g.xy(i, x, y);
+        z[0] += expf(((x - mx) * (x - mx) + (y - my) * (y - my)) * k);
+    }
+    block_sum<1>(z, red);
+    const float inv = 1.f / (z[0] + 1e-24f);
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // sum G g, sum G g dx, sum G g dy, sum g dx, sum g dy
+    for (int i = threadIdx.x; i < hw; i += HB) {
+        float x, y; g.xy(i, x, y);
+        const float dx = x - mx, dy = y - my;
+        const float q = expf((dx * dx + dy * dy) * k) * inv;
+        const float gq = G[i] * q;
+        s[0] += gq; s[1] = fmaf(gq, dx, s[1]); s[2] = fmaf(gq, dy, s[2]);
+        s[3] = fmaf(q, dx, s[3]); s[4] = fmaf(q, dy, s[4]);
+    }
+    block_sum<5>(s, red);
+    if (threadIdx.x == 0) {
+        const float is2 = -2.f * k;            // 1 / sigma^2
+        gcoords[2 * (size_t)blockIdx.x] = (s[1] - s[3] * s[0]) * is2;
+        gcoords[2 * (size_t)blockIdx.x + 1] = (s[2] - s[4] * s[0]) * is2;
+    }
+}
+
 // ------------------------------------------------------------------ regularisers (nn.py:208-298)
 #define REG_EPS 1e-24f
 
@@ -518,6 +553,17 @@ extern "C" int dsnt_make_gauss(const float* coords, float* out, int64_t rows, in
     const float k = (float)(-0.5 * (1.0 / (double)sigma) * (1.0 / (double)sigma));
     hipLaunchKernelGGL(make_gauss_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, coords, out, h, w, k);
     DSNT_CHECK_LAUNCH("dsnt_make_gauss");
+}
+
+extern "C" int dsnt_make_gauss_bwd(const float* coords, const float* g_out, float* g_coords, int64_t rows, int h, int w,
+                                   float sigma, void* stream) {
+    DSNT_REQUIRE(coords && g_out && g_coords, DSNT_ERR_ARG, "dsnt_make_gauss_bwd: null tensor");
+    DSNT_REQUIRE(sigma > 0.f, DSNT_ERR_ARG, "dsnt_make_gauss_bwd: sigma must be positive");
+    if (int e = check_rows("dsnt_make_gauss_bwd", rows, h, w)) return e;
+    const float k = (float)(-0.5 * (1.0 / (double)sigma) * (1.0 / (double)sigma));
+    hipLaunchKernelGGL(make_gauss_bwd_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, coords, g_out,
+                       g_coords, h, w, k);
+    DSNT_CHECK_LAUNCH("dsnt_make_gauss_bwd");
 }
 
 static inline float gauss_k(float sigma) { return (float)(-0.5 * (1.0 / (double)sigma) * (1.0 / (double)sigma)); }

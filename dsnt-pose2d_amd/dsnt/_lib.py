@@ -41,6 +41,7 @@ SIGNATURES = {
     'dsnt_expect_fwd': [P, P, L, I, I, P],
     'dsnt_expect_bwd': [P, P, L, I, I, P],
     'dsnt_make_gauss': [P, P, L, I, I, F, P],
+    'dsnt_make_gauss_bwd': [P, P, P, L, I, I, F, P],
     'dsnt_encode_heatmaps': [P, P, L, I, I, F, P],
     'dsnt_heatmap_mse_fwd': [P, P, P, L, I, I, F, P],
     'dsnt_heatmap_mse_bwd': [P, P, P, P, L, I, I, F, P],
@@ -100,6 +101,9 @@ SIGNATURES = {
     'dsnt_nhwc_to_nchw': [P, P, I, I, I, I, P],
     'dsnt_rmsprop_step': [P, P, P, L, F, F, F, F, F, P],
     'dsnt_sgd_step': [P, P, P, L, F, F, F, F, I, P],
+    'dsnt_rmsprop_step_guarded': [P, P, P, L, F, F, F, F, F, P, P],
+    'dsnt_sgd_step_guarded': [P, P, P, L, F, F, F, F, I, P, P],
+    'dsnt_nonfinite_flag': [P, L, P, I, P],
     'dsnt_pckh': [P, P, P, P, P, P, F, P, P, I, I, P],
     'dsnt_debug_mfma_peak': [P, I, I, I, I, P],
     'dsnt_debug_coexec': [P, I, I, I, P],

@@ -126,6 +126,10 @@ class Tape:
         self.amax_all = os.environ.get('DSNT_AMAX_ALL', '1') != '0'
         self._f16_dw_rows = []      # fp16x3 planes of the re-packed data-gradient weights
         self.dgrad_planes16, self.dgrad_bounds = None, None
+        # every fp16x3 launch with the tensors behind its operands and bounds: (list entry, {...}) — lets a test walk a
+        # step launch by launch and hold each bound against the operand it must dominate (tests/test_bounds_gpu.py)
+        self.f16_uses = []
+        self._pending_group_uses = []
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float32):
@@ -228,13 +232,15 @@ class Tape:
                 conv.append(C.byref(a))
             else:
                 conv.append(a)
-        lst.append((fn, tuple(conv), name, self.lane))
+        entry = (fn, tuple(conv), name, self.lane)
+        lst.append(entry)
+        return entry
 
     def f(self, name, *args):
-        self._emit(self.fwd, name, *args)
+        return self._emit(self.fwd, name, *args)
 
     def b(self, name, *args):
-        self._emit(self.bwd, name, *args)
+        return self._emit(self.bwd, name, *args)
 
     def on_backward(self, fn):
         lane = self.lane
@@ -329,7 +335,10 @@ class Tape:
             gtable = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
             self._keep.append(gtable)
             blocks = (max(n for _, n in descs) + 7) // 8 * 8
-            self.b('dsnt_conv_wgrad_group', gtable, len(descs), blocks)
+            e = self.b('dsnt_conv_wgrad_group', gtable, len(descs), blocks)
+            for u in self._pending_group_uses:
+                self.f16_uses.append((e, u))
+            self._pending_group_uses = []
         table = torch.tensor(rows, dtype=torch.int64).to(self.device)
         self._keep.append(table)
         blocks = max((r[4] // 4 + (r[5] + 3) // 4 + 63) // 64 for r in rows)
@@ -349,7 +358,8 @@ class Tape:
                 self.bwd.append((None, k, 'bucket', 0))
             self.on_backward(mark)
 
-    def run(self, lst, bucket_hook=None):
+    def run(self, lst, bucket_hook=None, probe=None):
+        """Replay a launch list.  `probe(entry)` (diagnostics / tests) is called before every launch."""
         main = torch.cuda.current_stream()
         if self.use_lanes and self.side_stream is None:
             self.side_stream = torch.cuda.Stream()
@@ -359,7 +369,8 @@ class Tape:
         if self.use_lanes:
             self.side_stream.wait_stream(main)
             self.wgrad_stream.wait_stream(main)
-        for fn, args, name, lane in lst:
+        for entry in lst:
+            fn, args, name, lane = entry
             if fn is None:
                 if name == 'sync':
                     src, dst, ev = args
@@ -368,6 +379,8 @@ class Tape:
                 elif bucket_hook is not None:
                     bucket_hook(args)
                 continue
+            if probe is not None:
+                probe(entry)
             rc = fn(*args, ptrs[lane])
             if rc != 0:
                 raise RuntimeError('%s failed (%d): %s' % (
@@ -487,8 +500,10 @@ class Tape:
         use16 = use6 and self.use_f16x3 and self.training and normed and p.wq16 is not None
         if use16:
             self.f16_weights(p)
-            self.f('dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, self.f16_bn_bound(src), p.b, y.buf,
-                   sc, sh, relu, r1, r2, part, g, None)
+            e = self.f('dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, self.f16_bn_bound(src), p.b, y.buf,
+                       sc, sh, relu, r1, r2, part, g, None)
+            self.f16_uses.append((e, dict(kind='fwd', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=src.abound,
+                                          w=p.w, w_bound=p.wb)))
         elif use6:
             self.f('dsnt_conv_fwd_bf16x6', x.buf, p.wq, p.wq_stride, p.b, y.buf, sc, sh, relu, r1, r2, part, g)
         else:
@@ -535,8 +550,13 @@ class Tape:
                     if nblk <= 0:
                         raise RuntimeError('dsnt_conv_wgrad_desc failed: %s' % self.lib.dsnt_last_error().decode())
                     self._pending_group.append((desc.raw, nblk))
+                    if w16:
+                        self._pending_group_uses.append(dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu,
+                                                             a_bound=ab, g=gy, g_bound=y.grad_amax))
                 elif w16:
-                    self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, 0, ab, y.grad_amax, g)
+                    e = self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, 0, ab, y.grad_amax, g)
+                    self.f16_uses.append((e, dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
+                                                  g=gy, g_bound=y.grad_amax)))
                 else:
                     self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
                            None, None, 0, g)
@@ -586,8 +606,9 @@ class Tape:
 
                 def dgrad(out, res, part=None, bnb=None):
                     if d16:
-                        self.b('dsnt_conv_fwd_f16x3_ex', gsrc, wq16, self.dgrad_total, wbd, g_amax, None, out, None, None,
-                               0, res, None, part, gd, bnb)
+                        e = self.b('dsnt_conv_fwd_f16x3_ex', gsrc, wq16, self.dgrad_total, wbd, g_amax, None, out, None,
+                                   None, 0, res, None, part, gd, bnb)
+                        self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
                     elif d6:
                         self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
                                part, gd, bnb)

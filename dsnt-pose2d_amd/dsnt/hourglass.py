@@ -234,7 +234,7 @@ class _Run(Function):
     def forward(ctx, runner, prog, x, *params):
         prog.in_nchw.copy_(x)
         prog.token += 1
-        prog.tape.run(prog.tape.fwd)
+        prog.tape.run(prog.tape.fwd, probe=runner.probe)
         ctx.runner, ctx.prog, ctx.token, ctx.nparams = runner, prog, prog.token, len(params)
         return tuple(o.clone() for o in prog.outs)
 
@@ -252,7 +252,7 @@ class _Run(Function):
                 gin.zero_()
             else:
                 gin.copy_(g)
-        prog.tape.run(prog.tape.bwd, runner.bucket_hook)
+        prog.tape.run(prog.tape.bwd, runner.bucket_hook, probe=runner.probe)
         if runner.before_publish is not None:
             runner.before_publish()
         runner.arena.publish_grads(runner.params)
@@ -269,6 +269,7 @@ class Runner:
         self.programs = {}
         self.params = []
         self._bns = None
+        self.probe = None             # diagnostics: called with the list entry before every launch
         self.bucket_hook = None       # called with k when gradient bucket k is complete (DP)
         self.before_publish = None    # called after the backward list (DP: wait for all-reduce)
 
@@ -307,7 +308,7 @@ class Runner:
             with torch.no_grad():
                 prog.in_nchw.copy_(x)
                 prog.token += 1
-                prog.tape.run(prog.tape.fwd)
+                prog.tape.run(prog.tape.fwd, probe=self.probe)
                 outs = tuple(o.clone() for o in prog.outs)
         return outs[0] if prog.single else list(outs)
 

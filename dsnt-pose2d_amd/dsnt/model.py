@@ -261,28 +261,26 @@ def _build_resnet_pose_model(base, dilate=0, truncate=0, output_strat='dsnt', pr
 
 def _build_hg_model(base, stacks=2, blocks=1, output_strat='gauss', preact='softmax',
                     reg='none', reg_coeff=1.0, hm_sigma=1.0):
-    m = re.search(r'hg(\d+)', base)
-    if m is not None:
-        stacks = int(m.group(1))
-    elif base == 'hg':
-        pass
-    else:
+    """Stacked-hourglass pose model (reference model.py:346-361): 'hg' keeps `stacks`, 'hg<N>' means N stacks;
+    the default output strategy of THIS builder is the heat-map one ('gauss'), as in the reference."""
+    suffix = re.search(r'hg(\d+)', base)
+    if suffix is None and base != 'hg':
         raise Exception('unsupported base model type: ' + base)
-    hg = hourglass.HourglassNet(hourglass.Bottleneck, num_stacks=stacks, num_blocks=blocks)
-    return HourglassHumanPoseModel(hg, n_chans=16, output_strat=output_strat, preact=preact,
-                                   reg=reg, reg_coeff=reg_coeff, hm_sigma=hm_sigma)
+    n_stacks = int(suffix.group(1)) if suffix is not None else stacks
+    backbone = hourglass.HourglassNet(hourglass.Bottleneck, num_stacks=n_stacks, num_blocks=blocks)
+    head = dict(output_strat=output_strat, preact=preact, reg=reg, reg_coeff=reg_coeff, hm_sigma=hm_sigma)
+    return HourglassHumanPoseModel(backbone, n_chans=16, **head)
+
+
+_BUILDERS = (('resnet', _build_resnet_pose_model), ('hg', _build_hg_model))
 
 
 def build_mpii_pose_model(base='resnet34', **kwargs):
-    """Create a pose estimation model"""
-    if base.startswith('resnet'):
-        build_model = _build_resnet_pose_model
-    elif base.startswith('hg'):
-        build_model = _build_hg_model
-    else:
+    """Create a pose estimation model (reference model.py:364-379).  Keyword arguments the chosen family's builder
+    does not declare (e.g. `dilate` for an hourglass) are dropped silently, so one `model_desc` dict serves both."""
+    builder = next((fn for prefix, fn in _BUILDERS if base.startswith(prefix)), None)
+    if builder is None:
         raise Exception('unsupported base model type: ' + base)
-    # Filter out unexpected parameters (reference model.py:374-377)
-    func_params = inspect.signature(build_model).parameters.values()
-    param_names = [p.name for p in func_params if p.default != inspect.Parameter.empty]
-    kwargs = {k: kwargs[k] for k in param_names if k in kwargs}
-    return build_model(base, **kwargs)
+    accepted = {name for name, prm in inspect.signature(builder).parameters.items()
+                if prm.default is not inspect.Parameter.empty}
+    return builder(base, **{k: v for k, v in kwargs.items() if k in accepted})

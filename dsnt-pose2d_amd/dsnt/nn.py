@@ -242,13 +242,17 @@ class _MakeGauss(Function):
         c = f32(coords).contiguous()
         out = torch.empty(*c.shape[:-1], height, width, device=c.device, dtype=c.dtype)
         call('dsnt_make_gauss', ptr(c), ptr(out), c.numel() // 2, height, width, float(sigma))
+        ctx.save_for_backward(c)
+        ctx.hw, ctx.sigma = (height, width), float(sigma)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError(
-            'dsnt.nn.make_gauss: gradient with respect to coords is not on the DSNT hot path '
-            '(targets never require grad in train.py); not implemented on the HIP path')
+        (c,) = ctx.saved_tensors
+        gc = torch.empty_like(c)
+        call('dsnt_make_gauss_bwd', ptr(c), ptr(f32(g).contiguous()), ptr(gc), c.numel() // 2, ctx.hw[0], ctx.hw[1],
+             ctx.sigma)
+        return gc, None, None, None
 
 
 def make_gauss(coords, width, height, sigma):
@@ -288,6 +292,10 @@ class _RegRows(Function):
     @staticmethod
     def backward(ctx, g):
         hm, mu = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError(
+                'dsnt.nn: the fused regularisers treat the target means as constants (train.py never asks for their '
+                'gradient); for d/d mu_t compose dsnt.nn.make_gauss (differentiable) with _js_2d / _kl_2d')
         ghm = torch.empty_like(hm)
         call('dsnt_reg_bwd', ptr(hm), ptr(mu), ptr(g.contiguous()), ptr(ghm), _rows(hm, 2),
              hm.shape[-2], hm.shape[-1], ctx.sigma, ctx.kind)

@@ -30,7 +30,8 @@ def _find_arena(model):
 class _FlatOptimizer(torch.optim.Optimizer):
     STATE_KEY = None        # name of the per-parameter state tensor in torch's format
 
-    def __init__(self, model, defaults):
+    def __init__(self, model, defaults, guard=None):
+        self.guard = guard          # dsnt.guard.NanGuard: the update is skipped while its device flag is up
         self.runner = _find_arena(model)
         arena = self.runner.arena
         arena_params = {id(p) for _, p, _, _ in arena.slots}
@@ -102,9 +103,9 @@ class _FlatOptimizer(torch.optim.Optimizer):
 class RMSprop(_FlatOptimizer):
     STATE_KEY = 'square_avg'
 
-    def __init__(self, model, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0):
+    def __init__(self, model, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0, guard=None):
         super().__init__(model, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay, momentum=0,
-                                     centered=False))
+                                     centered=False), guard)
 
     @property
     def square_avg(self):
@@ -122,9 +123,12 @@ class RMSprop(_FlatOptimizer):
         arena = self.runner.arena
         self._gather_grads()
         g = self.param_groups[0]
-        call('dsnt_rmsprop_step', ptr(arena.params), ptr(arena.grads), ptr(self.flat_state),
-             arena.numel, float(g['lr']), float(g['alpha']), float(g['eps']),
-             float(g['weight_decay']), float(self.grad_scale))
+        args = (ptr(arena.params), ptr(arena.grads), ptr(self.flat_state), arena.numel, float(g['lr']),
+                float(g['alpha']), float(g['eps']), float(g['weight_decay']), float(self.grad_scale))
+        if self.guard is not None:
+            call('dsnt_rmsprop_step_guarded', *args, ptr(self.guard.flag))
+        else:
+            call('dsnt_rmsprop_step', *args)
         for p, sq in zip(self.extra, self.extra_state):      # torch.optim.RMSprop's arithmetic, tensor by tensor
             if p.grad is None:
                 continue
@@ -139,9 +143,9 @@ class RMSprop(_FlatOptimizer):
 class SGD(_FlatOptimizer):
     STATE_KEY = 'momentum_buffer'
 
-    def __init__(self, model, lr=1e-3, momentum=0.0, weight_decay=0.0):
+    def __init__(self, model, lr=1e-3, momentum=0.0, weight_decay=0.0, guard=None):
         super().__init__(model, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, dampening=0,
-                                     nesterov=False))
+                                     nesterov=False), guard)
 
     @property
     def momentum_buf(self):
@@ -165,9 +169,12 @@ class SGD(_FlatOptimizer):
         self._gather_grads()
         g = self.param_groups[0]
         first = 1 if self._steps == 0 else 0
-        call('dsnt_sgd_step', ptr(arena.params), ptr(arena.grads), ptr(self.flat_state),
-             arena.numel, float(g['lr']), float(g['momentum']), float(g['weight_decay']),
-             float(self.grad_scale), first)
+        args = (ptr(arena.params), ptr(arena.grads), ptr(self.flat_state), arena.numel, float(g['lr']),
+                float(g['momentum']), float(g['weight_decay']), float(self.grad_scale), first)
+        if self.guard is not None:
+            call('dsnt_sgd_step_guarded', *args, ptr(self.guard.flag))
+        else:
+            call('dsnt_sgd_step', *args)
         for p, buf in zip(self.extra, self.extra_state):
             if p.grad is None:
                 continue

@@ -9,8 +9,10 @@
  *
  * Conventions
  *  - plain pointers + sizes; every pointer is DEVICE memory owned by the caller
- *    (PyTorch's allocator); the library allocates nothing and keeps no state
- *    except a thread-local error string;
+ *    (PyTorch's allocator); the library allocates nothing and the product entry points
+ *    declared here keep no state except a thread-local error string (the calibration /
+ *    timeline diagnostics live in dsnt_hip_debug.h, are not part of this ABI and are the
+ *    only code with process-wide switches);
  *  - all arithmetic is fp32; activations are NHWC ([N][H][W][C], C innermost);
  *    conv weights are OHWI ([Cout][R][S][Cin]); heat-maps for the DSNT head are
  *    planar rows ([rows = N*J][H*W]);
@@ -58,6 +60,10 @@ int dsnt_expect_bwd(const float* gcoords, float* ghm, int64_t rows, int h, int w
 /* nn.py:168-205 `make_gauss`: out[row] = normalised Gaussian at coords[row], sigma. */
 int dsnt_make_gauss(const float* coords, float* out, int64_t rows, int h, int w, float sigma,
                     void* stream);
+/* its backward (autograd through nn.py:180-203; the reference's make_gauss is differentiable in `coords`):
+ * g_coords[row] = sum_i g_out[row][i] * d out[row][i] / d coords[row]  (closed form, Gaussian re-evaluated). */
+int dsnt_make_gauss_bwd(const float* coords, const float* g_out, float* g_coords, int64_t rows, int h, int w,
+                        float sigma, void* stream);
 
 /* 'fc' output strategy: out_fc = nn.Linear(H*W, 2) on the flattened heat-maps (model.py:222-223, 293-303, 196-198).
  * out[rows][2] = hm[rows][hw] . W[2][hw]^T + b[2];  backward: ghm (may be NULL), gW[2][hw], gb[2] (may be NULL),
@@ -369,6 +375,20 @@ int dsnt_rmsprop_step(float* p, const float* g, float* square_avg, int64_t n, fl
 int dsnt_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, float lr,
                   float momentum, float weight_decay, float grad_scale, int first_step,
                   void* stream);
+/* The same updates under the step's non-finite guard (train.py:360-371 checks the loss for NaN before
+ * `backward()` / `step()` and dumps the model): `flag` is a device int[2] the caller owns and zeroes.  If
+ * flag[0] != 0 when the kernel starts (the loss check below fired earlier on this stream) NOTHING is updated — the
+ * weights stay the last finite ones; an element whose own gradient is not finite is skipped and raises
+ * DSNT_FLAG_GRAD in flag[1], which the next dsnt_nonfinite_flag call promotes into flag[0]. */
+#define DSNT_FLAG_LOSS 1
+#define DSNT_FLAG_GRAD 2
+int dsnt_rmsprop_step_guarded(float* p, const float* g, float* square_avg, int64_t n, float lr, float alpha,
+                              float eps, float weight_decay, float grad_scale, int* flag, void* stream);
+int dsnt_sgd_step_guarded(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                          float weight_decay, float grad_scale, int first_step, int* flag, void* stream);
+/* flag[0] |= code if any of x[0..n) is NaN or +-inf (train.py:360 `np.isnan(loss.data[0])`, without the
+ * device-to-host synchronisation: the caller reads the flag asynchronously); also flag[0] |= flag[1]. */
+int dsnt_nonfinite_flag(const float* x, int64_t n, int* flag, int code, void* stream);
 
 /* ------------------------------------------------------------------ metrics
  * evaluator.py:66-81 + train.py:243-258: PCKh hits on device.
@@ -377,25 +397,6 @@ int dsnt_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, floa
 int dsnt_pckh(const float* pred, const float* target, const double* m, const double* b,
               const float* mask, const double* head, float threshold, float* hits,
               float* valid, int B, int J, void* stream);
-
-/* ------------------------------------------------------------------ calibration
- * Not on the product path: sustained v_mfma_f32_32x32x2_f32 rate of this device
- * (blocks x threads, `iters` x 16 MFMAs per wave; dep = 1 independent / 4 dependent chains). */
-int dsnt_debug_mfma_peak(float* out, int blocks, int threads, int iters, int dep, void* stream);
-/* Debug timeline of the conv kernel: lane 0 of every wave of workgroup `block` stamps s_memtime
- * into buf[wave*128 + slot] (buf = 8*128 int64 on the device; NULL switches it off). */
-int dsnt_debug_set_timeline(long long* buf, int block);
-/* MFMA / VALU co-execution probe (512-thread blocks: 4 MFMA waves + 4 v_fma waves). */
-int dsnt_debug_coexec(float* out, int blocks, int mfma_iters, int valu_iters, void* stream);
-/* bf16 MFMA rate (v_mfma_f32_32x32x16_bf16) and its co-execution with VALU (threads 256 or 512). */
-int dsnt_debug_bf16_peak(float* out, int blocks, int threads, int mfma_iters, int valu_iters, void* stream);
-/* Debug/bench switch: route 3x3 convolutions of the bf16x6 path through the implicit-GEMM kernel instead of
- * the LDS halo-tile kernel (process-wide; not for production use). */
-int dsnt_debug_force_gemm6(int on);
-/* Issue-starvation probe: cycles a burst of valu_n x 16 v_fma_f32 takes on waves that share their SIMDs with
- * waves saturating the bf16 matrix pipe (out_cycles[blocks*4], s_memtime units); prio = s_setprio level. */
-int dsnt_debug_starve(float* out, long long* out_cycles, int blocks, int mfma_iters, int valu_n, int prio,
-                      void* stream);
 
 #ifdef __cplusplus
 }

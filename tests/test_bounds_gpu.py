@@ -1,0 +1,149 @@
+"""The fp16x3 default is only safe while every operand bound dominates its operand (an fp16 overflow would be
+fatal: csrc/conv.hip `pow2_scale` leaves 4x head-room and nothing else).  These tests walk a FULL-SIZE train step
+launch by launch — hg2 batch 32 and hg8 batch 16 at 256 px (BASELINE configs 3 and 5), hg1 batch 32 (config 2) —
+and, right before every fp16x3 launch, hold each bound slot against the tensor it must dominate AS IT IS AT THAT
+MOMENT (gradient buffers are donated and accumulated into, so the end-of-step content is not what a consumer read):
+
+* A operands seen through a train-mode BatchNorm(+ReLU): max|relu?(x scale + shift)| <= the analytic bound;
+* weights (forward layout and the re-packed data-gradient layout): max|w| <= the bound the prep launch wrote;
+* gradient operands (dY of data-gradient and weight-gradient launches): max|dY| <= the slot its writers raised.
+
+Also: loss and every gradient finite, the device-side non-finite guard stays down, and a poisoned loss raises it,
+blocks the optimiser and is reported by the asynchronous poll (train.py:360-371).
+"""
+import pytest
+import torch
+
+from dsnt import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _train_step_with_probe(base, reg, batch):
+    from dsnt.model import build_mpii_pose_model
+    m = build_mpii_pose_model(base=base, output_strat='dsnt', reg=reg)
+    synthetic.fill_state_dict(m, seed=0)
+    m.to(DEV).train()
+    x, t, k = synthetic.batch(batch, size=256, seed=1, mask_p=0.9)
+    x, t, k = x.to(DEV), t.to(DEV), k.to(DEV)
+    runner = m.hg._runner()
+    # step 1 un-probed (traces the programs), step 2 probed
+    loss = m.forward_loss(m(x), t, k)
+    loss.backward()
+    prog = [p for p in runner.programs.values() if p.training][0]
+    uses = {}
+    for entry, info in prog.tape.f16_uses:
+        uses.setdefault(id(entry), []).append(info)
+    checked = {'fwd': 0, 'wgrad': 0, 'dgrad': 0}
+    worst = {'a': 0.0, 'w': 0.0, 'g': 0.0}
+    bad = []
+
+    def amax_a(u):
+        v = u['x'] * u['sc'] + u['sh']
+        if u['relu']:
+            v = v.clamp_(min=0)
+        return float(v.abs().max())
+
+    def probe(entry):
+        infos = uses.get(id(entry))
+        if not infos:
+            return
+        torch.cuda.synchronize()
+        for u in infos:
+            checked[u['kind']] += 1
+            if 'x' in u:
+                got, bound = amax_a(u), float(u['a_bound'].max())
+                worst['a'] = max(worst['a'], got / bound)
+                if not got <= bound:
+                    bad.append((u['kind'], u['name'], 'A', got, bound))
+            if 'w' in u:
+                got, bound = float(u['w'].abs().max()), float(u['w_bound'].max())
+                worst['w'] = max(worst['w'], got / bound)
+                if not got <= bound:
+                    bad.append((u['kind'], u['name'], 'W', got, bound))
+            if 'g' in u:
+                got, bound = float(u['g'].abs().max()), float(u['g_bound'].max())
+                worst['g'] = max(worst['g'], got / max(bound, 1e-30))
+                if not got <= bound:
+                    bad.append((u['kind'], u['name'], 'dY', got, bound))
+
+    for p in m.parameters():
+        p.grad = None
+    runner.probe = probe
+    try:
+        out = m(x)
+        loss = m.forward_loss(out, t, k)
+        loss.backward()
+    finally:
+        runner.probe = None
+    torch.cuda.synchronize()
+    return m, loss, checked, worst, bad, prog
+
+
+@pytest.mark.parametrize('base,reg,batch,min_uses', [('hg2', 'js', 32, (40, 30, 30)), ('hg8', 'js', 16, (150, 100, 100)),
+                                                      ('hg1', 'none', 32, (20, 15, 15))])
+def test_every_fp16x3_bound_dominates_its_operand(base, reg, batch, min_uses):
+    m, loss, checked, worst, bad, prog = _train_step_with_probe(base, reg, batch)
+    assert not bad, bad[:8]
+    assert checked['fwd'] >= min_uses[0] and checked['wgrad'] >= min_uses[1] and checked['dgrad'] >= min_uses[2], checked
+    # exact bounds (weights, gradients) are tight; the analytic BatchNorm bound is loose but must not be absurd
+    assert worst['w'] == 1.0 and 0.0 < worst['g'] <= 1.0 and 0.0 < worst['a'] <= 1.0, worst
+    assert torch.isfinite(loss).item()
+    g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert torch.isfinite(g).all().item() and float(g.norm()) > 0
+    # every bound slot of the program is finite and non-negative
+    t = prog.tape
+    if t._amax_buf is not None:
+        assert torch.isfinite(t._amax_buf[:t._amax_used]).all().item() and float(t._amax_buf.min()) >= 0.0
+
+
+def test_nonfinite_guard_blocks_the_update_and_reports_asynchronously():
+    from dsnt.model import build_mpii_pose_model
+    from dsnt import optim
+    from dsnt.guard import NanGuard, NonFiniteError
+    m = build_mpii_pose_model(base='hg1', output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(m, seed=0)
+    m.to(DEV).train()
+    x, t, k = synthetic.batch(2, size=128, seed=1)
+    x, t, k = x.to(DEV), t.to(DEV), k.to(DEV)
+    guard = NanGuard(torch.device(DEV))
+    m.hg._runner().ensure(torch.device(DEV))
+    opt = optim.RMSprop(m, lr=2.5e-4, guard=guard)
+
+    def step(poison=None):
+        out = m(x)
+        loss = m.forward_loss(out, t, k)
+        if poison is not None:
+            loss = loss * poison
+        guard.check(loss)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        guard.poll()
+
+    before = m.hg.arena.params.clone()
+    step()
+    step()
+    guard.sync()                                        # finite steps: flag down, weights move
+    after = m.hg.arena.params.clone()
+    assert not torch.equal(before, after) and guard.flag.tolist() == [0, 0]
+    step(poison=float('nan'))                           # NaN loss: update skipped, poll reports at the latest one step on
+    assert torch.equal(m.hg.arena.params, after)
+    with pytest.raises(NonFiniteError, match='non-finite loss'):
+        step()
+        torch.cuda.synchronize()
+        guard.poll()
+    assert torch.equal(m.hg.arena.params, after)        # still blocked
+    guard.reset()
+    # a finite loss with a non-finite GRADIENT element: that element is skipped, the flag says so
+    m.zero_grad()
+    loss = m.forward_loss(m(x), t, k)
+    loss.backward()
+    m.hg.arena.grads[5] = float('inf')
+    p5 = float(m.hg.arena.params[5])
+    opt.step()
+    assert float(m.hg.arena.params[5]) == p5 and not torch.equal(m.hg.arena.params, after)
+    with pytest.raises(NonFiniteError, match='non-finite gradient'):
+        guard.sync()
+    assert torch.isfinite(m.hg.arena.params).all().item()

@@ -7,13 +7,17 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, 'include', 'dsnt_hip.h')
+HEADERS = [os.path.join(ROOT, 'include', 'dsnt_hip.h'),          # the product ABI
+           os.path.join(ROOT, 'include', 'dsnt_hip_debug.h')]    # calibration / timeline diagnostics (tools/ only)
 
 
-def _declared():
-    text = open(HEADER).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(dsnt_[a-z0-9_]+)\s*\(', text)))
+def _declared(headers=HEADERS):
+    names = set()
+    for h in headers:
+        text = open(h).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        names |= set(re.findall(r'\b(dsnt_[a-z0-9_]+)\s*\(', text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,6 +30,8 @@ def test_library_exports_every_declared_symbol():
     bound = set(_lib.SIGNATURES) | set(_lib.PLAIN)
     assert bound == set(names), (sorted(bound - set(names)), sorted(set(names) - bound))
     assert lib.dsnt_version() >= 100
+    # the product header declares no diagnostics, and nothing in the product package binds one at import time
+    assert not [n for n in _declared(HEADERS[:1]) if n.startswith('dsnt_debug')]
 
 
 def test_argument_validation_without_gpu():

@@ -539,3 +539,107 @@ def test_f16x3_preparation_launches():
     low = torch.empty(2, 4, 4, 64, device=dev)
     call('dsnt_upsample2_bwd_amax', ptr(x), ptr(low), 0, 2, 8, 8, 64, ptr(slot))
     assert slot.max().item() == low.abs().max().item()
+
+
+# (N, H, W, Cin [BN'd input channels], Cout [channels of the conv whose data gradient is taken], k)
+BNB_CASES = [
+    (4, 64, 64, 128, 128, 3),     # 3x3 halo-tile kernel (split paths) / 128x128 implicit GEMM (fp32 path)
+    (4, 64, 64, 256, 128, 1),     # reducing 1x1 of a Bottleneck: data gradient 128 -> 256
+    (4, 64, 64, 128, 256, 1),     # expanding 1x1: data gradient 256 -> 128
+    (2, 8, 8, 128, 128, 3),       # 128 rows: the K-split kernel on the fp32 path
+    (2, 16, 16, 128, 128, 3),     # 512 rows: 32x128 tiles / K-split
+]
+
+
+@pytest.mark.parametrize('case', BNB_CASES)
+@pytest.mark.parametrize('path', ['f32', 'bf16x6', 'f16x3'])
+def test_bn_backward_epilogue_with_relu_vs_autograd(case, path):
+    """ONE layer x -> BatchNorm(train) -> ReLU -> conv, backward through the production chain with the ReLU ON:
+    data-gradient launch with the BN-backward epilogue (ReLU mask + the two per-channel sums) -> finalise ->
+    apply, against torch autograd (fp64).  A single layer has no flip amplification, so the bars are tight
+    (2e-5 of the scale, as for the plain convolutions): inputs are nudged so that no pre-activation sits within
+    5e-4 of the ReLU kink, where two fp32 evaluations may legitimately disagree."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call, BnBwdEpilogue
+    N, H, W, Cin, Cout, k = case
+    dev = torch.device('cuda:0')
+    tag = 'bnb' + '_'.join(map(str, case))
+    pad = k // 2
+    M = N * H * W
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=21) * 1.3 + 0.2
+    gamma = synthetic.tensor(tag + 'g', (Cin,), seed=21, kind='uniform') * 0.5 + 1.0
+    beta = synthetic.tensor(tag + 'b', (Cin,), seed=21, scale=0.2)
+    w = synthetic.tensor(tag + 'w', (Cout, Cin, k, k), seed=21, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    gy = synthetic.tensor(tag + 'gy', (N, Cout, H, W), seed=22)
+    for _ in range(4):       # keep every pre-activation away from the kink (batch statistics move a little: iterate)
+        z = F.batch_norm(x.double(), None, None, gamma.double(), beta.double(), True, 0.0, 1e-5)
+        near = z.abs() < 1e-3
+        if not near.any():
+            break
+        std = x.double().var((0, 2, 3), unbiased=False, keepdim=True).add(1e-5).sqrt()
+        x = (x.double() + torch.where(near, torch.sign(z) * 4e-3 * std / gamma.double().view(1, -1, 1, 1),
+                                      torch.zeros_like(z))).float()
+    z = F.batch_norm(x.double(), None, None, gamma.double(), beta.double(), True, 0.0, 1e-5)
+    assert float(z.abs().min()) >= 5e-4
+    # reference: fp64 autograd through the layer
+    xr = x.double().requires_grad_()
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    a = F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.0, 1e-5))
+    F.conv2d(a, w.double(), None, padding=pad).backward(gy.double())
+
+    xd, gyd = _nhwc(x).to(dev), _nhwc(gy).to(dev)
+    gd, bd = gamma.to(dev), beta.to(dev)
+    tiles = (M + 127) // 128
+    part = torch.empty(tiles, 2, Cin, device=dev)
+    call('dsnt_bn_stats', ptr(xd), ptr(part), M, Cin)
+    mean, invstd, scale, shift = (torch.empty(Cin, device=dev) for _ in range(4))
+    call('dsnt_bn_finalize', ptr(part), tiles, M, Cin, ptr(gd), ptr(bd), None, None, 0.1, 1e-5, 1,
+         ptr(mean), ptr(invstd), ptr(scale), ptr(shift))
+    # data gradient of the conv: forward kernel on dY with tap-flipped, transposed weights, Cout -> Cin channels
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    wdg = torch.empty(Cin, k, k, Cout, device=dev)
+    call('dsnt_conv_pack_dgrad', ptr(wd), ptr(wdg), Cout, k, k, Cin)
+    g = _geom(N, H, W, Cout, Cin, k, k, 1, pad, 1)
+    bnb = BnBwdEpilogue(ptr(xd), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), 1)
+    dz = torch.empty(N, H, W, Cin, device=dev)
+    if path == 'f32':
+        bm = _lib.fn('dsnt_conv_fwd_bm')(C.byref(g))
+        tiles_d = (M + bm - 1) // bm
+        part_d = torch.zeros(tiles_d, 2, Cin, device=dev)
+        call('dsnt_conv_fwd_ex', ptr(gyd), ptr(wdg), None, ptr(dz), None, None, 0, None, None, ptr(part_d),
+             C.byref(g), C.byref(bnb))
+    else:
+        if not _lib.fn('dsnt_conv_bf16x6_ok')(C.byref(g)):
+            pytest.skip('geometry not supported by the split-precision kernels')
+        tiles_d = (M + 127) // 128
+        part_d = torch.zeros(tiles_d, 2, Cin, device=dev)
+        if path == 'bf16x6':
+            planes = torch.empty(3 * wdg.numel(), dtype=torch.bfloat16, device=dev)
+            call('dsnt_split_bf16x3', ptr(wdg), ptr(planes), wdg.numel())
+            call('dsnt_conv_fwd_bf16x6_ex', ptr(gyd), ptr(planes), wdg.numel(), None, ptr(dz), None, None, 0, None,
+                 None, ptr(part_d), C.byref(g), C.byref(bnb))
+        else:
+            wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+            call('dsnt_amax', ptr(wdg), wdg.numel(), ptr(wb))
+            call('dsnt_amax', ptr(gyd), gyd.numel(), ptr(ab))
+            planes = torch.empty(2 * wdg.numel(), dtype=torch.float16, device=dev)
+            call('dsnt_split_f16x2', ptr(wdg), ptr(planes), wdg.numel(), wdg.numel(), ptr(wb))
+            call('dsnt_conv_fwd_f16x3_ex', ptr(gyd), ptr(planes), wdg.numel(), ptr(wb), ptr(ab), None, ptr(dz), None,
+                 None, 0, None, None, ptr(part_d), C.byref(g), C.byref(bnb))
+    # dz = dL/d(bn output) masked by the ReLU: autograd's gradient at the BN output
+    dz_ref = torch.autograd.grad(F.conv2d(F.relu(zz := z.clone().requires_grad_()), w.double(), None, padding=pad),
+                                 zz, gy.double())[0]
+    tol = 2e-5
+    s_dz = dz_ref.abs().max().item()
+    assert (dz.cpu().permute(0, 3, 1, 2).double() - dz_ref).abs().max().item() <= tol * s_dz
+    assert float((dz == 0).float().mean()) > 0.2          # the mask really is on
+    dgamma, dbeta = torch.empty(Cin, device=dev), torch.empty(Cin, device=dev)
+    coef = torch.empty(2, Cin, device=dev)
+    call('dsnt_bn_bwd_finalize', ptr(part_d), tiles_d, M, Cin, ptr(dgamma), ptr(dbeta), 0, ptr(coef))
+    dx = torch.empty(N, H, W, Cin, device=dev)
+    call('dsnt_bn_act_bwd_apply', ptr(dz), ptr(xd), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(coef), 0,
+         ptr(dx), 0, M, Cin)
+    assert (dgamma.cpu().double() - gr.grad).abs().max().item() <= tol * max(1.0, gr.grad.abs().max().item())
+    assert (dbeta.cpu().double() - br.grad).abs().max().item() <= tol * max(1.0, br.grad.abs().max().item())
+    s_dx = xr.grad.abs().max().item()
+    assert (dx.cpu().permute(0, 3, 1, 2).double() - xr.grad).abs().max().item() <= tol * s_dx

@@ -96,6 +96,38 @@ def test_thresholded_softmax_grad(dev):  # tests/test_nn.py:140-154 (gradcheck, 
     assert (xd.grad.cpu().double() - xo.grad).abs().max() <= 1e-6
 
 
+@pytest.mark.parametrize('h,w,sigma', [(64, 64, 1 / 32), (5, 5, 0.4), (12, 20, 0.15)])
+def test_make_gauss_grad_vs_oracle(dev, h, w, sigma):
+    """`make_gauss` is differentiable in `coords` (nn.py:168-205): closed-form HIP backward vs the oracle's fp64
+    autograd, directly and through a KL built from the compatibility helpers (bar 2e-5 relative to the gradient scale)."""
+    import dsnt.nn as dn
+    from dsnt_oracle import nn as onn
+    mu = synthetic.tensor('mg.mu', (3, 16, 2), seed=9, kind='uniform') * 0.8
+    G = synthetic.tensor('mg.g', (3, 16, h, w), seed=9)
+    md = mu.to(dev).requires_grad_()
+    out = dn.make_gauss(md, w, h, sigma)
+    out.backward(G.to(dev))
+    mo = mu.double().requires_grad_()
+    oo = onn.make_gauss(mo, w, h, sigma)
+    oo.backward(G.double())
+    assert (out.detach().cpu().double() - oo.detach()).abs().max() <= 2e-6
+    scale = float(mo.grad.abs().max())
+    assert (md.grad.cpu().double() - mo.grad).abs().max() <= 2e-5 * scale
+    # through a divergence, as a caller optimising the target means would use it
+    p = torch.softmax(synthetic.tensor('mg.p', (3, 16, h * w), seed=9), -1).view(3, 16, h, w)
+    md2 = mu.to(dev).requires_grad_()
+    dn._kl_2d(p.to(dev), dn.make_gauss(md2, w, h, sigma)).sum().backward()
+    mo2 = mu.double().requires_grad_()
+    onn._kl_2d(p.double(), onn.make_gauss(mo2, w, h, sigma)).sum().backward()
+    # (KL's 1/q amplifies fp32 rounding of the far Gaussian tail: hold the direction and the scale)
+    gd, go = md2.grad.cpu().double().flatten(), mo2.grad.flatten()
+    assert torch.isfinite(gd).all()
+    assert float(gd @ go / (gd.norm() * go.norm())) > 1 - 1e-6
+    with pytest.raises(NotImplementedError, match='constants'):
+        md3 = mu.to(dev).requires_grad_()
+        dn.js_reg_loss(p.to(dev), md3, sigma).backward()
+
+
 def test_ops_vs_oracle_and_golden(dev):
     import dsnt.nn as dn
     from dsnt_oracle import nn as onn, model as omodel

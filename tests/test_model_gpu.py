@@ -229,6 +229,118 @@ def test_hg2_every_gradient_vs_oracle(smooth):
         assert _rel_l2(p.grad, 2 * g1[n], 1e-3 * g1[n].norm().item() + 1e-12) <= 1e-5, n
 
 
+def test_ten_rmsprop_steps_vs_oracle(mfma_path):
+    """TEN optimiser steps (hg1 + DSNT + JS, batch 4, 128 px, RMSprop lr 2.5e-4 as train.py:88-99) next to the CPU
+    oracle stepping torch.optim.RMSprop from the same weights on the same batch: coordinates within the north-star
+    bar (1e-4) before and after the first update, then bounded drift (two fp32 implementations of a ReLU network
+    under RMSprop's sign-like first steps separate slowly: the bars below are ~10x what was measured), identical
+    loss trajectory to 1e-3 relative, running statistics in step."""
+    from dsnt.model import build_mpii_pose_model
+    from dsnt import optim
+    from dsnt_oracle import model as omodel
+    m = build_mpii_pose_model(base='hg1', output_strat='dsnt', reg='js')
+    o = omodel.build_mpii_pose_model(base='hg1', output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(m, seed=6)
+    synthetic.fill_state_dict(o, seed=6)
+    m.cuda().train()
+    o.train()
+    x, target, mask = synthetic.batch(4, size=128, seed=3, mask_p=0.9)
+    xd, td, kd = x.to(DEV), target.to(DEV), mask.to(DEV)
+    m.hg._runner().ensure(torch.device(DEV))
+    opt = optim.RMSprop(m, lr=2.5e-4)
+    opt_o = torch.optim.RMSprop(o.parameters(), lr=2.5e-4)
+    dcoord, dloss, losses = [], [], []
+    for step in range(10):
+        out = m(xd)
+        loss = m.forward_loss(out, td, kd)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        out_o = o(x)
+        loss_o = o.forward_loss(out_o, target, mask)
+        opt_o.zero_grad()
+        loss_o.backward()
+        opt_o.step()
+        dcoord.append((out[-1].detach().cpu() - out_o[-1].detach()).abs().max().item())
+        dloss.append(abs(loss.item() - loss_o.item()) / abs(loss_o.item()))
+        losses.append(loss_o.item())
+    print('10-step drift (%s): dcoord %s dloss %s loss %s' % (mfma_path, ['%.1e' % v for v in dcoord],
+                                                             ['%.1e' % v for v in dloss], ['%.4f' % v for v in losses]))
+    assert dcoord[0] <= 1e-4 and dcoord[1] <= 1e-4, dcoord
+    assert max(dcoord) <= 5e-3 and max(dloss) <= 1e-3, (dcoord, dloss)
+    assert losses[-1] < losses[0]                      # and it trains
+    for (n, b), (_, c) in zip(m.named_buffers(), o.named_buffers()):
+        if 'running_mean' in n:
+            assert (b.cpu() - c).abs().max().item() <= 1e-3 * max(1.0, c.abs().max().item()), n
+    # the optimiser state is checkpointable in torch's format and resumes bit-exactly (train.py:364,492)
+    sd = opt.state_dict()
+    assert len(sd['state']) == len(list(m.parameters())) and float(sd['state'][0]['step']) == 10.0
+    before = m.hg.arena.params.clone()
+    out = m(xd)
+    loss = m.forward_loss(out, td, kd)
+    opt.zero_grad()
+    loss.backward()
+    g = m.hg.arena.grads.clone()
+    opt.step()
+    after = m.hg.arena.params.clone()
+    m.hg.arena.params.copy_(before)
+    opt2 = optim.RMSprop(m, lr=1.0)
+    opt2.load_state_dict(sd)
+    m.hg.arena.grads.copy_(g)
+    opt2.step()
+    assert torch.equal(m.hg.arena.params, after)
+
+
+def test_data_parallel_world1_nccl():
+    """`parallel.DataParallel` on the GPU (world size 1, RCCL): the bucket markers of the traced backward list fire in
+    backward-completion order for hourglass AND ResNet models, attaching changes no gradient bit, and the 1/world
+    averaging rides in the publish kernel (`publish_scale`)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from dsnt.model import build_mpii_pose_model
+    from dsnt import parallel
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        for base, size, nb in (('hg2', 128, 3), ('resnet18', 128, 1)):
+            m = build_mpii_pose_model(base=base, output_strat='fc' if base == 'hg2' else 'dsnt', reg='js')
+            synthetic.fill_state_dict(m, seed=0)
+            m.cuda().train()
+            x, t, k = synthetic.batch(4, size=size, seed=1, mask_p=0.9)
+            x, t, k = x.to(DEV), t.to(DEV), k.to(DEV)
+
+            def grads():
+                for p in m.parameters():
+                    p.grad = None
+                m.forward_loss(m(x), t, k).backward()
+                return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+            g0 = grads()
+            dp = parallel.DataParallel(m)
+            fired = []
+            hook = dp.runner.bucket_hook
+            dp.runner.bucket_hook = lambda kk: (fired.append(kk), hook(kk))
+            g1 = grads()
+            assert torch.equal(g0, g1), base
+            assert fired == list(range(nb - 1, -1, -1)) and dp.reducer.last_late == [], (base, fired)
+            assert len(dp.extra) == (2 if base == 'hg2' else 0)
+            dp.runner.arena.publish_scale = 0.5
+            g2 = grads()
+            n_arena = sum(p.numel() for _, p, _, _ in dp.runner.arena.slots)
+            arena_ids = {id(p) for _, p, _, _ in dp.runner.arena.slots}
+            mask_arena = torch.cat([torch.full((p.numel(),), id(p) in arena_ids) for p in m.parameters()]).to(DEV)
+            assert torch.equal(g2[mask_arena], 0.5 * g0[mask_arena]) and torch.equal(g2[~mask_arena], g0[~mask_arena])
+            assert int(mask_arena.sum()) == n_arena
+            dp.detach()
+            assert torch.equal(grads(), g0)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_optimizer_kernels():
     """Flat RMSprop / SGD-momentum kernels vs torch.optim on identical gradients (train.py:314-326)."""
     from dsnt._lib import ptr, call
