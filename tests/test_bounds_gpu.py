@@ -81,7 +81,7 @@ def _train_step_with_probe(base, reg, batch):
     return m, loss, checked, worst, bad, prog
 
 
-@pytest.mark.parametrize('base,reg,batch,min_uses', [('hg2', 'js', 32, (40, 30, 30)), ('hg8', 'js', 16, (150, 100, 100)),
+@pytest.mark.parametrize('base,reg,batch,min_uses', [('hg2', 'js', 32, (40, 30, 30)), ('hg8', 'js', 16, (120, 120, 120)),
                                                       ('hg1', 'none', 32, (20, 15, 15))])
 def test_every_fp16x3_bound_dominates_its_operand(base, reg, batch, min_uses):
     m, loss, checked, worst, bad, prog = _train_step_with_probe(base, reg, batch)
@@ -95,7 +95,7 @@ def test_every_fp16x3_bound_dominates_its_operand(base, reg, batch, min_uses):
     # every bound slot of the program is finite and non-negative
     t = prog.tape
     if t._amax_buf is not None:
-        assert torch.isfinite(t._amax_buf[:t._amax_used]).all().item() and float(t._amax_buf.min()) >= 0.0
+        assert torch.isfinite(t._amax_buf[:t._amax_used]).all().item() and float(t._amax_buf[:t._amax_used].min()) >= 0.0
 
 
 def test_nonfinite_guard_blocks_the_update_and_reports_asynchronously():
