@@ -103,7 +103,7 @@ def dominant_kernel_roofline(batch, iters=20):
         assert _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(planes16), w.numel(), w.numel(), ptr(wb), stream) == 0
         ab.fill_(float(torch.relu(x * sc + sh).max()) * 4.0)
         ms16 = timed(_lib.fn('dsnt_conv_fwd_f16x3_ex'),
-                     (ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y)) + common + (None,))
+                     (ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y)) + common + (None, None))
         achieved, peak, ms = flops / (ms16 * 1e-3) / 1e12, PEAK_BF16_MFMA / 3.0, ms16
         twins['bf16x6_kernel'] = {'achieved': round(flops / (ms6 * 1e-3) / 1e12, 2), 'peak': round(PEAK_BF16_MFMA / 6.0, 1),
                                   'us_per_launch': round(ms6 * 1e3, 1)}

@@ -26,7 +26,8 @@ def _newer(a, b):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    deps = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'dsnt_hip.h')]
+    deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'bn_tail.h'),
+            os.path.join(HERE, '..', 'include', 'dsnt_hip.h'), os.path.join(HERE, '..', 'include', 'dsnt_hip_debug.h')]
     objs, jobs = [], []
     os.makedirs(os.path.join(CSRC, 'build'), exist_ok=True)
     for src in SOURCES:

@@ -17,6 +17,7 @@
 // bank-conflict free.  One barrier per K-step, global loads for step s+1 in flight during the
 // MFMAs of step s (register staging: the A operand needs per-element BN/ReLU/padding).
 #include "common.h"
+#include "bn_tail.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -40,6 +41,8 @@ struct ConvP {
     const float* a_bound; const float* w_bound;
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil;
     int M, K, mtiles, ntiles;
+    // optional: the launch's last workgroup finishes the BatchNorm bookkeeping over `stats` (bn_tail.h)
+    BnTailP tail;
 };
 
 // Debug timeline (normally null): when set through dsnt_debug_set_timeline, lane 0 of every wave
@@ -215,10 +218,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     a0 += red[((size_t)w * BN + tid) * 2 + 0];
                     a1 += red[((size_t)w * BN + tid) * 2 + 1];
                 }
-                p.stats[((size_t)mtile * 2 + 0) * p.Cout + n] = a0;
-                p.stats[((size_t)mtile * 2 + 1) * p.Cout + n] = a1;
+                tail_store(p.stats + ((size_t)mtile * 2 + 0) * p.Cout + n, a0);      // write-through: see bn_tail.h
+                tail_store(p.stats + ((size_t)mtile * 2 + 1) * p.Cout + n, a1);
             }
         }
+        if (p.tail.counters) bn_tail_run<NT>(p.tail, p.stats, p.mtiles, p.Cout, p.M, mtile, p.ntiles, smem);
     }
 }
 
@@ -855,6 +859,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
     DBG_STAMP(125);
 }
 
+extern "C" int dsnt_bn_tail_group(void) { return BN_TAIL_GROUP; }
+
 extern "C" int dsnt_conv_bf16x6_ok(const dsnt_conv_geom* g) {
     if (!g) return 0;
     return g->Cin % BK6 == 0 && g->Cout % 4 == 0 && g->R * g->S * 2 <= 32 &&
@@ -940,7 +946,7 @@ static int check_geom(const dsnt_conv_geom* g, const char* who) {
 template <bool PRO>
 __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ float part[8][32][33];
+    __shared__ __attribute__((aligned(16))) float part[8][32][33];
     const int nt32 = (p.Cout + 31) >> 5;
     const int ntile = blockIdx.x % nt32, mtile = blockIdx.x / nt32;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1053,9 +1059,10 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int w = 0; w < 16; ++w) { a0 += red[(w * 32 + tid) * 2 + 0]; a1 += red[(w * 32 + tid) * 2 + 1]; }
-            p.stats[((size_t)mtile * 2 + 0) * p.Cout + n] = a0;
-            p.stats[((size_t)mtile * 2 + 1) * p.Cout + n] = a1;
+            tail_store(p.stats + ((size_t)mtile * 2 + 0) * p.Cout + n, a0);
+            tail_store(p.stats + ((size_t)mtile * 2 + 1) * p.Cout + n, a1);
         }
+        if (p.tail.counters) bn_tail_run<512>(p.tail, p.stats, p.mtiles, p.Cout, p.M, mtile, nt32, &part[0][0][0]);
     }
 }
 
@@ -1069,7 +1076,8 @@ static long ksplit_rows() {
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, float* y,
                          const float* in_scale, const float* in_shift, int in_relu,
                          const float* res1, const float* res2, float* stats_partial,
-                         const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, void* stream) {
+                         const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, const dsnt_bn_tail* g_tail,
+                         void* stream) {
     if (int e = check_geom(g, "dsnt_conv_fwd")) return e;
     DSNT_REQUIRE(!g_bnb || (g_bnb->x && g_bnb->scale && g_bnb->shift && g_bnb->mean && g_bnb->invstd &&
                             stats_partial && !res1 && !res2 && !bias), DSNT_ERR_ARG,
@@ -1090,6 +1098,9 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
         p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
         p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
     }
+    if (int e = bn_tail_fill(p.tail, g_tail, "dsnt_conv_fwd_ex")) return e;
+    DSNT_REQUIRE(!p.tail.counters || (stats_partial && p.tail.mode == (g_bnb ? 1 : 0)), DSNT_ERR_ARG,
+                 "dsnt_conv_fwd_ex: a dsnt_bn_tail needs stats_partial; mode 1 goes with the batch-norm-backward epilogue");
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
@@ -1114,14 +1125,15 @@ extern "C" int dsnt_conv_fwd(const float* x, const float* w, const float* bias, 
                              const float* in_scale, const float* in_shift, int in_relu,
                              const float* res1, const float* res2, float* stats_partial,
                              const dsnt_conv_geom* g, void* stream) {
-    return conv_fwd_impl(x, w, bias, y, in_scale, in_shift, in_relu, res1, res2, stats_partial, g, nullptr, stream);
+    return conv_fwd_impl(x, w, bias, y, in_scale, in_shift, in_relu, res1, res2, stats_partial, g, nullptr, nullptr, stream);
 }
 
 extern "C" int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y,
                                 const float* in_scale, const float* in_shift, int in_relu,
                                 const float* res1, const float* res2, float* stats_partial,
-                                const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream) {
-    return conv_fwd_impl(x, w, bias, y, in_scale, in_shift, in_relu, res1, res2, stats_partial, g, bnb, stream);
+                                const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail,
+                                void* stream) {
+    return conv_fwd_impl(x, w, bias, y, in_scale, in_shift, in_relu, res1, res2, stats_partial, g, bnb, tail, stream);
 }
 
 
@@ -1385,8 +1397,8 @@ extern "C" int dsnt_debug_force_gemm6(int on) { g_force_gemm6 = on != 0; return 
 static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_stride, const float* bias, float* y,
                           const float* in_scale, const float* in_shift, int in_relu,
                           const float* res1, const float* res2, float* stats_partial,
-                          const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, void* stream,
-                          const float* a_bound = nullptr, const float* w_bound = nullptr) {
+                          const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, const dsnt_bn_tail* g_tail,
+                          void* stream, const float* a_bound = nullptr, const float* w_bound = nullptr) {
     if (int e = check_geom(g, "dsnt_conv_fwd_bf16x6")) return e;
     DSNT_REQUIRE(!g_bnb || (g_bnb->x && g_bnb->scale && g_bnb->shift && g_bnb->mean && g_bnb->invstd &&
                             stats_partial && !res1 && !res2 && !bias), DSNT_ERR_ARG,
@@ -1412,6 +1424,9 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
         p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
         p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
     }
+    if (int e = bn_tail_fill(p.tail, g_tail, "dsnt_conv_fwd_bf16x6_ex")) return e;
+    DSNT_REQUIRE(!p.tail.counters || (stats_partial && p.tail.mode == (g_bnb ? 1 : 0)), DSNT_ERR_ARG,
+                 "dsnt_conv_fwd_bf16x6_ex: a dsnt_bn_tail needs stats_partial; mode 1 goes with the batch-norm-backward epilogue");
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
@@ -1438,25 +1453,26 @@ extern "C" int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_
                                     const float* res1, const float* res2, float* stats_partial,
                                     const dsnt_conv_geom* g, void* stream) {
     return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
-                          stats_partial, g, nullptr, stream);
+                          stats_partial, g, nullptr, nullptr, stream);
 }
 
 extern "C" int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* bias,
                                        float* y, const float* in_scale, const float* in_shift, int in_relu,
                                        const float* res1, const float* res2, float* stats_partial,
-                                       const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream) {
+                                       const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail,
+                                       void* stream) {
     return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
-                          stats_partial, g, bnb, stream);
+                          stats_partial, g, bnb, tail, stream);
 }
 
 extern "C" int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
                                       const float* a_bound, const float* bias, float* y, const float* in_scale,
                                       const float* in_shift, int in_relu, const float* res1, const float* res2,
                                       float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
-                                      void* stream) {
+                                      const dsnt_bn_tail* tail, void* stream) {
     DSNT_REQUIRE(a_bound && w_bound, DSNT_ERR_ARG, "dsnt_conv_fwd_f16x3_ex: the operand bounds (device scalars) are required");
     return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
-                          stats_partial, g, bnb, stream, a_bound, w_bound);
+                          stats_partial, g, bnb, tail, stream, a_bound, w_bound);
 }
 
 // max |src[i]| -> out[0] (bit pattern of a non-negative float: integer max is float max)

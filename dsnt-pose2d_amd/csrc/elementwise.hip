@@ -5,6 +5,7 @@
 // reduction is produced (partials are combined in fp64 by the finalise kernels: deterministic,
 // no atomics).
 #include "common.h"
+#include "bn_tail.h"
 
 #define TILE_ROWS 128
 
@@ -94,8 +95,8 @@ extern "C" int dsnt_bn_stats(const float* x, float* partial, int64_t M, int C, v
 template <int OP>
 __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                             float* __restrict__ y, unsigned char* __restrict__ idx,
-                                                            float* __restrict__ partial, int N, int Ho, int Wo, int C) {
-    __shared__ float red[256 * 8];
+                                                            float* partial, int N, int Ho, int Wo, int C, BnTailP tail) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 8];
     const int tid = threadIdx.x;
     const int C4 = C >> 2;
     const int cgs = C4 < 256 ? C4 : 256;
@@ -151,14 +152,18 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
                 for (int e = 0; e < 8; ++e) acc[e] += red[(j * cgs + tid) * 8 + e];
             float* p0 = partial + ((size_t)blockIdx.x * 2 + 0) * C + (size_t)(cg0 + tid) * 4;
             float* p1 = partial + ((size_t)blockIdx.x * 2 + 1) * C + (size_t)(cg0 + tid) * 4;
-            *reinterpret_cast<float4*>(p0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            *reinterpret_cast<float4*>(p1) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            tail_store4(p0, make_float4(acc[0], acc[1], acc[2], acc[3]));      // write-through: see bn_tail.h
+            tail_store4(p1, make_float4(acc[4], acc[5], acc[6], acc[7]));
         }
     }
+    if (tail.counters) bn_tail_run<256>(tail, partial, (int)((M + TILE_ROWS - 1) / TILE_ROWS), C, M, blockIdx.x, 1, red);
 }
 
 extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* partial, int N, int H, int W,
-                                       int C, void* stream) {
+                                       int C, const dsnt_bn_tail* g_tail, void* stream) {
+    BnTailP tail;
+    if (int e = bn_tail_fill(tail, g_tail, "dsnt_maxpool2_fwd_stats")) return e;
+    DSNT_REQUIRE(!tail.counters || tail.mode == 0, DSNT_ERR_ARG, "dsnt_maxpool2_fwd_stats: dsnt_bn_tail must be mode 0");
     DSNT_REQUIRE(x && y && idx && partial && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
                  "dsnt_maxpool2_fwd_stats: bad argument");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_fwd_stats: H and W must be even (got %dx%d)", H, W);
@@ -166,12 +171,15 @@ extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, f
                  (((uintptr_t)idx) & 3) == 0, DSNT_ERR_ALIGN, "dsnt_maxpool2_fwd_stats: alignment");
     const long M = (long)N * (H / 2) * (W / 2);
     hipLaunchKernelGGL(tile_op_stats_kernel<0>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
-                       (hipStream_t)stream, x, nullptr, y, idx, partial, N, H / 2, W / 2, C);
+                       (hipStream_t)stream, x, nullptr, y, idx, partial, N, H / 2, W / 2, C, tail);
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_fwd_stats");
 }
 
 extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, float* out, float* partial, int N,
-                                            int H, int W, int C, void* stream) {
+                                            int H, int W, int C, const dsnt_bn_tail* g_tail, void* stream) {
+    BnTailP tail;
+    if (int e = bn_tail_fill(tail, g_tail, "dsnt_upsample2_add_fwd_stats")) return e;
+    DSNT_REQUIRE(!tail.counters || tail.mode == 0, DSNT_ERR_ARG, "dsnt_upsample2_add_fwd_stats: dsnt_bn_tail must be mode 0");
     DSNT_REQUIRE(up && low && out && partial && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
                  "dsnt_upsample2_add_fwd_stats: bad argument");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_upsample2_add_fwd_stats: H and W must be even");
@@ -179,7 +187,7 @@ extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, f
                  dsnt_aligned16(partial), DSNT_ERR_ALIGN, "dsnt_upsample2_add_fwd_stats: alignment");
     const long M = (long)N * H * W;
     hipLaunchKernelGGL(tile_op_stats_kernel<1>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
-                       (hipStream_t)stream, up, low, out, nullptr, partial, N, H, W, C);
+                       (hipStream_t)stream, up, low, out, nullptr, partial, N, H, W, C, tail);
     DSNT_CHECK_LAUNCH("dsnt_upsample2_add_fwd_stats");
 }
 

@@ -34,6 +34,17 @@ class BnBwdEpilogue(C.Structure):
 
 BP = C.POINTER(BnBwdEpilogue)
 
+
+class BnTail(C.Structure):
+    """dsnt_bn_tail: the BatchNorm bookkeeping a statistics-producing launch finishes in its last workgroup."""
+    _fields_ = [('mode', C.c_int), ('accumulate', C.c_int), ('counters', C.c_void_p), ('level2', C.c_void_p),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
+                ('momentum', C.c_float), ('eps', C.c_float),
+                ('out0', C.c_void_p), ('out1', C.c_void_p), ('out2', C.c_void_p), ('out3', C.c_void_p)]
+
+
+TP = C.POINTER(BnTail)
+
 # name -> argtypes (the trailing `void* stream` included where the C signature has it)
 SIGNATURES = {
     'dsnt_preact_fwd': [P, P, L, I, I, F, F, P],
@@ -58,13 +69,13 @@ SIGNATURES = {
     'dsnt_head_loss_rows': [P, P, P, P, P, L, I, I, F, I, P],
     'dsnt_head_bwd': [P, P, P, P, P, P, P, L, I, I, F, I, P],
     'dsnt_conv_fwd': [P, P, P, P, P, P, I, P, P, P, GP, P],
-    'dsnt_conv_fwd_ex': [P, P, P, P, P, P, I, P, P, P, GP, BP, P],
-    'dsnt_conv_fwd_bf16x6_ex': [P, P, L, P, P, P, P, I, P, P, P, GP, BP, P],
+    'dsnt_conv_fwd_ex': [P, P, P, P, P, P, I, P, P, P, GP, BP, TP, P],
+    'dsnt_conv_fwd_bf16x6_ex': [P, P, L, P, P, P, P, I, P, P, P, GP, BP, TP, P],
     'dsnt_conv_pack_dgrad': [P, P, I, I, I, I, P],
     'dsnt_conv_pack_dgrad_all': [P, I, P, P, P, L, P],
     'dsnt_conv_fwd_bf16x6': [P, P, L, P, P, P, P, I, P, P, P, GP, P],
     'dsnt_split_bf16x3': [P, P, L, P],
-    'dsnt_conv_fwd_f16x3_ex': [P, P, L, P, P, P, P, P, P, I, P, P, P, GP, BP, P],
+    'dsnt_conv_fwd_f16x3_ex': [P, P, L, P, P, P, P, P, P, I, P, P, P, GP, BP, TP, P],
     'dsnt_amax': [P, L, P, P],
     'dsnt_split_f16x2': [P, P, L, L, P, P],
     'dsnt_f16_prep_weights': [P, I, P],
@@ -87,8 +98,8 @@ SIGNATURES = {
     'dsnt_upsample2_bwd_amax': [P, P, I, I, I, I, I, P, P],
     'dsnt_maxpool2_fwd': [P, P, P, I, I, I, I, P],
     'dsnt_maxpool2_bwd': [P, P, P, I, I, I, I, I, P],
-    'dsnt_maxpool2_fwd_stats': [P, P, P, P, I, I, I, I, P],
-    'dsnt_upsample2_add_fwd_stats': [P, P, P, P, I, I, I, I, P],
+    'dsnt_maxpool2_fwd_stats': [P, P, P, P, I, I, I, I, TP, P],
+    'dsnt_upsample2_add_fwd_stats': [P, P, P, P, I, I, I, I, TP, P],
     'dsnt_maxpool3s2_fwd': [P, P, P, I, I, I, I, P],
     'dsnt_maxpool3s2_bwd': [P, P, P, I, I, I, I, I, P],
     'dsnt_bn_add_act_fwd': [P, P, P, P, I, P, L, I, P],
@@ -116,6 +127,7 @@ PLAIN = {
     'dsnt_version': (I, []),
     'dsnt_last_error': (C.c_char_p, []),
     'dsnt_conv_fwd_bm': (I, [GP]),
+    'dsnt_bn_tail_group': (I, []),
     'dsnt_conv_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_splits': (I, [GP]),

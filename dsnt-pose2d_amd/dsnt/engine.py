@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvGeom, BnBwdEpilogue
+from ._lib import ConvGeom, BnBwdEpilogue, BnTail
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -32,13 +32,14 @@ BN_MOMENTUM = 0.1
 
 class Act:
     """An activation on the tape: NHWC buffer + lazily created gradient / batch statistics."""
-    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax')
+    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'stats_tail')
 
     def __init__(self, buf, name=''):
         self.buf = buf
         self.N, self.H, self.W, self.C = buf.shape
         self.grad = None        # torch tensor once some backward op has written it
         self.stats = None       # (partial tensor, ntiles)
+        self.stats_tail = None  # BnTail of the launch that writes `stats`: the first BatchNorm over this tensor claims it
         self.grad_amax = None   # fp16x3: device scalar max|grad| when ONE bn-backward apply wrote the whole gradient
         self.name = name
 
@@ -130,6 +131,18 @@ class Tape:
         # step launch by launch and hold each bound against the operand it must dominate (tests/test_bounds_gpu.py)
         self.f16_uses = []
         self._pending_group_uses = []
+        # BatchNorm finalisation folded into the producers' last workgroup (csrc/bn_tail.h); DSNT_BN_TAIL=0: separate
+        # dsnt_bn_finalize / dsnt_bn_bwd_finalize launches as before (A/B switch)
+        self.use_tail = os.environ.get('DSNT_BN_TAIL', '1') != '0'
+        # ... for producers of up to DSNT_BN_TAIL_ROWS rows.  Default 0 = off: measured on MI355X (hg2, batch 32) the
+        # 193 finalise launches are NOT on the critical path of an untraced step — 16.53 ms without tails, 16.69 ms with
+        # tails on every launch of <= 32768 rows (507 launches/step instead of 651), 16.80 ms with tails everywhere (460)
+        # — although under rocprofv3's kernel trace, which stretches every launch boundary, tails win 1.1 ms/step.
+        # Every workgroup of a tailed launch drains its stores and draws a ticket before it retires (~3 us).
+        self.tail_rows = int(os.environ.get('DSNT_BN_TAIL_ROWS', '0'))
+        self._tail_group = self.lib.dsnt_bn_tail_group()
+        self._tail_counters = torch.zeros(1 << 16, dtype=torch.int32, device=device)   # arrival tickets, self-resetting
+        self._tail_used = 0
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float32):
@@ -211,6 +224,24 @@ class Tape:
         prep, self.fwd = self.fwd, saved
         self.fwd[pos:pos] = prep
 
+    def new_tail(self):
+        """A disabled dsnt_bn_tail to hand to a statistics-producing launch; `claim_tail` switches it on."""
+        return BnTail() if (self.use_tail and self.training) else None
+
+    def claim_tail(self, tail, mode, tiles, Cc, rows):
+        """Give `tail` its tickets and scratch (launch arguments are read at launch time, so this may happen after the
+        producer was put on the list).  Returns False if it is already taken, tails are off or the launch is too large."""
+        if tail is None or tail.counters or rows > self.tail_rows:
+            return False
+        groups = (tiles + self._tail_group - 1) // self._tail_group
+        assert self._tail_used + 1 + groups <= self._tail_counters.numel()
+        cnt = self._tail_counters[self._tail_used:self._tail_used + 1 + groups]
+        self._tail_used += 1 + groups
+        level2 = self.empty(groups * 2 * Cc, dtype=torch.float64)
+        tail.mode = mode
+        tail.counters, tail.level2 = cnt.data_ptr(), level2.data_ptr()
+        return True
+
     def _use6(self, g):
         return (self.use_bf16x6 and g.N * g.Ho * g.Wo >= self.bf16x6_min_rows and
                 bool(self.lib.dsnt_conv_bf16x6_ok(C.byref(g))))
@@ -227,7 +258,7 @@ class Tape:
         for a in args:
             if isinstance(a, torch.Tensor):
                 conv.append(_lib.ptr(a))
-            elif isinstance(a, (ConvGeom, BnBwdEpilogue)):
+            elif isinstance(a, (ConvGeom, BnBwdEpilogue, BnTail)):
                 self._keep.append(a)
                 conv.append(C.byref(a))
             else:
@@ -275,7 +306,7 @@ class Tape:
         if not self.use_lanes:
             return x
         xb = Act(x.buf, x.name + '/branch')
-        xb.stats = x.stats
+        xb.stats, xb.stats_tail = x.stats, x.stats_tail
         if self.training:
             def join_grad():
                 if xb.grad is not None:
@@ -383,6 +414,8 @@ class Tape:
                 probe(entry)
             rc = fn(*args, ptrs[lane])
             if rc != 0:
+                torch.cuda.synchronize()
+                self._tail_counters.zero_()      # a list cut short may leave arrival tickets half-counted
                 raise RuntimeError('%s failed (%d): %s' % (
                     name, rc, _lib.load().dsnt_last_error().decode()))
         if self.use_lanes:
@@ -445,16 +478,38 @@ class Tape:
         n.mean, n.invstd, n.scale, n.shift = (self.empty(bn.C) for _ in range(4))
         if self.training:
             part, tiles = self.ensure_stats(x)
-            self.f('dsnt_bn_finalize', part, tiles, x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
-                   bn.momentum, bn.eps, 1, n.mean, n.invstd, n.scale, n.shift)
+            tl = x.stats_tail
+            if self.claim_tail(tl, 0, tiles, bn.C, x.M):
+                # the launch that writes `part` finishes this BatchNorm itself (its last workgroup): no finalise launch
+                tl.gamma, tl.beta = _lib.ptr(bn.gamma), _lib.ptr(bn.beta)
+                tl.running_mean, tl.running_var = _lib.ptr(bn.rmean), _lib.ptr(bn.rvar)
+                tl.momentum, tl.eps = bn.momentum, bn.eps
+                tl.out0, tl.out1, tl.out2, tl.out3 = (_lib.ptr(v) for v in (n.mean, n.invstd, n.scale, n.shift))
+            else:
+                self.f('dsnt_bn_finalize', part, tiles, x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
+                       bn.momentum, bn.eps, 1, n.mean, n.invstd, n.scale, n.shift)
         else:
             self.f('dsnt_bn_finalize', None, 0, x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
                    bn.momentum, bn.eps, 0, n.mean, n.invstd, n.scale, n.shift)
         return n
 
-    def _norm_backward(self, n, da, reduced=None):
+    def bwd_tail(self, n, tiles):
+        """dsnt_bn_tail (mode 1) for a data-gradient launch with the BatchNorm-backward epilogue of Normed n: its last
+        workgroup writes dgamma / dbeta / coef; None if tails are off.  Returns (tail, coef)."""
+        bn = n.bn
+        coef = self.scratch('bncoef', 2 * bn.C)
+        tl = self.new_tail()
+        if not self.claim_tail(tl, 1, tiles, bn.C, n.x.M):
+            return None, coef
+        tl.accumulate = 1 if bn.uses > 0 else 0
+        bn.uses += 1
+        tl.out0, tl.out1, tl.out2 = _lib.ptr(bn.ggamma), _lib.ptr(bn.gbeta), _lib.ptr(coef)
+        return tl, coef
+
+    def _norm_backward(self, n, da, reduced=None, finalised=False):
         """Given da = dL/d relu(bn(x)), accumulate dx into n.x.grad and dgamma/dbeta.  With
-        `reduced` = (partials, ntiles) the producer already masked da by the ReLU and reduced it."""
+        `reduced` = (partials, ntiles) the producer already masked da by the ReLU and reduced it; with `finalised` it
+        also wrote dgamma / dbeta / coef (bwd_tail)."""
         x, bn = n.x, n.bn
         coef = self.scratch('bncoef', 2 * bn.C)
         relu = 1 if n.relu else 0
@@ -466,9 +521,10 @@ class Tape:
             part = self.scratch('bnpart', tiles * 2 * bn.C).view(-1)
             self.b('dsnt_bn_act_bwd_reduce', da, x.buf, n.scale, n.shift, n.mean, n.invstd, relu, part,
                    x.M, bn.C)
-        acc_p = 1 if bn.uses > 0 else 0
-        bn.uses += 1
-        self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef)
+        if not finalised:
+            acc_p = 1 if bn.uses > 0 else 0
+            bn.uses += 1
+            self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef)
         buf, acc = self.grad_target(x, amax='apply')
         if x.grad_amax is not None:
             self.b('dsnt_bn_act_bwd_apply_amax', da, x.buf, n.scale, n.shift, n.mean, n.invstd, coef, relu,
@@ -486,13 +542,14 @@ class Tape:
         sc = src.scale if normed else None
         sh = src.shift if normed else None
         relu = 1 if (normed and src.relu) else 0
-        part = None
+        part, tail = None, None
         use6 = self._use6(g) and p.wq is not None
         if want_stats and self.training:
             bm = 128 if use6 else self.lib.dsnt_conv_fwd_bm(C.byref(g))
             tiles = (y.M + bm - 1) // bm
             part = self.empty(tiles, 2, p.Cout)
             y.stats = (part, tiles)
+            y.stats_tail = tail = self.new_tail()
         r1 = res1.buf if res1 is not None else None
         r2 = res2.buf if res2 is not None else None
         if self.use_f16x3 and self.training and normed:
@@ -501,13 +558,14 @@ class Tape:
         if use16:
             self.f16_weights(p)
             e = self.f('dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, self.f16_bn_bound(src), p.b, y.buf,
-                       sc, sh, relu, r1, r2, part, g, None)
+                       sc, sh, relu, r1, r2, part, g, None, tail)
             self.f16_uses.append((e, dict(kind='fwd', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=src.abound,
                                           w=p.w, w_bound=p.wb)))
         elif use6:
-            self.f('dsnt_conv_fwd_bf16x6', x.buf, p.wq, p.wq_stride, p.b, y.buf, sc, sh, relu, r1, r2, part, g)
+            self.f('dsnt_conv_fwd_bf16x6_ex', x.buf, p.wq, p.wq_stride, p.b, y.buf, sc, sh, relu, r1, r2, part, g,
+                   None, tail)
         else:
-            self.f('dsnt_conv_fwd', x.buf, p.w, p.b, y.buf, sc, sh, relu, r1, r2, part, g)
+            self.f('dsnt_conv_fwd_ex', x.buf, p.w, p.b, y.buf, sc, sh, relu, r1, r2, part, g, None, tail)
         if not self.training:
             return y
         slot = None
@@ -604,16 +662,16 @@ class Tape:
                     wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
                     self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total])
 
-                def dgrad(out, res, part=None, bnb=None):
+                def dgrad(out, res, part=None, bnb=None, tail=None):
                     if d16:
                         e = self.b('dsnt_conv_fwd_f16x3_ex', gsrc, wq16, self.dgrad_total, wbd, g_amax, None, out, None,
-                                   None, 0, res, None, part, gd, bnb)
+                                   None, 0, res, None, part, gd, bnb, tail)
                         self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
                     elif d6:
                         self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
-                               part, gd, bnb)
+                               part, gd, bnb, tail)
                     else:
-                        self.b('dsnt_conv_fwd_ex', gsrc, wd, None, out, None, None, 0, res, None, part, gd, bnb)
+                        self.b('dsnt_conv_fwd_ex', gsrc, wd, None, out, None, None, 0, res, None, part, gd, bnb, tail)
                 if normed:
                     # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
                     # data-gradient epilogue; only finalise + apply remain as separate launches
@@ -623,8 +681,9 @@ class Tape:
                     part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
                     bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
                                         _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
-                    dgrad(dz, None, part, bnb)
-                    self._norm_backward(src, dz, reduced=(part, tiles))
+                    tl, _ = self.bwd_tail(src, tiles)
+                    dgrad(dz, None, part, bnb, tl)
+                    self._norm_backward(src, dz, reduced=(part, tiles), finalised=tl is not None)
                 else:
                     buf, acc = self.grad_target(x)
                     dgrad(buf, buf if acc else None)
@@ -658,7 +717,8 @@ class Tape:
             # the consumer is a BatchNorm (hourglass.py:33): its batch statistics ride in the same pass
             tiles = (y.M + 127) // 128
             part = self.empty(tiles, 2, x.C)
-            self.f('dsnt_maxpool2_fwd_stats', x.buf, y.buf, idx, part, x.N, x.H, x.W, x.C)
+            y.stats_tail = self.new_tail()
+            self.f('dsnt_maxpool2_fwd_stats', x.buf, y.buf, idx, part, x.N, x.H, x.W, x.C, y.stats_tail)
             y.stats = (part, tiles)
         else:
             self.f('dsnt_maxpool2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
@@ -709,7 +769,8 @@ class Tape:
         if self.training and self.fuse_op_stats:
             tiles = (out.M + 127) // 128
             part = self.empty(tiles, 2, up.C)
-            self.f('dsnt_upsample2_add_fwd_stats', up.buf, low.buf, out.buf, part, up.N, up.H, up.W, up.C)
+            out.stats_tail = self.new_tail()
+            self.f('dsnt_upsample2_add_fwd_stats', up.buf, low.buf, out.buf, part, up.N, up.H, up.W, up.C, out.stats_tail)
             out.stats = (part, tiles)
         else:
             self.f('dsnt_upsample2_add_fwd', up.buf, low.buf, out.buf, up.N, up.H, up.W, up.C)

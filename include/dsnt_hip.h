@@ -38,6 +38,26 @@ typedef enum {
     DSNT_ERR_HIP = 4          /* hipGetLastError() after launch */
 } dsnt_status;
 
+/* Optional tail of a launch that leaves per-tile partial sums for a BatchNorm: the LAST workgroup to arrive
+ * (agent-scope release/acquire ticket, csrc/bn_tail.h) adds the partials — in tile order, fp64, whatever the arrival
+ * order — and does what dsnt_bn_finalize (mode 0) / dsnt_bn_bwd_finalize (mode 1) would do in a launch of their own
+ * (hourglass.py:33-43: every conv is preceded by BN -> ReLU; 193 such launches per hg2 train step otherwise).
+ * counters: [1 + (mtiles + 31) / 32] uint32, zero before the first launch (the tail re-zeroes them);
+ * level2:   [(mtiles + 31) / 32][2][C] doubles of scratch;
+ * mode 0: gamma/beta (may be NULL), running_mean/var (both or neither), momentum, eps -> out0..3 = mean, invstd,
+ *         scale, shift [C];  mode 1: out0 = dgamma, out1 = dbeta (either may be NULL; += if accumulate),
+ *         out2 = coef [2][C] (sum dz / M, sum dz*xhat / M).  counters == NULL (or a NULL struct): no tail. */
+typedef struct {
+    int mode, accumulate;
+    unsigned* counters;
+    double* level2;
+    const float* gamma; const float* beta; float* running_mean; float* running_var;
+    float momentum, eps;
+    float* out0; float* out1; float* out2; float* out3;
+} dsnt_bn_tail;
+/* m-tiles whose partial rows one first-level reduction covers (32) */
+int dsnt_bn_tail_group(void);
+
 int dsnt_version(void);
 const char* dsnt_last_error(void);
 
@@ -145,7 +165,9 @@ typedef struct {
 int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y,
                      const float* in_scale, const float* in_shift, int in_relu,
                      const float* res1, const float* res2, float* stats_partial,
-                     const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream);
+                     const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail, void* stream);
+/* (`tail`, here and in the other _ex variants: the BatchNorm bookkeeping over stats_partial done by the launch's last
+ * workgroup — forward statistics of the consumer BatchNorm, or with `bnb` the dgamma / dbeta / coef of the backward.) */
 
 /* Rows per stats_partial tile that dsnt_conv_fwd uses for this geometry (128 or 32): the
  * caller sizes stats_partial as [ceil(M/bm)][2][Cout] and hands ceil(M/bm) to dsnt_bn_finalize. */
@@ -167,7 +189,8 @@ int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_t plane_str
 int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* bias,
                             float* y, const float* in_scale, const float* in_shift, int in_relu,
                             const float* res1, const float* res2, float* stats_partial,
-                            const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream);
+                            const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail,
+                            void* stream);
 
 /* fp16x3 variant: x * s = h1 + h2 on TWO fp16 planes after a power-of-two scale, three MFMAs per product (error vs
  * fp64 below a plain fp32 GEMM's: conv.hip, tools/split_numerics.py).  a_bound / w_bound are DEVICE scalars >= the
@@ -180,7 +203,8 @@ int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int64_t plane_
 int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
                            const float* a_bound, const float* bias, float* y, const float* in_scale,
                            const float* in_shift, int in_relu, const float* res1, const float* res2,
-                           float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, void* stream);
+                           float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
+                           const dsnt_bn_tail* tail, void* stream);
 /* out[0..63] = bound slots whose maximum is max |src[i]|; dst = two fp16 planes (plane_stride elements apart) of src * pow2(bound). */
 int dsnt_amax(const float* src, int64_t n, float* out, void* stream);
 int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t plane_stride, const float* bound, void* stream);
@@ -355,9 +379,9 @@ int dsnt_upsample2_bwd(const float* dout, float* dlow, int accumulate,
  * hourglass is a BatchNorm: hourglass.py:33,78-90): partial[ceil(M/128)][2][C] exactly as dsnt_bn_stats over the
  * stored result would give (bit-identical), M = output pixels. */
 int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* partial, int N, int H, int W, int C,
-                            void* stream);
+                            const dsnt_bn_tail* tail, void* stream);
 int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, float* out, float* partial, int N, int H, int W,
-                                 int C, void* stream);
+                                 int C, const dsnt_bn_tail* tail, void* stream);
 
 /* y (+)= a*x, flat; n % 4 == 0 not required. */
 int dsnt_axpy(const float* x, float* y, float a, int accumulate, int64_t n, void* stream);

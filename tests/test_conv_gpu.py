@@ -221,10 +221,10 @@ def test_pool_upsample(N, H, W, Cc):
         part, want = torch.empty(tiles, 2, Cc, device=dev), torch.empty(tiles, 2, Cc, device=dev)
         if name.startswith('dsnt_maxpool'):
             idx2 = torch.empty_like(idx)
-            call(name, *args_plain, ptr(res2), ptr(idx2), ptr(part), N, H, W, Cc)
+            call(name, *args_plain, ptr(res2), ptr(idx2), ptr(part), N, H, W, Cc, None)
             assert torch.equal(idx2, idx)
         else:
-            call(name, *args_plain, ptr(res2), ptr(part), N, H, W, Cc)
+            call(name, *args_plain, ptr(res2), ptr(part), N, H, W, Cc, None)
         call('dsnt_bn_stats', ptr(res), ptr(want), M, Cc)
         assert torch.equal(res2, res)
         assert torch.equal(part, want)
@@ -441,7 +441,7 @@ def test_conv_f16x3_matches_fp32_accuracy(case, pro, loose):
     M = N * g.Ho * g.Wo
     stats = torch.zeros((M + 127) // 128, 2, Cout, device=dev)
     call('dsnt_conv_fwd_f16x3_ex', ptr(xd), ptr(planes), wd.numel(), ptr(wb), ptr(ab), ptr(bd), ptr(y),
-         ptr(scd) if pro else None, ptr(shd) if pro else None, 1, ptr(resd), None, ptr(stats), C.byref(g), None)
+         ptr(scd) if pro else None, ptr(shd) if pro else None, 1, ptr(resd), None, ptr(stats), C.byref(g), None, None)
     got = y.cpu().permute(0, 3, 1, 2)
     scale = y32.abs().max().item()
     assert (got - (y32 + res)).abs().max().item() <= 2e-5 * scale
@@ -551,9 +551,24 @@ BNB_CASES = [
 ]
 
 
+def _make_tail(mode, tiles, Cc, dev, **fields):
+    """A dsnt_bn_tail with its tickets and scratch; returns (struct, keep-alive tensors)."""
+    from dsnt import _lib
+    grp = _lib.fn('dsnt_bn_tail_group')()
+    groups = (tiles + grp - 1) // grp
+    counters = torch.zeros(1 + groups, dtype=torch.int32, device=dev)
+    level2 = torch.empty(groups * 2 * Cc, dtype=torch.float64, device=dev)
+    t = _lib.BnTail()
+    t.mode, t.counters, t.level2 = mode, counters.data_ptr(), level2.data_ptr()
+    for k, v in fields.items():
+        setattr(t, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return t, (counters, level2)
+
+
 @pytest.mark.parametrize('case', BNB_CASES)
 @pytest.mark.parametrize('path', ['f32', 'bf16x6', 'f16x3'])
-def test_bn_backward_epilogue_with_relu_vs_autograd(case, path):
+@pytest.mark.parametrize('use_tail', [False, True])
+def test_bn_backward_epilogue_with_relu_vs_autograd(case, path, use_tail):
     """ONE layer x -> BatchNorm(train) -> ReLU -> conv, backward through the production chain with the ReLU ON:
     data-gradient launch with the BN-backward epilogue (ReLU mask + the two per-channel sums) -> finalise ->
     apply, against torch autograd (fp64).  A single layer has no flip amplification, so the bars are tight
@@ -602,12 +617,18 @@ def test_bn_backward_epilogue_with_relu_vs_autograd(case, path):
     g = _geom(N, H, W, Cout, Cin, k, k, 1, pad, 1)
     bnb = BnBwdEpilogue(ptr(xd), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), 1)
     dz = torch.empty(N, H, W, Cin, device=dev)
+    dgamma, dbeta = torch.empty(Cin, device=dev), torch.empty(Cin, device=dev)
+    coef = torch.empty(2, Cin, device=dev)
+    bm = _lib.fn('dsnt_conv_fwd_bm')(C.byref(g)) if path == 'f32' else 128
+    tail, keep = None, None
+    if use_tail:        # the launch's last workgroup writes dgamma / dbeta / coef itself (csrc/bn_tail.h)
+        tail_s, keep = _make_tail(1, (M + bm - 1) // bm, Cin, dev, out0=dgamma, out1=dbeta, out2=coef)
+        tail = C.byref(tail_s)
     if path == 'f32':
-        bm = _lib.fn('dsnt_conv_fwd_bm')(C.byref(g))
         tiles_d = (M + bm - 1) // bm
         part_d = torch.zeros(tiles_d, 2, Cin, device=dev)
         call('dsnt_conv_fwd_ex', ptr(gyd), ptr(wdg), None, ptr(dz), None, None, 0, None, None, ptr(part_d),
-             C.byref(g), C.byref(bnb))
+             C.byref(g), C.byref(bnb), tail)
     else:
         if not _lib.fn('dsnt_conv_bf16x6_ok')(C.byref(g)):
             pytest.skip('geometry not supported by the split-precision kernels')
@@ -617,7 +638,7 @@ def test_bn_backward_epilogue_with_relu_vs_autograd(case, path):
             planes = torch.empty(3 * wdg.numel(), dtype=torch.bfloat16, device=dev)
             call('dsnt_split_bf16x3', ptr(wdg), ptr(planes), wdg.numel())
             call('dsnt_conv_fwd_bf16x6_ex', ptr(gyd), ptr(planes), wdg.numel(), None, ptr(dz), None, None, 0, None,
-                 None, ptr(part_d), C.byref(g), C.byref(bnb))
+                 None, ptr(part_d), C.byref(g), C.byref(bnb), tail)
         else:
             wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
             call('dsnt_amax', ptr(wdg), wdg.numel(), ptr(wb))
@@ -625,7 +646,7 @@ def test_bn_backward_epilogue_with_relu_vs_autograd(case, path):
             planes = torch.empty(2 * wdg.numel(), dtype=torch.float16, device=dev)
             call('dsnt_split_f16x2', ptr(wdg), ptr(planes), wdg.numel(), wdg.numel(), ptr(wb))
             call('dsnt_conv_fwd_f16x3_ex', ptr(gyd), ptr(planes), wdg.numel(), ptr(wb), ptr(ab), None, ptr(dz), None,
-                 None, 0, None, None, ptr(part_d), C.byref(g), C.byref(bnb))
+                 None, 0, None, None, ptr(part_d), C.byref(g), C.byref(bnb), tail)
     # dz = dL/d(bn output) masked by the ReLU: autograd's gradient at the BN output
     dz_ref = torch.autograd.grad(F.conv2d(F.relu(zz := z.clone().requires_grad_()), w.double(), None, padding=pad),
                                  zz, gy.double())[0]
@@ -633,9 +654,14 @@ def test_bn_backward_epilogue_with_relu_vs_autograd(case, path):
     s_dz = dz_ref.abs().max().item()
     assert (dz.cpu().permute(0, 3, 1, 2).double() - dz_ref).abs().max().item() <= tol * s_dz
     assert float((dz == 0).float().mean()) > 0.2          # the mask really is on
-    dgamma, dbeta = torch.empty(Cin, device=dev), torch.empty(Cin, device=dev)
-    coef = torch.empty(2, Cin, device=dev)
-    call('dsnt_bn_bwd_finalize', ptr(part_d), tiles_d, M, Cin, ptr(dgamma), ptr(dbeta), 0, ptr(coef))
+    if use_tail:
+        assert int(keep[0].abs().max()) == 0               # every ticket counter is back at zero
+        ref = [torch.empty_like(dgamma), torch.empty_like(dbeta), torch.empty_like(coef)]
+        call('dsnt_bn_bwd_finalize', ptr(part_d), tiles_d, M, Cin, ptr(ref[0]), ptr(ref[1]), 0, ptr(ref[2]))
+        for got_, want_ in zip((dgamma, dbeta, coef), ref):      # same sums as the stand-alone launch (fp64, other order)
+            assert (got_ - want_).abs().max().item() <= 1e-6 * max(1.0, want_.abs().max().item())
+    else:
+        call('dsnt_bn_bwd_finalize', ptr(part_d), tiles_d, M, Cin, ptr(dgamma), ptr(dbeta), 0, ptr(coef))
     dx = torch.empty(N, H, W, Cin, device=dev)
     call('dsnt_bn_act_bwd_apply', ptr(dz), ptr(xd), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(coef), 0,
          ptr(dx), 0, M, Cin)
@@ -643,3 +669,90 @@ def test_bn_backward_epilogue_with_relu_vs_autograd(case, path):
     assert (dbeta.cpu().double() - br.grad).abs().max().item() <= tol * max(1.0, br.grad.abs().max().item())
     s_dx = xr.grad.abs().max().item()
     assert (dx.cpu().permute(0, 3, 1, 2).double() - xr.grad).abs().max().item() <= tol * s_dx
+
+
+@pytest.mark.parametrize('kind', ['conv_f32_128', 'conv_f32_32x128', 'conv_ksplit', 'conv_bf16x6', 'conv_halo_f16x3',
+                                  'maxpool', 'upsample'])
+def test_bn_tail_forward_matches_the_finalize_launch(kind):
+    """Forward statistics finished by the producer's last workgroup (dsnt_bn_tail mode 0) == dsnt_bn_finalize over the
+    same partial sums: mean / invstd / scale / shift and the running statistics, for every kind of producer; a second
+    launch (tickets must have re-armed themselves) gives bit-identical vectors and moves the running statistics on."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    dev = torch.device('cuda:0')
+    shapes = {'conv_f32_128': (4, 32, 32, 64, 128, 3), 'conv_f32_32x128': (2, 16, 16, 128, 256, 1),
+              'conv_ksplit': (2, 8, 8, 128, 128, 3), 'conv_bf16x6': (4, 64, 64, 128, 256, 1),
+              'conv_halo_f16x3': (8, 64, 64, 128, 128, 3), 'maxpool': (6, 32, 32, 0, 256, 0), 'upsample': (6, 32, 32, 0, 256, 0)}
+    N, H, W, Cin, Cout, k = shapes[kind]
+    gamma = (synthetic.tensor('bt.g', (Cout,), seed=50, kind='uniform') + 1.5).to(dev)
+    beta = (synthetic.tensor('bt.b', (Cout,), seed=50) * 0.2).to(dev)
+
+    def run(tail):
+        """launch the producer with `tail` (or None); returns (partials, tiles, M)"""
+        if kind.startswith('conv'):
+            g = _geom(N, H, W, Cin, Cout, k, k, 1, k // 2, 1)
+            x = synthetic.tensor('bt.x', (N, H, W, Cin), seed=51).to(dev)
+            w = (synthetic.tensor('bt.w', (Cout, k, k, Cin), seed=51) * 0.05).to(dev)
+            b = (synthetic.tensor('bt.bias', (Cout,), seed=51) * 0.1).to(dev)
+            y = torch.empty(N, H, W, Cout, device=dev)
+            M = N * H * W
+            bm = _lib.fn('dsnt_conv_fwd_bm')(C.byref(g)) if 'f32' in kind or kind == 'conv_ksplit' else 128
+            tiles = (M + bm - 1) // bm
+            part = torch.zeros(tiles, 2, Cout, device=dev)
+            if kind in ('conv_f32_128', 'conv_f32_32x128', 'conv_ksplit'):
+                call('dsnt_conv_fwd_ex', ptr(x), ptr(w), ptr(b), ptr(y), None, None, 0, None, None, ptr(part), C.byref(g),
+                     None, tail)
+            elif kind == 'conv_bf16x6':
+                planes = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=dev)
+                call('dsnt_split_bf16x3', ptr(w), ptr(planes), w.numel())
+                call('dsnt_conv_fwd_bf16x6_ex', ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y), None, None, 0, None, None,
+                     ptr(part), C.byref(g), None, tail)
+            else:
+                wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+                call('dsnt_amax', ptr(w), w.numel(), ptr(wb))
+                call('dsnt_amax', ptr(x), x.numel(), ptr(ab))
+                planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+                call('dsnt_split_f16x2', ptr(w), ptr(planes), w.numel(), w.numel(), ptr(wb))
+                call('dsnt_conv_fwd_f16x3_ex', ptr(x), ptr(planes), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), None, None,
+                     0, None, None, ptr(part), C.byref(g), None, tail)
+            torch.cuda.synchronize()
+            return part, tiles, M
+        x = synthetic.tensor('bt.px', (N, H, W, Cout), seed=52).to(dev)
+        if kind == 'maxpool':
+            M = N * (H // 2) * (W // 2)
+            tiles = (M + 127) // 128
+            part = torch.zeros(tiles, 2, Cout, device=dev)
+            y = torch.empty(N, H // 2, W // 2, Cout, device=dev)
+            idx = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.uint8, device=dev)
+            call('dsnt_maxpool2_fwd_stats', ptr(x), ptr(y), ptr(idx), ptr(part), N, H, W, Cout, tail)
+        else:
+            M = N * H * W
+            tiles = (M + 127) // 128
+            part = torch.zeros(tiles, 2, Cout, device=dev)
+            low = synthetic.tensor('bt.low', (N, H // 2, W // 2, Cout), seed=53).to(dev)
+            y = torch.empty(N, H, W, Cout, device=dev)
+            call('dsnt_upsample2_add_fwd_stats', ptr(x), ptr(low), ptr(y), ptr(part), N, H, W, Cout, tail)
+        torch.cuda.synchronize()
+        return part, tiles, M
+
+    part0, tiles, M = run(None)
+    want = [torch.empty(Cout, device=dev) for _ in range(4)]
+    rm_w, rv_w = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    call('dsnt_bn_finalize', ptr(part0), tiles, M, Cout, ptr(gamma), ptr(beta), ptr(rm_w), ptr(rv_w), 0.1, 1e-5, 1,
+         *(ptr(v) for v in want))
+    got = [torch.full((Cout,), float('nan'), device=dev) for _ in range(4)]
+    rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    tail_s, keep = _make_tail(0, tiles, Cout, dev, gamma=gamma, beta=beta, running_mean=rm, running_var=rv,
+                              momentum=0.1, eps=1e-5, out0=got[0], out1=got[1], out2=got[2], out3=got[3])
+    part1, _, _ = run(C.byref(tail_s))
+    assert torch.equal(part0, part1) and int(keep[0].abs().max()) == 0
+    for a, b, nm in zip(got, want, ('mean', 'invstd', 'scale', 'shift')):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), (kind, nm)
+    assert (rm - rm_w).abs().max().item() <= 1e-6 and (rv - rv_w).abs().max().item() <= 1e-6 * max(1.0, float(rv_w.max()))
+    first = [g_.clone() for g_ in got]
+    rm1 = rm.clone()
+    for g_ in got:
+        g_.fill_(float('nan'))
+    run(C.byref(tail_s))                                   # tickets re-armed themselves
+    assert all(torch.equal(a, b) for a, b in zip(got, first)) and int(keep[0].abs().max()) == 0
+    assert (rm - (0.9 * rm1 + 0.1 * first[0])).abs().max().item() <= 1e-6

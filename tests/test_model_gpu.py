@@ -174,7 +174,7 @@ def test_end_to_end_vs_golden(base, size, reg, tag, mfma_path):
     with torch.no_grad():
         ev = m(x)[-1].cpu().numpy()
     assert np.abs(ev - g['eval_coords']).max() <= 1e-4
-    n6 = _count_launches(m.hg, 'dsnt_conv_fwd_bf16x6')
+    n6 = _count_launches(m.hg, 'dsnt_conv_fwd_bf16x6') + _count_launches(m.hg, 'dsnt_conv_fwd_bf16x6_ex')
     n16 = _count_launches(m.hg, 'dsnt_conv_fwd_f16x3_ex')
     if mfma_path == 'bf16x6':
         assert n6 > 100 and n16 == 0
@@ -359,6 +359,40 @@ def test_data_parallel_world1_nccl():
             assert torch.equal(grads(), g0)
     finally:
         dist.destroy_process_group()
+
+
+def test_bn_tails_give_the_same_step(monkeypatch):
+    """BatchNorm finalisation folded into the producers' last workgroup (DSNT_BN_TAIL_ROWS, csrc/bn_tail.h) against the
+    stand-alone finalise launches: same loss / coordinates / gradients to fp32 rounding (the fp64 partial sums are added
+    in another order), ~190 launches fewer, bit-reproducible."""
+    from dsnt.model import build_mpii_pose_model
+
+    def step(rows):
+        monkeypatch.setenv('DSNT_BN_TAIL_ROWS', str(rows))
+        m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+        synthetic.fill_state_dict(m, seed=0)
+        m.cuda().train()
+        x, t, k = synthetic.batch(4, size=128, seed=1, mask_p=0.9)
+        res = []
+        for _ in range(2):
+            for p in m.parameters():
+                p.grad = None
+            out = m(x.to(DEV))
+            loss = m.forward_loss(out, t.to(DEV), k.to(DEV))
+            loss.backward()
+            res.append((loss.item(), out[-1].detach().clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()))
+        prog = [p for p in m.hg._runner().programs.values() if p.training][0]
+        rs = {n: b.clone() for n, b in m.named_buffers() if 'running' in n}
+        return res, prog.n_fwd + prog.n_bwd, rs
+    (a0, a1), n_a, rs_a = step(0)
+    (b0, b1), n_b, rs_b = step(10 ** 9)
+    assert n_a - n_b >= 150, (n_a, n_b)
+    assert abs(a0[0] - b0[0]) <= 1e-6 * abs(a0[0]) and (a0[1] - b0[1]).abs().max().item() <= 2e-6
+    assert (a0[2] - b0[2]).norm().item() <= 1e-4 * a0[2].norm().item()
+    for n in rs_a:
+        assert (rs_a[n] - rs_b[n]).abs().max().item() <= 1e-5 * max(1.0, rs_a[n].abs().max().item()), n
+    # the two forward/backward passes of each model differ only through the running statistics (not used in train mode)
+    assert b0[0] == b1[0] and torch.equal(b0[1], b1[1]) and torch.equal(b0[2], b1[2])
 
 
 def test_optimizer_kernels():

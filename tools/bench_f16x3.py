@@ -36,7 +36,7 @@ for (H, Cin, Cout, k) in shapes:
         scp, shp = (ptr(sc), ptr(sh)) if pro else (None, None)
         a32 = (ptr(x), ptr(w), ptr(b), ptr(y32), scp, shp, 1, None, None, ptr(stats), C.byref(g))
         a6 = (ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y6), scp, shp, 1, None, None, ptr(stats), C.byref(g))
-        a16 = (ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y16), scp, shp, 1, None, None, ptr(stats), C.byref(g), None)
+        a16 = (ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y16), scp, shp, 1, None, None, ptr(stats), C.byref(g), None, None)
         t32 = timeit(_lib.fn('dsnt_conv_fwd'), a32); t6 = timeit(_lib.fn('dsnt_conv_fwd_bf16x6'), a6)
         t16 = timeit(_lib.fn('dsnt_conv_fwd_f16x3_ex'), a16)
         sc_ = y6.abs().max().item()

@@ -28,7 +28,7 @@ for _ in range(5):
     if which == 'fwd6':
         _lib.fn('dsnt_conv_fwd_bf16x6')(ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
     elif which == 'fwd16':
-        _lib.fn('dsnt_conv_fwd_f16x3_ex')(ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None, st)
+        _lib.fn('dsnt_conv_fwd_f16x3_ex')(ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None, None, st)
     elif which == 'wgrad16':
         _lib.fn('dsnt_conv_wgrad_f16x3')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g), st)
     elif which == 'wgrad6':

@@ -34,7 +34,7 @@ if os.environ.get('TL_F16'):      # fp16x3 form of the same kernel
     assert _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(wq16), w.numel(), w.numel(), ptr(wb), st) == 0
     ab.fill_(float(torch.relu(x * sc + sh).max()) * 4.0)
     fn = _lib.fn('dsnt_conv_fwd_f16x3_ex')
-    args = (ptr(x), ptr(wq16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None)
+    args = (ptr(x), ptr(wq16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None, None)
 else:
     fn = _lib.fn('dsnt_conv_fwd_bf16x6')
     args = (ptr(x), ptr(wq), w.numel(), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g))
