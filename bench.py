@@ -265,7 +265,7 @@ def head_roofline(batch=1024, iters=10):
     ms = e0.elapsed_time(e1) / iters
     nbytes = 4.0 * rows * 64 * 64 * 4
     gbs = nbytes / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernels': 'head_fwd + head_loss_rows + head_bwd (+ masked averages)', 'batch': batch,
+    return {'bound': 'hbm', 'kernels': 'head_fwd + head_loss_grad (+ loss reduce, gradient rescale) through dsnt.nn autograd', 'batch': batch,
             'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbs / 8000.0, 4),
             'frac_of_measured_copy_peak_6290': round(gbs / 6290.0, 4), 'algorithmic_bytes': nbytes,
             'ms_fwd_loss_bwd': round(ms, 4)}

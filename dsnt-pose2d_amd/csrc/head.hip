@@ -37,6 +37,28 @@ struct Row {
             }
         }
     }
+    // f(slot, index, value) for every element this thread owns (CACHED rows only): slot = 0..15 is a compile-time
+    // constant after unrolling, so per-element temporaries indexed by it live in registers
+    template <typename F>
+    __device__ __forceinline__ void each_slot(F f) const {
+        const int tid = threadIdx.x;
+        if (VEC == 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = (k * HB + tid) * 4;
+                if (i < hw) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f(4 * k + e, i + e, v[4 * k + e]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = k * HB + tid;
+                if (i < hw) f(k, i, v[k]);
+            }
+        }
+    }
     // f(index, value) for every element this thread owns
     template <typename F>
     __device__ __forceinline__ void each(F f) const {
@@ -63,6 +85,17 @@ struct Row {
         }
     }
 };
+
+// exp(x) for x <= 0 on the hardware exp2 (v_exp_f32, <= 1 ulp) with a compensated x * log2(e): the product is formed
+// as t + r with t = fl(x L), r = fma(x, L, -t) + x L_lo, so the argument error (|x| 2^-24 for a plain multiply: 2e-6
+// relative at x = -30) does not reach the result: e^x = 2^t (1 + r ln 2).  ~6 instructions instead of libm's ~25.
+__device__ __forceinline__ float fast_exp(float x) {
+    const float L = 1.44269502162933349609375f, Ll = 1.92596299112661746e-8f;
+    const float t = x * L;
+    const float r = fmaf(x, Ll, fmaf(x, L, -t));
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, r * 0.69314718055994530942f, e);
+}
 
 struct Grid2 {
     int W, H; float offx, offy;
@@ -404,13 +437,42 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(const float* __restrict__ 
     row.each([&](int, float v) { m = fmaxf(m, v); });
     m = block_max(m, red);
     float s[1] = {0.f};
-    row.each([&](int, float v) { s[0] += expf(v - m); });
+    if (CACHED) {
+        // one exponential per element: they replace the logits in the row registers
+#pragma unroll
+        for (int k = 0; k < 16; ++k) row.v[k] = fast_exp(row.v[k] - m);
+        row.each([&](int, float e) { s[0] += e; });
+    } else {
+        row.each([&](int, float v) { s[0] += expf(v - m); });
+    }
     block_sum<1>(s, red);
     const float denom = s[0];
     const Grid2 g(h, w);
     float* out = hm + off;
     float c[2] = {0.f, 0.f};
-    if (CACHED && VEC == 4) {
+    if (CACHED && VEC == 4 && (w & 3) == 0) {
+        // four consecutive pixels of one heat-map row per 16-byte store: one division for the position, the
+        // normalisation as a multiplication by 1 / sum (one more rounding than e / sum: <= 1 ulp)
+        const float inv = 1.f / denom;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = (k * HB + threadIdx.x) * 4;
+            if (i < hw) {
+                const int rr = i / w, cc = i - rr * w;
+                const float y = (2.f * rr - g.offy) / (float)h;
+                float p[4], px = 0.f, ps = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p[e] = row.v[4 * k + e] * inv;
+                    const float x = (2.f * (cc + e) - g.offx) / (float)w;
+                    px = fmaf(x, p[e], px);
+                    ps += p[e];
+                }
+                c[0] += px; c[1] = fmaf(y, ps, c[1]);
+                *reinterpret_cast<float4*>(out + i) = make_float4(p[0], p[1], p[2], p[3]);
+            }
+        }
+    } else if (CACHED && VEC == 4) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = (k * HB + threadIdx.x) * 4;
@@ -418,7 +480,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(const float* __restrict__ 
                 float p[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    p[e] = expf(row.v[4 * k + e] - m) / denom;
+                    p[e] = row.v[4 * k + e] / denom;
                     float x, y; g.xy(i + e, x, y);
                     c[0] = fmaf(x, p[e], c[0]); c[1] = fmaf(y, p[e], c[1]);
                 }
@@ -427,7 +489,7 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(const float* __restrict__ 
         }
     } else {
         row.each([&](int i, float v) {
-            const float p = expf(v - m) / denom;
+            const float p = (CACHED ? v : expf(v - m)) / denom;
             out[i] = p;
             float x, y; g.xy(i, x, y);
             c[0] = fmaf(x, p, c[0]); c[1] = fmaf(y, p, c[1]);
@@ -493,6 +555,172 @@ __global__ __launch_bounds__(HB) void head_bwd_kernel(const float* __restrict__ 
     block_sum<1>(s, red);
     float* out = g_logits + r * hw;
     row.each([&](int i, float p) { out[i] = p * (dLdp(i, p) - s[0]); });
+}
+
+// ------------------------------------------------------------------ fused head loss + its gradient (train step)
+// One pass over the saved heat-maps produces, per row, the Euclidean distance, the regulariser value AND
+//   G0[row] = d( w_row * (dist + reg_coeff * reg) ) / d logits,   w_row = mask_row / clamp(sum mask, 1)
+// i.e. the gradient of this stack's loss for an upstream gradient of 1 (what `loss.backward()` sends;
+// dsnt_scale_by_scalar applies any other value): the train step's head is then 4 HBM passes per stack — logits in,
+// heat-maps out (dsnt_head_fwd), heat-maps in, d logits out — instead of 5 (the heat-maps were read once for the
+// loss rows and once more in backward).  Per-element values are computed ONCE and kept in registers between the
+// reduction sum_j p_j dL/dp_j and the output pass.  JS (the regulariser of BASELINE configs 3-5) has a fast form:
+// the target Gaussian is separable, exp(k((x-tx)^2 + (y-ty)^2)) = ex[w] * ey[h] — W + H exponentials per row in LDS
+// instead of H*W — and the three logarithms per element use the hardware log2 (v_log_f32, <= 1 ulp in log2;
+// arguments are >= 1e-24, normal numbers): with libm logf the kernel was ALU-bound at twice its HBM time.
+#define HEAD_SEP_MAX 512          // W + H up to which the separable factors fit the static LDS array
+#define LN2 0.69314718055994530942f
+
+template <int VEC>
+__global__ __launch_bounds__(HB) void head_loss_grad_kernel(const float* __restrict__ hm, const float* __restrict__ coords,
+                                                            const float* __restrict__ target, const float* __restrict__ mask,
+                                                            const float* __restrict__ denom_p, float* __restrict__ dist_out,
+                                                            float* __restrict__ reg_out, float* __restrict__ g0, int h, int w,
+                                                            float sigma, float k, int kind, float reg_coeff) {
+    __shared__ float red[16];
+    __shared__ __attribute__((aligned(16))) float exy[HEAD_SEP_MAX];
+    const size_t r = blockIdx.x;
+    const int hw = h * w;
+    // the row's scalars first, then the 16 KB row: everything is in flight together
+    const float tx = target[2 * r], ty = target[2 * r + 1];
+    const float cx = coords[2 * r], cy = coords[2 * r + 1];
+    const float mk = mask ? mask[r] : 1.f;
+    const float den = denom_p[1];
+    Row<VEC, true> row;
+    row.load(hm + r * hw, hw);
+    const Grid2 g(h, w);
+    const float dxm = cx - tx, dym = cy - ty;
+    const float d = sqrtf(dxm * dxm + dym * dym);
+    const float wm = mk / den;
+    // un-guarded like the reference: dist == 0 with wm != 0 gives NaN (nn.py:113-114)
+    const float f = wm / (2.f * d);
+    const float ax = f * (2.f * dxm), ay = f * (2.f * dym);
+    const float gr = kind >= 0 ? wm * reg_coeff : 0.f;
+    float gv[16];
+    float acc[2] = {0.f, 0.f};              // regulariser value, sum_j p_j dL/dp_j
+    if (kind == 0 && w + h <= HEAD_SEP_MAX) {
+        // separable target Gaussian: ex[0..w), ey[0..h)
+        for (int i = threadIdx.x; i < w + h; i += HB) {
+            const float t = i < w ? (2.f * i - g.offx) / (float)w - tx : (2.f * (i - w) - g.offy) / (float)h - ty;
+            exy[i] = expf(t * t * k);
+        }
+        __syncthreads();
+        float sxy[2] = {0.f, 0.f};
+        for (int i = threadIdx.x; i < w + h; i += HB) sxy[i < w ? 0 : 1] += exy[i];
+        block_sum<2>(sxy, red);
+        const float invz = 1.f / (sxy[0] * sxy[1] + 1e-24f);
+        auto elem = [&](int slot, float p, float x, float y, float qx, float qy) {
+            const float q = qx * qy;
+            const float m = 0.5f * (p + q);
+            // logarithms in the log2 domain (v_log_f32), ln 2 folded into the two places they are used
+            const float lm = __builtin_amdgcn_logf(m + REG_EPS);
+            const float dp = __builtin_amdgcn_logf(p + REG_EPS) - lm, dq = __builtin_amdgcn_logf(q + REG_EPS) - lm;
+            acc[0] = fmaf(0.5f * LN2, fmaf(p, dp, q * dq), acc[0]);
+            const float dr = 0.5f * (fmaf(LN2, dp, p * __builtin_amdgcn_rcpf(p + REG_EPS)) - m * __builtin_amdgcn_rcpf(m + REG_EPS));
+            const float v = fmaf(ax, x, ay * y) + gr * dr;
+            gv[slot] = v;
+            acc[1] = fmaf(p, v, acc[1]);
+        };
+        if (VEC == 4 && (w & 3) == 0) {
+            // four consecutive pixels of one heat-map row per thread and chunk: one division for the position
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int i = (kk * HB + threadIdx.x) * 4;
+                if (i < hw) {
+                    const int rr = i / w, cc = i - rr * w;
+                    const float y = (2.f * rr - g.offy) / (float)h;
+                    const float qy = exy[w + rr] * invz;
+                    const float4 qx = *reinterpret_cast<const float4*>(exy + cc);
+                    const float qxs[4] = {qx.x, qx.y, qx.z, qx.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        elem(4 * kk + e, row.v[4 * kk + e], (2.f * (cc + e) - g.offx) / (float)w, y, qxs[e], qy);
+                }
+            }
+        } else {
+            row.each_slot([&](int slot, int i, float p) {
+                const int rr = i / w, cc = i - rr * w;
+                elem(slot, p, (2.f * cc - g.offx) / (float)w, (2.f * rr - g.offy) / (float)h, exy[cc], exy[w + rr] * invz);
+            });
+        }
+        block_sum<2>(acc, red);
+    } else {
+        RegCtx c = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float val = 0.f;
+        if (kind >= 0) {
+            c = reg_context(row, g, tx, ty, k, kind, red);
+            val = reg_value(row, g, c, tx, ty, k, sigma, kind, red);
+        }
+        row.each_slot([&](int slot, int i, float p) {
+            float x, y; g.xy(i, x, y);
+            float v = ax * x + ay * y;
+            if (kind >= 0 && gr != 0.f) v += gr * reg_grad(p, x, y, c, tx, ty, k, sigma, kind);
+            gv[slot] = v;
+            acc[1] = fmaf(p, v, acc[1]);
+        });
+        float s1[1] = {acc[1]};
+        block_sum<1>(s1, red);
+        acc[0] = val; acc[1] = s1[0];
+    }
+    float* out = g0 + r * hw;
+    if (VEC == 4) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int i = (kk * HB + threadIdx.x) * 4;
+            if (i < hw)
+                *reinterpret_cast<float4*>(out + i) = make_float4(row.v[4 * kk] * (gv[4 * kk] - acc[1]), row.v[4 * kk + 1] * (gv[4 * kk + 1] - acc[1]),
+                                                                  row.v[4 * kk + 2] * (gv[4 * kk + 2] - acc[1]), row.v[4 * kk + 3] * (gv[4 * kk + 3] - acc[1]));
+        }
+    } else {
+        row.each_slot([&](int slot, int i, float p) { out[i] = p * (gv[slot] - acc[1]); });
+    }
+    if (threadIdx.x == 0) {
+        dist_out[r] = d;
+        if (reg_out) reg_out[r] = acc[0];
+    }
+}
+
+// out2 = {sum m / max(sum m, 1) [unused], max(sum m, 1)} for a mask (or n for no mask): the denominator of
+// masked_average (nn.py:81-94) as a device scalar for the kernel above
+__global__ __launch_bounds__(HB) void mask_denom_kernel(const float* __restrict__ m, float* __restrict__ out2, long n) {
+    __shared__ float red[16];
+    float s[1] = {0.f};
+    for (long i = threadIdx.x; i < n; i += HB) s[0] += m ? m[i] : 1.f;
+    block_sum<1>(s, red);
+    if (threadIdx.x == 0) { out2[0] = s[0]; out2[1] = fmaxf(s[0], 1.f); }
+}
+
+// loss[0] = sum(dist m) / denom + reg_coeff sum(reg m) / denom; e2 = {sum(dist m) / denom, denom} (what
+// dsnt_masked_avg_fwd leaves for its backward): the two masked averages and their combination in one launch
+__global__ __launch_bounds__(HB) void head_loss_reduce_kernel(const float* __restrict__ dist, const float* __restrict__ reg,
+                                                              const float* __restrict__ m, const float* __restrict__ denom2,
+                                                              float reg_coeff, float* __restrict__ loss, float* __restrict__ e2,
+                                                              long n) {
+    __shared__ float red[16];
+    float s[2] = {0.f, 0.f};
+    for (long i = threadIdx.x; i < n; i += HB) {
+        const float wgt = m ? m[i] : 1.f;
+        s[0] += m ? dist[i] * wgt : dist[i];
+        if (reg) s[1] += m ? reg[i] * wgt : reg[i];
+    }
+    block_sum<2>(s, red);
+    if (threadIdx.x == 0) {
+        const float den = denom2[1];
+        const float a = s[0] / den;
+        e2[0] = a; e2[1] = den;
+        loss[0] = reg ? a + reg_coeff * (s[1] / den) : a;
+    }
+}
+
+// x *= s[0] unless s[0] == 1 (then the kernel returns at once: the usual `loss.backward()` costs no memory pass)
+__global__ void scale_by_scalar_kernel(float4* __restrict__ x, const float* __restrict__ s, long n4) {
+    const float a = s[0];
+    if (a == 1.f) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = x[i];
+        v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+        x[i] = v;
+    }
 }
 
 // ------------------------------------------------------------------ host wrappers
@@ -649,6 +877,47 @@ extern "C" int dsnt_head_bwd(const float* hm, const float* coords, const float* 
     ROW_DISPATCH(head_bwd_kernel, (int)rows, h * w, dsnt_aligned16(hm), hm, coords, target, dist, g_dist, g_reg,
                  g_logits, h, w, sigma, gauss_k(sigma), reg_kind);
     DSNT_CHECK_LAUNCH("dsnt_head_bwd");
+}
+
+extern "C" int dsnt_mask_denom(const float* mask, float* denom2, int64_t n, void* stream) {
+    DSNT_REQUIRE(denom2 && n > 0, DSNT_ERR_ARG, "dsnt_mask_denom: bad argument");
+    hipLaunchKernelGGL(mask_denom_kernel, dim3(1), dim3(HB), 0, (hipStream_t)stream, mask, denom2, (long)n);
+    DSNT_CHECK_LAUNCH("dsnt_mask_denom");
+}
+
+extern "C" int dsnt_head_loss_grad(const float* hm, const float* coords, const float* target, const float* mask,
+                                   const float* denom2, float* dist, float* reg_row, float* g_logits, int64_t rows, int h, int w,
+                                   float sigma, int reg_kind, float reg_coeff, void* stream) {
+    DSNT_REQUIRE(hm && coords && target && denom2 && dist && g_logits && (reg_kind < 0 || reg_row), DSNT_ERR_ARG,
+                 "dsnt_head_loss_grad: null tensor");
+    DSNT_REQUIRE(reg_kind >= -1 && reg_kind <= 3, DSNT_ERR_ARG, "dsnt_head_loss_grad: unknown regulariser %d", reg_kind);
+    if (int e = check_rows("dsnt_head_loss_grad", rows, h, w)) return e;
+    DSNT_REQUIRE((long)h * w <= 4096, DSNT_ERR_SHAPE, "dsnt_head_loss_grad: heat-maps of up to 4096 pixels (got %dx%d); use "
+                 "dsnt_head_loss_rows + dsnt_head_bwd for larger ones", h, w);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = ((h * w) % 4 == 0) && dsnt_aligned16(hm) && dsnt_aligned16(g_logits);
+    if (vec) hipLaunchKernelGGL(head_loss_grad_kernel<4>, dim3((int)rows), dim3(HB), 0, st, hm, coords, target, mask, denom2, dist,
+                                reg_row, g_logits, h, w, sigma, gauss_k(sigma), reg_kind, reg_coeff);
+    else hipLaunchKernelGGL(head_loss_grad_kernel<1>, dim3((int)rows), dim3(HB), 0, st, hm, coords, target, mask, denom2, dist,
+                            reg_row, g_logits, h, w, sigma, gauss_k(sigma), reg_kind, reg_coeff);
+    DSNT_CHECK_LAUNCH("dsnt_head_loss_grad");
+}
+
+extern "C" int dsnt_head_loss_reduce(const float* dist, const float* reg_row, const float* mask, const float* denom2,
+                                     float reg_coeff, float* loss, float* e2, int64_t rows, void* stream) {
+    DSNT_REQUIRE(dist && denom2 && loss && e2 && rows > 0, DSNT_ERR_ARG, "dsnt_head_loss_reduce: bad argument");
+    hipLaunchKernelGGL(head_loss_reduce_kernel, dim3(1), dim3(HB), 0, (hipStream_t)stream, dist, reg_row, mask, denom2, reg_coeff,
+                       loss, e2, (long)rows);
+    DSNT_CHECK_LAUNCH("dsnt_head_loss_reduce");
+}
+
+extern "C" int dsnt_scale_by_scalar(float* x, const float* s, int64_t n, void* stream) {
+    DSNT_REQUIRE(x && s && n > 0 && n % 4 == 0 && dsnt_aligned16(x), DSNT_ERR_ARG,
+                 "dsnt_scale_by_scalar: n must be a positive multiple of 4, x 16-byte aligned");
+    long gsz = (n / 4 + 255) / 256;
+    if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, (float4*)x, s, (long)(n / 4));
+    DSNT_CHECK_LAUNCH("dsnt_scale_by_scalar");
 }
 
 // ---------------------------------------------------------------- 'fc' output strategy

@@ -68,6 +68,10 @@ SIGNATURES = {
     'dsnt_head_fwd': [P, P, P, L, I, I, P],
     'dsnt_head_loss_rows': [P, P, P, P, P, L, I, I, F, I, P],
     'dsnt_head_bwd': [P, P, P, P, P, P, P, L, I, I, F, I, P],
+    'dsnt_head_loss_grad': [P, P, P, P, P, P, P, P, L, I, I, F, I, F, P],
+    'dsnt_mask_denom': [P, P, L, P],
+    'dsnt_head_loss_reduce': [P, P, P, P, F, P, P, L, P],
+    'dsnt_scale_by_scalar': [P, P, L, P],
     'dsnt_conv_fwd': [P, P, P, P, P, P, I, P, P, P, GP, P],
     'dsnt_conv_fwd_ex': [P, P, P, P, P, P, I, P, P, P, GP, BP, TP, P],
     'dsnt_conv_fwd_bf16x6_ex': [P, P, L, P, P, P, P, I, P, P, P, GP, BP, TP, P],

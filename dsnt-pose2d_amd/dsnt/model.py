@@ -117,14 +117,18 @@ class HourglassHumanPoseModel(HumanPoseModel):
     def forward_loss(self, out_vars, target_var, mask_var):
         if self.output_strat == 'dsnt' or self.output_strat == 'fc':
             total_loss = 0
+            denom2 = None            # the masked-average denominator: one tiny launch shared by all stacks
             for i, out_var in enumerate(out_vars):
                 fused = self._fused.get(id(out_var))
                 if fused is not None and fused[2] is out_var:
                     logits, hm, coords = fused
                     sigma = 2.0 * self.hm_sigma / hm.size(-1)
+                    if denom2 is None:
+                        m_ = None if mask_var is None else mask_var.to(torch.float32).expand(coords.shape[:-1])
+                        denom2 = dnn.mask_denominator(m_, coords.numel() // 2, hm.device)
                     total_loss = total_loss + dnn.head_loss(
                         logits, hm.detach(), coords.detach(), target_var, mask_var, self.reg,
-                        sigma, self.reg_coeff)
+                        sigma, self.reg_coeff, denom2)
                 else:
                     loss = dnn.euclidean_loss(out_var, target_var, mask_var)
                     reg_loss = self._calculate_reg_loss(

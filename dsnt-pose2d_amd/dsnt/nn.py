@@ -358,45 +358,67 @@ def head_forward(logits):
 
 
 class _HeadLoss(Function):
-    """euclidean_loss + reg_coeff * reg_loss for one stack, straight from the logits' saved
-    heat-maps; backward is ONE kernel producing d loss / d logits."""
+    """euclidean_loss + reg_coeff * reg_loss for one stack, straight from the logits' saved heat-maps.
+
+    Train step (gradients wanted, heat-maps of <= 4096 pixels): ONE kernel reads the heat-maps and leaves both the
+    per-row loss terms and d loss / d logits for an upstream gradient of 1 (`dsnt_head_loss_grad`); backward only
+    rescales it when the upstream gradient is not 1 — the heat-maps are read once, not twice (SURVEY.md Appendix A:
+    4 HBM passes per stack).  Otherwise: loss rows now, `dsnt_head_bwd` in backward."""
 
     @staticmethod
-    def forward(ctx, logits, hm, coords, target, mask, kind, sigma, reg_coeff):
+    def forward(ctx, logits, hm, coords, target, mask, kind, sigma, reg_coeff, denom2):
         h, w = hm.shape[-2], hm.shape[-1]
         rows = _rows(hm, 2)
         t = f32(target).expand_as(coords).contiguous()
         m = None if mask is None else f32(mask).expand(coords.shape[:-1]).contiguous()
         dist = torch.empty(rows, device=hm.device, dtype=hm.dtype)
         reg = torch.empty(rows, device=hm.device, dtype=hm.dtype) if kind >= 0 else None
-        call('dsnt_head_loss_rows', ptr(hm), ptr(coords), ptr(t), ptr(dist), ptr(reg), rows, h, w,
-             sigma, kind)
-        e2 = torch.empty(2, device=hm.device, dtype=hm.dtype)
-        call('dsnt_masked_avg_fwd', ptr(dist), ptr(m), ptr(e2), rows)
-        loss = e2[0].clone()
-        if kind >= 0:
-            r2 = torch.empty(2, device=hm.device, dtype=hm.dtype)
-            call('dsnt_masked_avg_fwd', ptr(reg), ptr(m), ptr(r2), rows)
-            loss = loss + reg_coeff * r2[0]
+        if denom2 is None:
+            denom2 = mask_denominator(m, rows, hm.device)
+        ctx.g0 = None
+        if ctx.needs_input_grad[0] and h * w <= 4096:
+            g0 = torch.empty_like(hm)
+            call('dsnt_head_loss_grad', ptr(hm), ptr(coords), ptr(t), ptr(m), ptr(denom2), ptr(dist), ptr(reg), ptr(g0),
+                 rows, h, w, sigma, kind, reg_coeff)
+            ctx.g0 = g0
+        else:
+            call('dsnt_head_loss_rows', ptr(hm), ptr(coords), ptr(t), ptr(dist), ptr(reg), rows, h, w,
+                 sigma, kind)
+        out = torch.empty(3, device=hm.device, dtype=hm.dtype)      # [loss, e2[0], e2[1]]
+        e2 = out[1:]
+        call('dsnt_head_loss_reduce', ptr(dist), ptr(reg), ptr(m), ptr(denom2), reg_coeff, ptr(out), ptr(e2), rows)
         ctx.save_for_backward(hm, coords, t, m, dist, e2)
         ctx.kind, ctx.sigma, ctx.reg_coeff = kind, sigma, reg_coeff
-        return loss
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):
         hm, coords, t, m, dist, e2 = ctx.saved_tensors
         h, w = hm.shape[-2], hm.shape[-1]
         rows = _rows(hm, 2)
-        g1 = g.contiguous().view(1)
+        g1 = f32(g).contiguous().view(1)
+        if ctx.g0 is not None:                 # first backward through the fused kernel's gradient: rescale in place
+            g_logits, ctx.g0 = ctx.g0, None
+            call('dsnt_scale_by_scalar', ptr(g_logits), ptr(g1), g_logits.numel())
+            return g_logits, None, None, None, None, None, None, None, None
         g_dist = torch.empty(rows, device=hm.device, dtype=hm.dtype)
         call('dsnt_masked_avg_bwd', ptr(g1), ptr(m), ptr(e2), ptr(g_dist), rows)
         g_reg = (g_dist * ctx.reg_coeff) if ctx.kind >= 0 else None   # same mask and denominator
         g_logits = torch.empty_like(hm)
         call('dsnt_head_bwd', ptr(hm), ptr(coords), ptr(t), ptr(dist), ptr(g_dist), ptr(g_reg),
              ptr(g_logits), rows, h, w, ctx.sigma, ctx.kind)
-        return g_logits, None, None, None, None, None, None, None
+        return g_logits, None, None, None, None, None, None, None, None
 
 
-def head_loss(logits, hm, coords, target, mask, reg, sigma, reg_coeff):
+def mask_denominator(mask, rows, device):
+    """{sum(mask), clamp(sum(mask), 1)} as two device floats (`masked_average`'s denominator, nn.py:81-94; mask None:
+    `rows`): computed once per `forward_loss` call and shared by every stack's head_loss."""
+    m = None if mask is None else f32(mask).contiguous()
+    out = torch.empty(2, device=device, dtype=torch.float32)
+    call('dsnt_mask_denom', ptr(m), ptr(out), rows)
+    return out
+
+
+def head_loss(logits, hm, coords, target, mask, reg, sigma, reg_coeff, denom2=None):
     kind = REG_KINDS.get(reg, -1)
-    return _HeadLoss.apply(logits, hm, coords, target, mask, kind, float(sigma), float(reg_coeff))
+    return _HeadLoss.apply(logits, hm, coords, target, mask, kind, float(sigma), float(reg_coeff), denom2)

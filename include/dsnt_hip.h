@@ -124,6 +124,23 @@ int dsnt_head_fwd(const float* logits, float* hm, float* coords, int64_t rows, i
 int dsnt_head_loss_rows(const float* hm, const float* coords, const float* target,
                         float* dist, float* reg_row, int64_t rows, int h, int w, float sigma,
                         int reg_kind, void* stream);
+/* Fused head, loss AND its gradient in one pass over the saved heat-maps (the train step; model.py:233-246,
+ * train.py:358,381): per row the Euclidean distance and the regulariser value (as dsnt_head_loss_rows) and
+ *   g_logits[row] = d( w_row (dist + reg_coeff reg) ) / d logits,  w_row = mask[row] / clamp(sum mask, 1)
+ * (mask NULL: 1 / max(rows, 1) — nn.py:81-94), i.e. the gradient of this stack's loss for an upstream gradient of 1;
+ * dsnt_scale_by_scalar applies another upstream value.  denom2 = the 2 floats dsnt_mask_denom left ({sum mask, its
+ * clamp}: once per step, every stack shares the mask).  The head of a train step is then 4 HBM passes per stack
+ * instead of 5.  H * W <= 4096. */
+int dsnt_mask_denom(const float* mask, float* denom2, int64_t n, void* stream);
+int dsnt_head_loss_grad(const float* hm, const float* coords, const float* target, const float* mask,
+                        const float* denom2, float* dist, float* reg_row, float* g_logits, int64_t rows, int h, int w,
+                        float sigma, int reg_kind, float reg_coeff, void* stream);
+/* loss[0] = masked_average(dist) + reg_coeff * masked_average(reg_row) (reg_row NULL: no regulariser) in one launch;
+ * e2 = {masked_average(dist), denominator} as dsnt_masked_avg_fwd leaves it. */
+int dsnt_head_loss_reduce(const float* dist, const float* reg_row, const float* mask, const float* denom2,
+                          float reg_coeff, float* loss, float* e2, int64_t rows, void* stream);
+/* x[0..n) *= s[0] (device scalar); returns at once when s[0] == 1. */
+int dsnt_scale_by_scalar(float* x, const float* s, int64_t n, void* stream);
 /* Fused head, backward: d loss / d logits in one pass, given per-row upstream factors
  * g_dist[row] (for the Euclidean term) and g_reg[row] (for the regulariser), i.e.
  * model.py:233-246 + nn.py:66-78 + softmax backward collapsed. */

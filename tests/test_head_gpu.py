@@ -201,6 +201,26 @@ def test_fused_head_vs_oracle(dev, reg, use_mask):
     assert (ld.grad.cpu().double() - lo.grad).abs().max() <= 2e-5 * scale
 
 
+def test_fused_head_upstream_gradient_and_second_backward(dev):
+    """The train-step kernel leaves d loss / d logits for an upstream gradient of 1; any other upstream value rescales
+    it on the device, and a second backward through the same graph (retain_graph) falls back to dsnt_head_bwd."""
+    import dsnt.nn as dn
+    logits, target, mask = _head_inputs(dev)
+    ld = logits.to(dev).requires_grad_()
+    hm, co = dn.head_forward(ld)
+    loss = dn.head_loss(ld, hm.detach(), co.detach(), target.to(dev), mask.to(dev), 'js', 2.0 / 64, 1.0)
+    g1, = torch.autograd.grad(loss, ld, retain_graph=True)              # fused gradient, upstream 1
+    g2, = torch.autograd.grad(loss * 2.5, ld, retain_graph=True)        # second pass: dsnt_head_bwd, upstream 2.5
+    assert (g2 - 2.5 * g1).abs().max().item() <= 2e-5 * 2.5 * g1.abs().max().item()
+    hm2, co2 = dn.head_forward(ld)
+    loss2 = dn.head_loss(ld, hm2.detach(), co2.detach(), target.to(dev), mask.to(dev), 'js', 2.0 / 64, 1.0)
+    g3, = torch.autograd.grad(loss2 * -0.75, ld)                        # fused gradient rescaled in place
+    assert torch.equal(g3, g1 * -0.75)
+    with torch.no_grad():                                               # no gradient wanted: value-only kernel, same loss
+        l3 = dn.head_loss(ld, hm.detach(), co.detach(), target.to(dev), mask.to(dev), 'js', 2.0 / 64, 1.0)
+    assert abs(l3.item() - loss.item()) <= 1e-5 * abs(loss.item())
+
+
 @pytest.mark.parametrize('h,w', [(5, 5), (7, 7), (14, 14), (28, 28), (8, 8), (64, 48), (96, 96)])
 def test_odd_shapes(dev, h, w):
     """Ragged / unaligned rows (ResNet heat-maps 7..28, H*W not a multiple of 4, > 4096)."""
