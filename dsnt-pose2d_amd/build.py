@@ -18,6 +18,11 @@ if os.environ.get('DSNT_TIMELINE'):      # wave timeline stamps in the conv kern
     FLAGS.append('-DDSNT_TIMELINE')
 if os.environ.get('DSNT_TIMELINE') == '2':  # loader stamps split into wait / stage (tools/timeline6.py)
     FLAGS.append('-DDSNT_TIMELINE2')
+# kernel experiments: extra compiler flags and another output name (load it with DSNT_HIP_LIB=<path>), e.g.
+#   DSNT_CXXFLAGS=-DDSNT_WG6U_SCHED DSNT_LIB_NAME=libdsnt_exp.so python dsnt-pose2d_amd/build.py --force
+FLAGS += os.environ.get('DSNT_CXXFLAGS', '').split()
+if os.environ.get('DSNT_LIB_NAME'):
+    LIB = os.path.join(CSRC, os.environ['DSNT_LIB_NAME'])
 
 
 def _newer(a, b):
@@ -29,10 +34,11 @@ def build(force=False, verbose=True):
     deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'bn_tail.h'),
             os.path.join(HERE, '..', 'include', 'dsnt_hip.h'), os.path.join(HERE, '..', 'include', 'dsnt_hip_debug.h')]
     objs, jobs = [], []
-    os.makedirs(os.path.join(CSRC, 'build'), exist_ok=True)
+    bdir = 'build' if not os.environ.get('DSNT_LIB_NAME') else 'build_' + os.path.splitext(os.environ['DSNT_LIB_NAME'])[0]
+    os.makedirs(os.path.join(CSRC, bdir), exist_ok=True)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, 'build', os.path.splitext(src)[0] + '.o')
+        o = os.path.join(CSRC, bdir, os.path.splitext(src)[0] + '.o')
         objs.append(o)
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
             extra = ['-fno-slp-vectorize'] if src == 'conv.hip' else []     # no v_pk_*_f32 beside the MFMAs

@@ -639,7 +639,7 @@ extern "C" int dsnt_split_bf16x3(const float* src, void* dst, int64_t n, void* s
     DSNT_CHECK_LAUNCH("dsnt_split_bf16x3");
 }
 
-template <int WM, int WN, int TM, int TN, bool PRO, bool F16 = false>
+template <int WM, int WN, int TM, int TN, bool PRO, bool F16 = false, int DA = 4>
 __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
     constexpr int NPL = F16 ? 2 : 3;            // operand planes (fp16x3: two fp16 planes, three MFMAs)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -648,6 +648,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* A6 = reinterpret_cast<__bf16*>(smem);          // [2][NPL][BM][PITCH6]
     __bf16* B6 = A6 + 2 * NPL * BM * PITCH6;               // [2][NPL][BN][PITCH6]
+    float* SS = reinterpret_cast<float*>(B6 + 2 * NPL * BN * PITCH6);   // [2][Cin]: BN scale / shift of the A operand
 
     int tile;
     xcd_remap(blockIdx.x, p.mtiles * p.ntiles, tile);
@@ -710,49 +711,72 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
             const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)(NPL - 1) * p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
         // fp16x3: operand scale (a power of two) from the bound the producer left in device memory
         const float sa = F16 ? pow2_scale(bound64(p.a_bound)) : 1.f;
-        struct Stage {
-            u32x4 ra[APASS], rb[NPL];
-            float4 sc, sh;
-            unsigned ok;
-        };
-        Stage S0, S1;
+        // The A operand is what this kernel waits for: with K = 128 ... 256 a tile is 8 ... 16 K-steps, each a fresh
+        // 8 KB slice of activations from HBM, and the chip-wide bytes in flight bound the bandwidth (Little's law: 512
+        // resident workgroups x 2 stages x 8 KB = 8 MB gave 3.6 TB/s at ~2.2 us loaded latency).  DA register stages
+        // keep DA slices per workgroup in flight; the weights (L2 hits) stay on two stages; the BatchNorm scale / shift
+        // vectors live in LDS (copied once, pre-multiplied by the fp16x3 operand scale) instead of riding in every stage.
+        struct AStage { u32x4 ra[APASS]; };
+        struct BStage { u32x4 rb[NPL]; };
+        AStage SA[DA];
+        BStage SB[2];
         const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
-        auto gload = [&](Stage& st, int step) {
-            const int kb = step * BK6;
-            const int tap = kb / p.Cin, cb = kb - tap * p.Cin;
-            const int r = tap / p.S, s_ = tap - r * p.S;
-            const unsigned toff = (unsigned)(((r * p.dil) * p.W + s_ * p.dil) * p.Cin + cb) * 4u;
-            if (PRO) {
-                st.sc = *reinterpret_cast<const float4*>(p.in_scale + cb + kc * 4);
-                st.sh = *reinterpret_cast<const float4*>(p.in_shift + cb + kc * 4);
-                if (F16) {      // relu(x sc + sh) s_a = relu(x (sc s_a) + sh s_a): the scale rides in the BN vectors
-                    st.sc.x *= sa; st.sc.y *= sa; st.sc.z *= sa; st.sc.w *= sa;
-                    st.sh.x *= sa; st.sh.y *= sa; st.sh.z *= sa; st.sh.w *= sa;
-                }
-            }
-            st.ok = vmask >> (tap * APASS);
+        const int last = nsteps - 1;
+        // K-step bookkeeping without divisions: the loads (A: DA steps ahead, B: two ahead) and the stores walk the
+        // K-steps in order, so each keeps running scalars (channel base, filter tap) advanced branch-free and frozen
+        // at the last step (the tail re-loads / re-stores it: never read, or into the idle buffer).  `kb / Cin` and
+        // `tap / S` per call were ~100 instructions of emulated integer division per step on the waves the MFMA
+        // waves wait for.
+        struct Walk { int step, cb, r, s_; };
+        Walk wa = {0, 0, 0, 0}, ws = {0, 0, 0, 0};
+        int wb_step = 0;
+        auto advance = [&](Walk& w) {
+            const int adv = w.step < last ? 1 : 0;
+            w.step += adv;
+            w.cb += adv * BK6;
+            const int wrap = w.cb >= p.Cin ? 1 : 0;
+            w.cb = wrap ? 0 : w.cb;
+            w.s_ += wrap;
+            const int wrap2 = w.s_ == p.S ? 1 : 0;
+            w.s_ = wrap2 ? 0 : w.s_;
+            w.r += wrap2;
+        };
+        auto gloadA = [&](AStage& st) {
+            const unsigned toff = (unsigned)(((wa.r * p.dil) * p.W + wa.s_ * p.dil) * p.Cin + wa.cb) * 4u;
 #pragma unroll
             for (int i = 0; i < APASS; ++i)
                 st.ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, apix[i] + toff, 0, 0);
-            const unsigned koff = (unsigned)kb * 2u;
+            advance(wa);
+        };
+        auto gloadB = [&](BStage& st) {
+            const unsigned koff = (unsigned)(wb_step * BK6) * 2u;
 #pragma unroll
             for (int j = 0; j < NPL; ++j)
                 st.rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bpix[j] + koff, 0, 0);
+            wb_step += wb_step < last ? 1 : 0;
         };
-        auto lstore = [&](const Stage& st, int buf) {
+        auto lstore = [&](const AStage& sa_, const BStage& sb_, int buf) {
+            const int cb = ws.cb;
+            const unsigned okm = vmask >> ((ws.r * p.S + ws.s_) * APASS);
+            advance(ws);
+            float4 sc, sh;
+            if (PRO) {
+                sc = *reinterpret_cast<const float4*>(SS + cb + kc * 4);
+                sh = *reinterpret_cast<const float4*>(SS + p.Cin + cb + kc * 4);
+            }
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
-                float4 v = make_float4(__uint_as_float(st.ra[i].x), __uint_as_float(st.ra[i].y),
-                                       __uint_as_float(st.ra[i].z), __uint_as_float(st.ra[i].w));
+                float4 v = make_float4(__uint_as_float(sa_.ra[i].x), __uint_as_float(sa_.ra[i].y),
+                                       __uint_as_float(sa_.ra[i].z), __uint_as_float(sa_.ra[i].w));
                 uint2 q1, q2, q3;
                 // branch-free zero padding (a divergent branch around the loaded registers makes hipcc
                 // drain vmcnt(0) before the next prefetch: see the fp32 loader)
-                const bool ok = (st.ok >> i) & 1u;
+                const bool ok = (okm >> i) & 1u;
                 if (PRO) {
                     // BN FMAs; ReLU and the padding select as ONE median per element:
                     // valid rows clamp to [0 or -inf, +inf), padded rows to [0, 0]
-                    const sp_f32x2 a = {fmaf(v.x, st.sc.x, st.sh.x), fmaf(v.y, st.sc.y, st.sh.y)};
-                    const sp_f32x2 b = {fmaf(v.z, st.sc.z, st.sh.z), fmaf(v.w, st.sc.w, st.sh.w)};
+                    const sp_f32x2 a = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y)};
+                    const sp_f32x2 b = {fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
                     const float lo = ok ? lo_valid : 0.f, hi = ok ? __builtin_inff() : 0.f;
                     v.x = __builtin_amdgcn_fmed3f(a.x, lo, hi); v.y = __builtin_amdgcn_fmed3f(a.y, lo, hi);
                     v.z = __builtin_amdgcn_fmed3f(b.x, lo, hi); v.w = __builtin_amdgcn_fmed3f(b.y, lo, hi);
@@ -775,51 +799,50 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
             if (brow < BN) {
 #pragma unroll
                 for (int j = 0; j < NPL; ++j)
-                    *reinterpret_cast<u32x4*>(B6 + ((size_t)(buf * NPL + j) * BN + brow) * PITCH6 + bhalf * 8) = st.rb[j];
+                    *reinterpret_cast<u32x4*>(B6 + ((size_t)(buf * NPL + j) * BN + brow) * PITCH6 + bhalf * 8) = sb_.rb[j];
             }
         };
-        // No conditionals around gload/lstore: hipcc's vmcnt bookkeeping is exact only on straight-line
-        // code.  With `if (s + 3 < nsteps) gload(...)` it assumed the loads might not have been issued
-        // and waited for vmcnt(0) before every LDS store, i.e. no load ever stayed in flight across a
-        // step.  The tail re-loads the last step (never stored, or stored into the idle buffer).
-        const int last = nsteps - 1;
-        gload(S0, 0);
-        gload(S1, min(1, last));
-        lstore(S0, 0);
-        gload(S0, min(2, last));
-        __syncthreads();
-        int s = 0;
-        for (; s + 1 < nsteps; s += 2) {
-            DBG_STAMP(1 + 3 * s);
-#ifdef DSNT_TIMELINE2      // stamps: start | stage's loads landed | LDS stores issued  (PRO: 7 younger loads)
-            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            DBG_STAMP(2 + 3 * s);
-            lstore(S1, 1);
-            DBG_STAMP(3 + 3 * s);
-            gload(S1, min(s + 3, last));
-            __syncthreads();
-            DBG_STAMP(4 + 3 * s);
-            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            DBG_STAMP(5 + 3 * s);
-            lstore(S0, 0);
-            DBG_STAMP(6 + 3 * s);
-            gload(S0, min(s + 4, last));
-            __syncthreads();
-#else
-            lstore(S1, 1);
-            DBG_STAMP(2 + 3 * s);
-            gload(S1, min(s + 3, last));
-            DBG_STAMP(3 + 3 * s);
-            __syncthreads();
-            DBG_STAMP(4 + 3 * s);
-            lstore(S0, 0);                 // when s + 2 == nsteps this refills idle buffer 0: harmless
-            DBG_STAMP(5 + 3 * s);
-            gload(S0, min(s + 4, last));
-            DBG_STAMP(6 + 3 * s);
-            __syncthreads();
-#endif
+        // No conditionals around the loads and stores of the main loop: hipcc's vmcnt bookkeeping is exact only on
+        // straight-line code (a guarded prefetch made it wait for vmcnt(0) before every LDS store).  Phase i = 1 .. nsteps
+        // stores K-step i into buffer i & 1 (the MFMA waves are on step i - 1), then refills the A stage with step
+        // i + DA and the B stage with step i + 2; the loop is unrolled over P = lcm(DA, 2) phases so that stage and
+        // buffer indices are compile-time constants.
+        constexpr int P = (DA % 2 == 0) ? DA : 2 * DA;
+#pragma unroll
+        for (int d = 0; d < DA; ++d) gloadA(SA[d]);
+        gloadB(SB[0]);
+        gloadB(SB[1]);
+        if (PRO) {                                   // the BatchNorm vectors -> LDS, once
+            for (int c = ltid; c < p.Cin; c += 256) {
+                SS[c] = p.in_scale[c] * sa;
+                SS[p.Cin + c] = p.in_shift[c] * sa;
+            }
         }
-        if (s < nsteps) __syncthreads();
+        __syncthreads();                             // (all eight waves) SS is in place
+        lstore(SA[0], SB[0], 0);
+        gloadA(SA[0]);
+        gloadB(SB[0]);
+        __syncthreads();
+        int i = 1;
+        for (; i + P - 1 <= nsteps; i += P) {
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                DBG_STAMP(1 + 3 * (i + u - 1));
+                lstore(SA[(1 + u) % DA], SB[(1 + u) & 1], (1 + u) & 1);
+                DBG_STAMP(2 + 3 * (i + u - 1));
+                gloadA(SA[(1 + u) % DA]);
+                gloadB(SB[(1 + u) & 1]);
+                DBG_STAMP(3 + 3 * (i + u - 1));
+                __syncthreads();
+            }
+        }
+        // up to P - 1 phases left (uniform branches; nothing is prefetched any more)
+#pragma unroll
+        for (int u = 0; u < P - 1; ++u)
+            if (i + u <= nsteps) {
+                lstore(SA[(1 + u) % DA], SB[(1 + u) & 1], (1 + u) & 1);
+                __syncthreads();
+            }
     } else {
         // ------------------------------------------------------------------ MFMA waves
         struct Frag { bf16x8 a[TM][3], b[TN][3]; };
@@ -843,7 +866,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
 #pragma unroll
                 for (int b = 0; b < TN; ++b) mma_split<F16>(acc[a][b], f.a[a], f.b[b]);
         };
-        __syncthreads();
+        __syncthreads();                   // the loaders' BatchNorm vectors are in LDS
+        __syncthreads();                   // K-step 0 is staged
         for (int s = 0; s < nsteps; ++s) {
             DBG_STAMP(1 + 3 * s);
             rd(F, s & 1);
@@ -1183,6 +1207,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
     const int cw = wave & 3;
     const int wm = cw >> 1, wn = cw & 1;
     (void)BROWS;
+    DBG_INIT();
+    DBG_STAMP(0);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1294,6 +1320,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
         for (int c2 = 0; c2 < nchunks; c2 += 2) {
 #pragma unroll
             for (int j = 0; j < 18; ++j) {
+                if (c2 == 0) DBG_STAMP(1 + 3 * j);                 // timeline builds (tools/timeline_halo.py): step start
                 // while the MFMA waves work on step j: stage step j+1, fetch step j+3
                 storeB((j + 1) & 1, (j + 1) & 1);
                 gloadB((j + 1) & 1, c2 + (j + 3) / 9, (j + 3) % 9);
@@ -1307,7 +1334,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
                     storeA(0);
                     gloadA(c2 + j / 9 + 2);
                 }
+                if (c2 == 0) DBG_STAMP(2 + 3 * j);                 // staged, loads issued
                 __syncthreads();
+                if (c2 == 0) DBG_STAMP(3 + 3 * j);                 // through the barrier
             }
         }
     } else {
@@ -1326,6 +1355,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
         for (int c2 = 0; c2 < nchunks; c2 += 2) {
 #pragma unroll
             for (int j = 0; j < 18; ++j) {
+                if (c2 == 0) DBG_STAMP(1 + 3 * j);
                 const int t = j % 9, buf = j & 1;
                 const int toff = ((t / 3) * HWD + (t % 3)) * PITCH6 + (ABUF == 2 ? (j / 9) * NPL * HPP * PITCH6 : 0);
 #pragma unroll
@@ -1342,12 +1372,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_kernel(ConvP p) {
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b) mma_split<F16>(acc[a][b], F.a[a], F.b[b]);
+                if (c2 == 0) DBG_STAMP(2 + 3 * j);                 // MFMAs issued
                 __syncthreads();
+                if (c2 == 0) DBG_STAMP(3 + 3 * j);                 // through the barrier
             }
         }
     }
     const int mbase = (img * p.H + th * 8) * p.W + tw * 16;
+    DBG_STAMP(124);
     conv_epilogue<2, WN, TM, TN, true>(p, acc, smem, mtile, ntile, tid, wave, lane, mbase);
+    DBG_STAMP(125);
 }
 
 template <int TN, bool F16 = false>
@@ -1356,6 +1390,9 @@ static void launch_conv3x3_6(const ConvP& p, bool pro, hipStream_t st) {
     size_t lds = (size_t)((F16 ? 2 : 1) * NPL * 192 + 2 * NPL * BN) * PITCH6 * 2;
     const size_t epi = (size_t)128 * (BN + 4) * 4;
     if (epi > lds) lds = epi;
+    static int one = -1;            // DSNT_HALO_ONE=1 (experiment): pad the LDS request so that only ONE workgroup fits a CU
+    if (one < 0) { const char* e = getenv("DSNT_HALO_ONE"); one = (e && e[0] == '1') ? 1 : 0; }
+    if (one) lds = 100 * 1024;
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {
         hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1375,20 +1412,28 @@ static bool conv3x3_halo_ok(const dsnt_conv_geom* g) {
 template <int WM, int WN, int TM, int TN, bool F16 = false>
 static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    size_t lds = (size_t)2 * (F16 ? 2 : 3) * (BM + BN) * PITCH6 * 2;
+    size_t lds = (size_t)2 * (F16 ? 2 : 3) * (BM + BN) * PITCH6 * 2 + (size_t)2 * p.Cin * sizeof(float);   // tiles + BN vectors
     const size_t epi = (size_t)BM * (BN + 4) * 4;          // the epilogue's C tile lives in the same LDS
     if (epi > lds) lds = epi;
-    static bool attr_done = false;
-    if (!attr_done && lds > 65536) {
-        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+    static size_t attr_lds = 0;
+    if (lds > 65536 && lds > attr_lds) {
+        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
     }
+    // A-operand register stages: 2 (default) or 4 (DSNT_GEMM_DEPTH=4).  Measured on MI355X: four stages are 2-5 %
+    // SLOWER on every 1x1 shape of the hourglass (the kernel is not waiting for HBM latency: see DESIGN.md, issue bound)
+    static int depth = -1;
+    if (depth < 0) { const char* e = getenv("DSNT_GEMM_DEPTH"); depth = (e && e[0] == '4') ? 4 : 2; }
     dim3 gr(p.mtiles * p.ntiles), bl(512);
-    if (pro) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16>), gr, bl, lds, st, p);
-    else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16>), gr, bl, lds, st, p);
+    // (the three-plane kernel with the BN prologue needs 139 registers with four stages: one workgroup per CU; it keeps two)
+    if (depth == 2 || (pro && !F16)) {
+        if (pro) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 2>), gr, bl, lds, st, p);
+        else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>), gr, bl, lds, st, p);
+    } else if (pro) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 4>), gr, bl, lds, st, p);
+    else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 4>), gr, bl, lds, st, p);
 }
 
 static bool g_force_gemm6 = false;      // debug/bench: route 3x3 convolutions through the implicit-GEMM kernel

@@ -7,7 +7,7 @@ from dsnt import _lib
 from dsnt._lib import ptr, ConvGeom
 dev = torch.device('cuda:0')
 B = 32
-shapes = [(64, 128, 128, 3), (64, 256, 128, 1), (64, 128, 256, 1), (32, 128, 128, 3), (128, 64, 64, 3)]
+shapes = [(64, 128, 128, 3), (64, 256, 128, 1), (64, 128, 256, 1), (64, 256, 256, 1), (32, 128, 256, 1), (32, 256, 128, 1), (32, 128, 128, 3), (128, 64, 64, 3)]
 st = torch.cuda.current_stream().cuda_stream
 def timeit(fn, args, iters=10):
     for _ in range(2): assert fn(*args, st) == 0

@@ -6,8 +6,9 @@ sys.path[:0] = [os.path.join(ROOT, 'dsnt-pose2d_amd')]
 from dsnt import _lib
 from dsnt._lib import ptr, ConvGeom
 dev = torch.device('cuda:0')
-B, H, Cin, Cout, k = 32, 64, 128, 128, 3
 which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
+B = 32
+H, Cin, Cout, k = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (64, 128, 128, 3)
 g = ConvGeom(B, H, H, Cin, H, H, Cout, k, k, 1, k // 2, 1)
 x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
 b = torch.zeros(Cout, device=dev); sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
