@@ -43,6 +43,8 @@ WORKLOADS = {
     'hg8_js': ('hg8', 'js', 16, 168.3),
     # BASELINE config 1 (the reference's CPU-runnable case) on the HIP path: ResNet-34 + DSNT, 8x8 heat-maps
     'resnet34': ('resnet34', 'none', 8, 28.4),
+    # SURVEY 8(f) f-2, NOT the headline metric: eval-mode forward (inference.py:33-48), plain and with flip augmentation
+    'hg2_infer': ('hg2', 'none', 32, 17.98),
 }
 PEAK_F32_MFMA = 157.3  # TFLOP/s, MI355X_MICROARCH.md
 
@@ -271,6 +273,51 @@ def head_roofline(batch=1024, iters=10):
             'ms_fwd_loss_bwd': round(ms, 4)}
 
 
+def infer_bench(model, x, batch, world, rank, args):
+    """Eval-mode forward throughput (replicas only across GPUs: no collective), with and without the reference's
+    horizontal-flip test-time augmentation (inference.py:33-48: both orientations through the backbone, the flipped
+    half mirrored back with left/right joints swapped, mean of the un-normalised heat-maps, then the DSNT head)."""
+    from dsnt.inference import HFLIP_INDICES
+    model.eval()
+    idx = HFLIP_INDICES.to(x.device)
+
+    def plain():
+        with torch.no_grad():
+            return model(x)[-1]
+
+    def flipped():
+        with torch.no_grad():
+            hm = model.forward_part1(torch.cat([x, x.flip(-1)], 0))[-1]
+            hm2 = hm[batch:].flip(-1).index_select(-3, idx)
+            return model.forward_part2([(hm[:batch] + hm2) / 2])[-1]
+    res = {}
+    for name, fn in (('plain', plain), ('flip_tta', flipped)):
+        for _ in range(max(args.warmup, 1)):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        res[name] = (time.perf_counter() - t0) / args.steps
+    if rank == 0:
+        out = {'metric': 'images/sec (inference, eval-mode forward, 256x256, 16 joints)', 'value': round(world * batch / res['plain'], 1),
+               'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(1e3 * res['plain'], 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'hg2 + DSNT inference, batch %d per GPU, replicas' % batch, 'global_batch': world * batch,
+                          'parallelism': 'replicas%d' % world},
+               'flip_tta_images_per_sec': round(world * batch / res['flip_tta'], 1),
+               'note': 'not the BASELINE metric (that is the train step: default workload)'}
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -315,6 +362,8 @@ def main():
     x, target, mask = synthetic.batch(batch, size=256, seed=1 + rank, mask_p=1.0)
     x, target, mask = x.to(dev), target.to(dev), mask.to(dev)
 
+    if args.workload == 'hg2_infer':
+        return infer_bench(model, x, batch, world, rank, args)
     runner = (model.hg if hasattr(model, 'hg') else model)._runner()
     runner.ensure(dev)
     from dsnt.guard import NanGuard

@@ -634,7 +634,7 @@ extern "C" int dsnt_split_bf16x3(const float* src, void* dst, int64_t n, void* s
     const long n4 = n / 4;
     long g = (n4 + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(split_bf16x3_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)src, (uint2*)dst, n4);
     DSNT_CHECK_LAUNCH("dsnt_split_bf16x3");
 }
@@ -932,10 +932,10 @@ static int launch_fwd(const ConvP& p, bool pro, hipStream_t st) {
                       ((size_t)p.N * p.H * p.W * p.Cin * 4u < (1ull << 31)) &&
                       ((size_t)p.Cout * p.K * 4u < (1ull << 31));
     dim3 gr(grid), bl(512);
-    if (pro && fast) hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, true, true>), gr, bl, lds, st, p);
-    else if (pro) hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, true, false>), gr, bl, lds, st, p);
-    else if (fast) hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, false, true>), gr, bl, lds, st, p);
-    else hipLaunchKernelGGL((conv_fwd_kernel<WM, WN, TM, TN, false, false>), gr, bl, lds, st, p);
+    if (pro && fast) DSNT_LAUNCH((conv_fwd_kernel<WM, WN, TM, TN, true, true>), gr, bl, lds, st, p);
+    else if (pro) DSNT_LAUNCH((conv_fwd_kernel<WM, WN, TM, TN, true, false>), gr, bl, lds, st, p);
+    else if (fast) DSNT_LAUNCH((conv_fwd_kernel<WM, WN, TM, TN, false, true>), gr, bl, lds, st, p);
+    else DSNT_LAUNCH((conv_fwd_kernel<WM, WN, TM, TN, false, false>), gr, bl, lds, st, p);
     return 0;
 }
 
@@ -1136,8 +1136,8 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
     if (BM == 32 && p.M <= ksplit_rows() && p.Cin % 8 == 0 && (size_t)p.N * p.H * p.W * p.Cin * 4u < (1ull << 31) &&
         (size_t)p.Cout * p.K * 4u < (1ull << 31)) {
         const int grid = p.mtiles * ((p.Cout + 31) / 32);
-        if (pro) hipLaunchKernelGGL(conv_ksplit_kernel<true>, dim3(grid), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL(conv_ksplit_kernel<false>, dim3(grid), dim3(512), 0, st, p);
+        if (pro) DSNT_LAUNCH(conv_ksplit_kernel<true>, dim3(grid), dim3(512), 0, st, p);
+        else DSNT_LAUNCH(conv_ksplit_kernel<false>, dim3(grid), dim3(512), 0, st, p);
     } else if (BM == 128 && BN == 128) launch_fwd<2, 2, 2, 2>(p, pro, st);
     else if (BM == 128 && BN == 64) launch_fwd<2, 2, 2, 1>(p, pro, st);
     else if (BM == 128 && BN == 32) launch_fwd<4, 1, 1, 1>(p, pro, st);
@@ -1400,8 +1400,8 @@ static void launch_conv3x3_6(const ConvP& p, bool pro, hipStream_t st) {
         attr_done = true;
     }
     dim3 gr(p.mtiles * p.ntiles), bl(512);
-    if (pro) hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TN, true, F16>), gr, bl, lds, st, p);
-    else hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TN, false, F16>), gr, bl, lds, st, p);
+    if (pro) DSNT_LAUNCH((conv3x3_bf16x6_kernel<TN, true, F16>), gr, bl, lds, st, p);
+    else DSNT_LAUNCH((conv3x3_bf16x6_kernel<TN, false, F16>), gr, bl, lds, st, p);
 }
 
 static bool conv3x3_halo_ok(const dsnt_conv_geom* g) {
@@ -1430,10 +1430,10 @@ static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
     dim3 gr(p.mtiles * p.ntiles), bl(512);
     // (the three-plane kernel with the BN prologue needs 139 registers with four stages: one workgroup per CU; it keeps two)
     if (depth == 2 || (pro && !F16)) {
-        if (pro) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 2>), gr, bl, lds, st, p);
-        else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>), gr, bl, lds, st, p);
-    } else if (pro) hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 4>), gr, bl, lds, st, p);
-    else hipLaunchKernelGGL((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 4>), gr, bl, lds, st, p);
+        if (pro) DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 2>), gr, bl, lds, st, p);
+        else DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>), gr, bl, lds, st, p);
+    } else if (pro) DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 4>), gr, bl, lds, st, p);
+    else DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 4>), gr, bl, lds, st, p);
 }
 
 static bool g_force_gemm6 = false;      // debug/bench: route 3x3 convolutions through the implicit-GEMM kernel
@@ -1535,10 +1535,11 @@ __global__ void amax_kernel(const float4* __restrict__ src, unsigned* __restrict
 extern "C" int dsnt_amax(const float* src, int64_t n, float* out, void* stream) {
     DSNT_REQUIRE(src && out && n > 0 && n % 4 == 0 && dsnt_aligned16(src), DSNT_ERR_ARG,
                  "dsnt_amax: n must be a positive multiple of 4, src 16-byte aligned");
+    DSNT_REQUIRE(!dsnt_recording(), DSNT_ERR_ARG, "dsnt_amax: cannot be recorded into a launch list (it clears its output with a memset)");
     if (hipMemsetAsync(out, 0, 4 * DSNT_BOUND_SLOTS, (hipStream_t)stream) != hipSuccess) return dsnt_set_error(DSNT_ERR_HIP, "dsnt_amax: memset");
     long g = (n / 4 + 255) / 256;
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+    DSNT_LAUNCH(amax_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
                        (unsigned*)out, (long)(n / 4));
     DSNT_CHECK_LAUNCH("dsnt_amax");
 }
@@ -1563,7 +1564,7 @@ extern "C" int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t 
     const long n4 = n / 4;
     long g = (n4 + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+    DSNT_LAUNCH(split_f16x2_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
                        (uint2*)dst, n4, (long)(plane_stride / 4), bound);
     DSNT_CHECK_LAUNCH("dsnt_split_f16x2");
 }
@@ -1600,7 +1601,7 @@ __global__ __launch_bounds__(256) void f16_prep_weights_kernel(const long long* 
 
 extern "C" int dsnt_f16_prep_weights(const int64_t* table, int rows, void* stream) {
     DSNT_REQUIRE(table && rows > 0, DSNT_ERR_ARG, "dsnt_f16_prep_weights: bad argument");
-    hipLaunchKernelGGL(f16_prep_weights_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)table);
+    DSNT_LAUNCH(f16_prep_weights_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)table);
     DSNT_CHECK_LAUNCH("dsnt_f16_prep_weights");
 }
 
@@ -1620,7 +1621,7 @@ __global__ __launch_bounds__(64) void f16_prep_bn_bounds_kernel(const long long*
 
 extern "C" int dsnt_f16_prep_bn_bounds(const int64_t* table, int rows, void* stream) {
     DSNT_REQUIRE(table && rows > 0, DSNT_ERR_ARG, "dsnt_f16_prep_bn_bounds: bad argument");
-    hipLaunchKernelGGL(f16_prep_bn_bounds_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, (const long long*)table);
+    DSNT_LAUNCH(f16_prep_bn_bounds_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, (const long long*)table);
     DSNT_CHECK_LAUNCH("dsnt_f16_prep_bn_bounds");
 }
 
@@ -1644,7 +1645,7 @@ extern "C" int dsnt_conv_pack_dgrad(const float* w, float* wd, int Cout, int R, 
                  "dsnt_conv_pack_dgrad: bad argument");
     const int total = Cout * R * S * Cin;
     const int grid = (total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024;
-    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wd, Cout,
+    DSNT_LAUNCH(pack_dgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wd, Cout,
                        R, S, Cin);
     DSNT_CHECK_LAUNCH("dsnt_conv_pack_dgrad");
 }
@@ -1681,7 +1682,7 @@ extern "C" int dsnt_conv_pack_dgrad_all(const int* table, int nconv, const float
                                         void* planes, int64_t total, void* stream) {
     DSNT_REQUIRE(table && params && out && planes && nconv > 0 && total > 0, DSNT_ERR_ARG,
                  "dsnt_conv_pack_dgrad_all: bad argument");
-    hipLaunchKernelGGL(pack_dgrad_all_kernel, dim3(64, nconv), dim3(256), 0, (hipStream_t)stream, table, params,
+    DSNT_LAUNCH(pack_dgrad_all_kernel, dim3(64, nconv), dim3(256), 0, (hipStream_t)stream, table, params,
                        out, (unsigned short*)planes, (long)total);
     DSNT_CHECK_LAUNCH("dsnt_conv_pack_dgrad_all");
 }
@@ -2448,7 +2449,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const long long* 
 
 extern "C" int dsnt_wgrad_reduce_all(const int64_t* table, int rows, int max_blocks, void* stream) {
     DSNT_REQUIRE(table && rows > 0 && rows <= 65535 && max_blocks > 0, DSNT_ERR_ARG, "dsnt_wgrad_reduce_all: bad argument");
-    hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3(max_blocks, rows), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(wgrad_reduce_all_kernel, dim3(max_blocks, rows), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)table);
     DSNT_CHECK_LAUNCH("dsnt_wgrad_reduce_all");
 }
@@ -2564,7 +2565,7 @@ extern "C" int dsnt_conv_wgrad_group(const void* table, int nconv, int max_block
         hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_bf16x6_group_kernel, dim3(max_blocks, nconv), dim3(512), lds, (hipStream_t)stream,
+    DSNT_LAUNCH(conv_wgrad_bf16x6_group_kernel, dim3(max_blocks, nconv), dim3(512), lds, (hipStream_t)stream,
                        (const WgradP*)table);
     DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_group");
 }
@@ -2616,21 +2617,21 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
                 attr16 = true;
             }
             const int lds16 = 2 * 2 * 2 * 128 * PITCH6 * 2;
-            if (in_scale) hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<true, true>), dim3(grid), dim3(512), lds16, st, p);
-            else hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<false, true>), dim3(grid), dim3(512), lds16, st, p);
+            if (in_scale) DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<true, true>), dim3(grid), dim3(512), lds16, st, p);
+            else DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<false, true>), dim3(grid), dim3(512), lds16, st, p);
         } else if (unified) {
-            if (in_scale) hipLaunchKernelGGL(conv_wgrad_bf16x6u_kernel<true>, dim3(grid), dim3(256), lds, st, p);
-            else hipLaunchKernelGGL(conv_wgrad_bf16x6u_kernel<false>, dim3(grid), dim3(256), lds, st, p);
-        } else if (in_scale) hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<true, false>), dim3(grid), dim3(512), lds, st, p);
-        else hipLaunchKernelGGL((conv_wgrad_bf16x6_kernel<false, false>), dim3(grid), dim3(512), lds, st, p);
+            if (in_scale) DSNT_LAUNCH(conv_wgrad_bf16x6u_kernel<true>, dim3(grid), dim3(256), lds, st, p);
+            else DSNT_LAUNCH(conv_wgrad_bf16x6u_kernel<false>, dim3(grid), dim3(256), lds, st, p);
+        } else if (in_scale) DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<true, false>), dim3(grid), dim3(512), lds, st, p);
+        else DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<false, false>), dim3(grid), dim3(512), lds, st, p);
     } else if (in_scale)
-        hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(256), 0, st, p);
+        DSNT_LAUNCH(conv_wgrad_kernel<true>, dim3(grid), dim3(256), 0, st, p);
     else
-        hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(grid), dim3(256), 0, st, p);
+        DSNT_LAUNCH(conv_wgrad_kernel<false>, dim3(grid), dim3(256), 0, st, p);
     if (dw) {       // dw == nullptr: slabs only, the caller reduces later (dsnt_wgrad_reduce_all)
         const int CK = p.Cout * p.K;
         const int total = CK / 4 + (p.Cout + 3) / 4;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias,
+        DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias,
                            p.splits, CK, p.Cout, accumulate);
     }
     DSNT_CHECK_LAUNCH("dsnt_conv_wgrad");

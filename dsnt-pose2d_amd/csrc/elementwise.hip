@@ -82,7 +82,7 @@ extern "C" int dsnt_bn_stats(const float* x, float* partial, int64_t M, int C, v
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(partial), DSNT_ERR_ALIGN,
                  "dsnt_bn_stats: C %% 4 and 16-byte alignment required");
     const int tiles = (int)((M + TILE_ROWS - 1) / TILE_ROWS);
-    hipLaunchKernelGGL(tile_reduce_kernel<0>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x,
+    DSNT_LAUNCH(tile_reduce_kernel<0>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x,
                        nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial, (long)M, C);
     DSNT_CHECK_LAUNCH("dsnt_bn_stats");
 }
@@ -170,7 +170,7 @@ extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, f
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(partial) &&
                  (((uintptr_t)idx) & 3) == 0, DSNT_ERR_ALIGN, "dsnt_maxpool2_fwd_stats: alignment");
     const long M = (long)N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(tile_op_stats_kernel<0>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
+    DSNT_LAUNCH(tile_op_stats_kernel<0>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
                        (hipStream_t)stream, x, nullptr, y, idx, partial, N, H / 2, W / 2, C, tail);
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_fwd_stats");
 }
@@ -186,7 +186,7 @@ extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, f
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(up) && dsnt_aligned16(low) && dsnt_aligned16(out) &&
                  dsnt_aligned16(partial), DSNT_ERR_ALIGN, "dsnt_upsample2_add_fwd_stats: alignment");
     const long M = (long)N * H * W;
-    hipLaunchKernelGGL(tile_op_stats_kernel<1>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
+    DSNT_LAUNCH(tile_op_stats_kernel<1>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
                        (hipStream_t)stream, up, low, out, nullptr, partial, N, H, W, C, tail);
     DSNT_CHECK_LAUNCH("dsnt_upsample2_add_fwd_stats");
 }
@@ -201,7 +201,7 @@ extern "C" int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const flo
                  dsnt_aligned16(invstd), DSNT_ERR_ALIGN,
                  "dsnt_bn_act_bwd_reduce: C %% 4 and 16-byte alignment required");
     const int tiles = (int)((M + TILE_ROWS - 1) / TILE_ROWS);
-    hipLaunchKernelGGL(tile_reduce_kernel<1>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, da, x,
+    DSNT_LAUNCH(tile_reduce_kernel<1>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, da, x,
                        scale, shift, mean, invstd, relu, partial, (long)M, C);
     DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_reduce");
 }
@@ -279,10 +279,41 @@ extern "C" int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int
     DSNT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DSNT_ERR_ARG,
                  "dsnt_bn_finalize: running_mean/var must be given together");
     const double unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
                        partial, ntiles, 1.0 / (double)M, unbias, C, gamma, beta, running_mean,
                        running_var, momentum, eps, training, mean, invstd, scale, shift, 0);
     DSNT_CHECK_LAUNCH("dsnt_bn_finalize");
+}
+
+// Eval-mode BatchNorm vectors of MANY layers in one launch (table rows of int64: {gamma*, beta*, running_mean*,
+// running_var*, mean*, invstd*, scale*, shift*, C, bits of float eps}): what dsnt_bn_finalize(training = 0) computes per
+// layer — 96 launches per hg2 forward otherwise, the larger part of a batch-1 inference (inference.py:33-48).
+__global__ __launch_bounds__(256) void bn_eval_prep_kernel(const long long* __restrict__ table) {
+    const long long* t = table + (size_t)blockIdx.x * 10;
+    const float* gamma = reinterpret_cast<const float*>(t[0]);
+    const float* beta = reinterpret_cast<const float*>(t[1]);
+    const float* rm = reinterpret_cast<const float*>(t[2]);
+    const float* rv = reinterpret_cast<const float*>(t[3]);
+    float* mean = reinterpret_cast<float*>(t[4]);
+    float* invstd = reinterpret_cast<float*>(t[5]);
+    float* scale = reinterpret_cast<float*>(t[6]);
+    float* shift = reinterpret_cast<float*>(t[7]);
+    const int C = (int)t[8];
+    const float eps = __uint_as_float((unsigned)t[9]);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double var = rv[c];
+        const float is = (float)(1.0 / sqrt(var + (double)eps));
+        const float mu = rm[c];
+        const float sc = gamma ? gamma[c] * is : is;
+        mean[c] = mu; invstd[c] = is; scale[c] = sc;
+        shift[c] = (beta ? beta[c] : 0.f) - mu * sc;
+    }
+}
+
+extern "C" int dsnt_bn_eval_prep(const int64_t* table, int rows, void* stream) {
+    DSNT_REQUIRE(table && rows > 0, DSNT_ERR_ARG, "dsnt_bn_eval_prep: bad argument");
+    DSNT_LAUNCH(bn_eval_prep_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)table);
+    DSNT_CHECK_LAUNCH("dsnt_bn_eval_prep");
 }
 
 extern "C" int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M, int C,
@@ -290,7 +321,7 @@ extern "C" int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M,
                                     void* stream) {
     DSNT_REQUIRE(partial && coef && ntiles > 0 && C > 0 && M > 0, DSNT_ERR_ARG,
                  "dsnt_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
                        partial, ntiles, 1.0 / (double)M, 1.0, C, nullptr, nullptr, nullptr, nullptr,
                        0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate);
     DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize");
@@ -322,7 +353,7 @@ extern "C" int dsnt_bn_act_fwd(const float* x, const float* scale, const float* 
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(scale) &&
                  dsnt_aligned16(shift), DSNT_ERR_ALIGN, "dsnt_bn_act_fwd: alignment");
     const long n4 = (long)M * C / 4;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(bn_act_fwd_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)x, (const float4*)scale, (const float4*)shift, relu, (float4*)y,
                        n4, C / 4);
     DSNT_CHECK_LAUNCH("dsnt_bn_act_fwd");
@@ -375,7 +406,7 @@ __global__ void fill_zero_kernel(float* p, long n) {
 
 extern "C" int dsnt_fill_zero(float* p, int64_t n, void* stream) {
     DSNT_REQUIRE(p && n > 0, DSNT_ERR_ARG, "dsnt_fill_zero: bad argument");
-    hipLaunchKernelGGL(fill_zero_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, (long)n);
+    DSNT_LAUNCH(fill_zero_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, (long)n);
     DSNT_CHECK_LAUNCH("dsnt_fill_zero");
 }
 
@@ -394,7 +425,7 @@ static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* s
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(da) && dsnt_aligned16(x) && dsnt_aligned16(dx) &&
                  dsnt_aligned16(coef), DSNT_ERR_ALIGN, "dsnt_bn_act_bwd_apply: alignment");
     const long n4 = (long)M * C / 4;
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0,
+    DSNT_LAUNCH(bn_act_bwd_apply_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
                        (const float4*)shift, (const float4*)mean, (const float4*)invstd,
                        (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax);
@@ -436,7 +467,7 @@ extern "C" int dsnt_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int N, 
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && (((uintptr_t)idx) & 3) == 0,
                  DSNT_ERR_ALIGN, "dsnt_maxpool2_fwd: alignment");
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(maxpool2_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)x, (float4*)y, (uchar4*)idx, N, H, W, C / 4);
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_fwd");
 }
@@ -485,7 +516,7 @@ static int maxpool2_bwd_impl(const float* dy, const uint8_t* idx, float* dx, int
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_bwd: H and W must be even");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dy) && dsnt_aligned16(dx), DSNT_ERR_ALIGN, "dsnt_maxpool2_bwd: alignment");
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(maxpool2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, N, H, W, C / 4, (unsigned*)amax);
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_bwd");
 }
@@ -513,7 +544,7 @@ extern "C" int dsnt_upsample2_add_fwd(const float* up, const float* low, float* 
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(up) && dsnt_aligned16(low) && dsnt_aligned16(out),
                  DSNT_ERR_ALIGN, "dsnt_upsample2_add_fwd: alignment");
     const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2_add_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0,
+    DSNT_LAUNCH(upsample2_add_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)up, (const float4*)low, (float4*)out, N, H, W, C / 4);
     DSNT_CHECK_LAUNCH("dsnt_upsample2_add_fwd");
 }
@@ -557,7 +588,7 @@ static int upsample2_bwd_impl(const float* dout, float* dlow, int accumulate, in
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_upsample2_bwd: H and W must be even");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dout) && dsnt_aligned16(dlow), DSNT_ERR_ALIGN, "dsnt_upsample2_bwd: alignment");
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(upsample2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)dout, (float4*)dlow, accumulate, N, H, W, C / 4, (unsigned*)amax);
     DSNT_CHECK_LAUNCH("dsnt_upsample2_bwd");
 }
@@ -588,7 +619,7 @@ __global__ void axpy_kernel(const float* __restrict__ x, float* y, float a, int 
 static int axpy_impl(const float* x, float* y, float a, int accumulate, int64_t n, float* amax, void* stream) {
     DSNT_REQUIRE(x && y && n > 0, DSNT_ERR_ARG, "dsnt_axpy: bad argument");
     DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(y), DSNT_ERR_ALIGN, "dsnt_axpy: alignment");
-    hipLaunchKernelGGL(axpy_kernel, dim3(flat_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+    DSNT_LAUNCH(axpy_kernel, dim3(flat_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
                        a, accumulate, (long)n, (unsigned*)amax);
     DSNT_CHECK_LAUNCH("dsnt_axpy");
 }
@@ -624,13 +655,13 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
 
 extern "C" int dsnt_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int Cpad, void* stream) {
     DSNT_REQUIRE(src && dst && N > 0 && C > 0 && HW > 0 && Cpad >= C, DSNT_ERR_ARG, "dsnt_nchw_to_nhwc: bad argument");
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(flat_grid((long)N * HW, 256)), dim3(256), 0,
+    DSNT_LAUNCH(nchw_to_nhwc_kernel, dim3(flat_grid((long)N * HW, 256)), dim3(256), 0,
                        (hipStream_t)stream, src, dst, N, C, HW, Cpad);
     DSNT_CHECK_LAUNCH("dsnt_nchw_to_nhwc");
 }
 extern "C" int dsnt_nhwc_to_nchw(const float* src, float* dst, int N, int C, int HW, int Cpad, void* stream) {
     DSNT_REQUIRE(src && dst && N > 0 && C > 0 && HW > 0 && Cpad >= C, DSNT_ERR_ARG, "dsnt_nhwc_to_nchw: bad argument");
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(flat_grid((long)N * HW, 256)), dim3(256), 0,
+    DSNT_LAUNCH(nhwc_to_nchw_kernel, dim3(flat_grid((long)N * HW, 256)), dim3(256), 0,
                        (hipStream_t)stream, src, dst, N, C, HW, Cpad);
     DSNT_CHECK_LAUNCH("dsnt_nhwc_to_nchw");
 }
@@ -660,7 +691,7 @@ __global__ void rmsprop_kernel(float* p, const float* __restrict__ g, float* sq,
 static int rmsprop_impl(float* p, const float* g, float* square_avg, int64_t n, float lr, float alpha, float eps,
                         float weight_decay, float grad_scale, int* flag, void* stream) {
     DSNT_REQUIRE(p && g && square_avg && n > 0, DSNT_ERR_ARG, "dsnt_rmsprop_step: bad argument");
-    hipLaunchKernelGGL(rmsprop_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
+    DSNT_LAUNCH(rmsprop_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
                        square_avg, (long)n, lr, alpha, eps, weight_decay, grad_scale, flag);
     DSNT_CHECK_LAUNCH("dsnt_rmsprop_step");
 }
@@ -695,7 +726,7 @@ __global__ void sgd_kernel(float* p, const float* __restrict__ g, float* buf, lo
 static int sgd_impl(float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
                     float weight_decay, float grad_scale, int first_step, int* flag, void* stream) {
     DSNT_REQUIRE(p && g && n > 0, DSNT_ERR_ARG, "dsnt_sgd_step: bad argument");
-    hipLaunchKernelGGL(sgd_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
+    DSNT_LAUNCH(sgd_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g,
                        momentum != 0.f ? momentum_buf : nullptr, (long)n, lr, momentum, weight_decay,
                        grad_scale, first_step, flag);
     DSNT_CHECK_LAUNCH("dsnt_sgd_step");
@@ -721,7 +752,7 @@ __global__ void nonfinite_flag_kernel(const float* __restrict__ x, long n, int* 
 }
 extern "C" int dsnt_nonfinite_flag(const float* x, int64_t n, int* flag, int code, void* stream) {
     DSNT_REQUIRE(x && flag && n > 0 && code != 0, DSNT_ERR_ARG, "dsnt_nonfinite_flag: bad argument");
-    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n,
+    DSNT_LAUNCH(nonfinite_flag_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n,
                        flag, code);
     DSNT_CHECK_LAUNCH("dsnt_nonfinite_flag");
 }
@@ -750,7 +781,7 @@ extern "C" int dsnt_pckh(const float* pred, const float* target, const double* m
                          float* valid, int B, int J, void* stream) {
     DSNT_REQUIRE(pred && target && m && b && mask && head && hits && valid && B > 0 && J > 0,
                  DSNT_ERR_ARG, "dsnt_pckh: bad argument");
-    hipLaunchKernelGGL(pckh_kernel, dim3((B * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred,
+    DSNT_LAUNCH(pckh_kernel, dim3((B * J + 255) / 256), dim3(256), 0, (hipStream_t)stream, pred,
                        target, m, b, mask, head, threshold, hits, valid, B, J);
     DSNT_CHECK_LAUNCH("dsnt_pckh");
 }
@@ -795,7 +826,7 @@ extern "C" int dsnt_maxpool3s2_fwd(const float* x, float* y, uint8_t* idx, int N
                  DSNT_ERR_ALIGN, "dsnt_maxpool3s2_fwd: alignment");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;        // floor((H + 2 - 3) / 2) + 1
     const long total = (long)N * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(maxpool3s2_fwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)x, (float4*)y, (uchar4*)idx, N, H, W, Ho, Wo, C / 4);
     DSNT_CHECK_LAUNCH("dsnt_maxpool3s2_fwd");
 }
@@ -839,7 +870,7 @@ extern "C" int dsnt_maxpool3s2_bwd(const float* dy, const uint8_t* idx, float* d
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dy) && dsnt_aligned16(dx), DSNT_ERR_ALIGN, "dsnt_maxpool3s2_bwd: alignment");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(maxpool3s2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, N, H, W, Ho, Wo, C / 4);
     DSNT_CHECK_LAUNCH("dsnt_maxpool3s2_bwd");
 }
@@ -864,7 +895,7 @@ extern "C" int dsnt_bn_add_act_fwd(const float* x, const float* scale, const flo
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(res) && dsnt_aligned16(scale) &&
                  dsnt_aligned16(shift), DSNT_ERR_ALIGN, "dsnt_bn_add_act_fwd: alignment");
     const long n4 = (long)M * C / 4;
-    hipLaunchKernelGGL(bn_add_act_fwd_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(bn_add_act_fwd_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)x, (const float4*)scale, (const float4*)shift, (const float4*)res, relu,
                        (float4*)y, n4, C / 4);
     DSNT_CHECK_LAUNCH("dsnt_bn_add_act_fwd");
@@ -882,7 +913,7 @@ __global__ void relu_bwd_kernel(const float4* __restrict__ dy, const float4* __r
 extern "C" int dsnt_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* stream) {
     DSNT_REQUIRE(dy && y && dz && n > 0 && n % 4 == 0, DSNT_ERR_ARG, "dsnt_relu_bwd: bad argument");
     DSNT_REQUIRE(dsnt_aligned16(dy) && dsnt_aligned16(y) && dsnt_aligned16(dz), DSNT_ERR_ALIGN, "dsnt_relu_bwd: alignment");
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(flat_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(relu_bwd_kernel, dim3(flat_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)dy, (const float4*)y, (float4*)dz, (long)(n / 4));
     DSNT_CHECK_LAUNCH("dsnt_relu_bwd");
 }
@@ -912,7 +943,7 @@ extern "C" int dsnt_zero_insert(const float* dy, float* out, int N, int Ho, int 
                  "dsnt_zero_insert: %dx%d does not hold %dx%d at stride %d", Hs, Ws, Ho, Wo, stride);
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dy) && dsnt_aligned16(out), DSNT_ERR_ALIGN, "dsnt_zero_insert: alignment");
     const long total = (long)N * Hs * Ws * (C / 4);
-    hipLaunchKernelGGL(zero_insert_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(zero_insert_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)dy, (float4*)out, N, Ho, Wo, Hs, Ws, stride, C / 4);
     DSNT_CHECK_LAUNCH("dsnt_zero_insert");
 }

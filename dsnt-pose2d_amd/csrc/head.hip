@@ -729,9 +729,9 @@ __global__ void scale_by_scalar_kernel(float4* __restrict__ x, const float* __re
         const bool vec_ = ((hw) % 4 == 0) && (ptr_ok);                                                 \
         const bool cached_ = (hw) <= 4096;                                                             \
         hipStream_t st_ = (hipStream_t)stream;                                                         \
-        if (vec_ && cached_) hipLaunchKernelGGL((KERNEL<4, true>), dim3(rows), dim3(HB), 0, st_, __VA_ARGS__);   \
-        else if (cached_) hipLaunchKernelGGL((KERNEL<1, true>), dim3(rows), dim3(HB), 0, st_, __VA_ARGS__);      \
-        else hipLaunchKernelGGL((KERNEL<1, false>), dim3(rows), dim3(HB), 0, st_, __VA_ARGS__);                  \
+        if (vec_ && cached_) DSNT_LAUNCH((KERNEL<4, true>), dim3(rows), dim3(HB), 0, st_, __VA_ARGS__);   \
+        else if (cached_) DSNT_LAUNCH((KERNEL<1, true>), dim3(rows), dim3(HB), 0, st_, __VA_ARGS__);      \
+        else DSNT_LAUNCH((KERNEL<1, false>), dim3(rows), dim3(HB), 0, st_, __VA_ARGS__);                  \
     } while (0)
 
 static int check_rows(const char* who, int64_t rows, int h, int w) {
@@ -769,7 +769,7 @@ extern "C" int dsnt_expect_fwd(const float* hm, float* coords, int64_t rows, int
 extern "C" int dsnt_expect_bwd(const float* gcoords, float* ghm, int64_t rows, int h, int w, void* stream) {
     DSNT_REQUIRE(gcoords && ghm, DSNT_ERR_ARG, "dsnt_expect_bwd: null tensor");
     if (int e = check_rows("dsnt_expect_bwd", rows, h, w)) return e;
-    hipLaunchKernelGGL(expect_bwd_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, gcoords, ghm, h, w);
+    DSNT_LAUNCH(expect_bwd_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, gcoords, ghm, h, w);
     DSNT_CHECK_LAUNCH("dsnt_expect_bwd");
 }
 
@@ -779,7 +779,7 @@ extern "C" int dsnt_make_gauss(const float* coords, float* out, int64_t rows, in
     DSNT_REQUIRE(sigma > 0.f, DSNT_ERR_ARG, "dsnt_make_gauss: sigma must be positive");
     if (int e = check_rows("dsnt_make_gauss", rows, h, w)) return e;
     const float k = (float)(-0.5 * (1.0 / (double)sigma) * (1.0 / (double)sigma));
-    hipLaunchKernelGGL(make_gauss_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, coords, out, h, w, k);
+    DSNT_LAUNCH(make_gauss_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, coords, out, h, w, k);
     DSNT_CHECK_LAUNCH("dsnt_make_gauss");
 }
 
@@ -789,7 +789,7 @@ extern "C" int dsnt_make_gauss_bwd(const float* coords, const float* g_out, floa
     DSNT_REQUIRE(sigma > 0.f, DSNT_ERR_ARG, "dsnt_make_gauss_bwd: sigma must be positive");
     if (int e = check_rows("dsnt_make_gauss_bwd", rows, h, w)) return e;
     const float k = (float)(-0.5 * (1.0 / (double)sigma) * (1.0 / (double)sigma));
-    hipLaunchKernelGGL(make_gauss_bwd_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, coords, g_out,
+    DSNT_LAUNCH(make_gauss_bwd_kernel, dim3((int)rows), dim3(HB), 0, (hipStream_t)stream, coords, g_out,
                        g_coords, h, w, k);
     DSNT_CHECK_LAUNCH("dsnt_make_gauss_bwd");
 }
@@ -819,7 +819,7 @@ extern "C" int dsnt_reg_bwd(const float* hm, const float* target, const float* g
 extern "C" int dsnt_euclid_fwd(const float* actual, const float* target, float* dist, int64_t n, int d,
                                void* stream) {
     DSNT_REQUIRE(actual && target && dist && n > 0 && d > 0, DSNT_ERR_ARG, "dsnt_euclid_fwd: bad argument");
-    hipLaunchKernelGGL(euclid_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(euclid_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        actual, target, dist, (long)n, d);
     DSNT_CHECK_LAUNCH("dsnt_euclid_fwd");
 }
@@ -828,21 +828,21 @@ extern "C" int dsnt_euclid_bwd(const float* actual, const float* target, const f
                                float* g_actual, int64_t n, int d, void* stream) {
     DSNT_REQUIRE(actual && target && dist && g_dist && g_actual && n > 0 && d > 0, DSNT_ERR_ARG,
                  "dsnt_euclid_bwd: bad argument");
-    hipLaunchKernelGGL(euclid_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(euclid_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        actual, target, dist, g_dist, g_actual, (long)n, d);
     DSNT_CHECK_LAUNCH("dsnt_euclid_bwd");
 }
 
 extern "C" int dsnt_masked_avg_fwd(const float* losses, const float* mask, float* out2, int64_t n, void* stream) {
     DSNT_REQUIRE(losses && out2 && n > 0, DSNT_ERR_ARG, "dsnt_masked_avg_fwd: bad argument");
-    hipLaunchKernelGGL(masked_avg_fwd_kernel, dim3(1), dim3(HB), 0, (hipStream_t)stream, losses, mask, out2, (long)n);
+    DSNT_LAUNCH(masked_avg_fwd_kernel, dim3(1), dim3(HB), 0, (hipStream_t)stream, losses, mask, out2, (long)n);
     DSNT_CHECK_LAUNCH("dsnt_masked_avg_fwd");
 }
 
 extern "C" int dsnt_masked_avg_bwd(const float* g_out, const float* mask, const float* out2, float* g_losses,
                                    int64_t n, void* stream) {
     DSNT_REQUIRE(g_out && out2 && g_losses && n > 0, DSNT_ERR_ARG, "dsnt_masked_avg_bwd: bad argument");
-    hipLaunchKernelGGL(masked_avg_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    DSNT_LAUNCH(masked_avg_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        g_out, mask, out2, g_losses, (long)n);
     DSNT_CHECK_LAUNCH("dsnt_masked_avg_bwd");
 }
@@ -881,7 +881,7 @@ extern "C" int dsnt_head_bwd(const float* hm, const float* coords, const float* 
 
 extern "C" int dsnt_mask_denom(const float* mask, float* denom2, int64_t n, void* stream) {
     DSNT_REQUIRE(denom2 && n > 0, DSNT_ERR_ARG, "dsnt_mask_denom: bad argument");
-    hipLaunchKernelGGL(mask_denom_kernel, dim3(1), dim3(HB), 0, (hipStream_t)stream, mask, denom2, (long)n);
+    DSNT_LAUNCH(mask_denom_kernel, dim3(1), dim3(HB), 0, (hipStream_t)stream, mask, denom2, (long)n);
     DSNT_CHECK_LAUNCH("dsnt_mask_denom");
 }
 
@@ -896,9 +896,9 @@ extern "C" int dsnt_head_loss_grad(const float* hm, const float* coords, const f
                  "dsnt_head_loss_rows + dsnt_head_bwd for larger ones", h, w);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = ((h * w) % 4 == 0) && dsnt_aligned16(hm) && dsnt_aligned16(g_logits);
-    if (vec) hipLaunchKernelGGL(head_loss_grad_kernel<4>, dim3((int)rows), dim3(HB), 0, st, hm, coords, target, mask, denom2, dist,
+    if (vec) DSNT_LAUNCH(head_loss_grad_kernel<4>, dim3((int)rows), dim3(HB), 0, st, hm, coords, target, mask, denom2, dist,
                                 reg_row, g_logits, h, w, sigma, gauss_k(sigma), reg_kind, reg_coeff);
-    else hipLaunchKernelGGL(head_loss_grad_kernel<1>, dim3((int)rows), dim3(HB), 0, st, hm, coords, target, mask, denom2, dist,
+    else DSNT_LAUNCH(head_loss_grad_kernel<1>, dim3((int)rows), dim3(HB), 0, st, hm, coords, target, mask, denom2, dist,
                             reg_row, g_logits, h, w, sigma, gauss_k(sigma), reg_kind, reg_coeff);
     DSNT_CHECK_LAUNCH("dsnt_head_loss_grad");
 }
@@ -906,7 +906,7 @@ extern "C" int dsnt_head_loss_grad(const float* hm, const float* coords, const f
 extern "C" int dsnt_head_loss_reduce(const float* dist, const float* reg_row, const float* mask, const float* denom2,
                                      float reg_coeff, float* loss, float* e2, int64_t rows, void* stream) {
     DSNT_REQUIRE(dist && denom2 && loss && e2 && rows > 0, DSNT_ERR_ARG, "dsnt_head_loss_reduce: bad argument");
-    hipLaunchKernelGGL(head_loss_reduce_kernel, dim3(1), dim3(HB), 0, (hipStream_t)stream, dist, reg_row, mask, denom2, reg_coeff,
+    DSNT_LAUNCH(head_loss_reduce_kernel, dim3(1), dim3(HB), 0, (hipStream_t)stream, dist, reg_row, mask, denom2, reg_coeff,
                        loss, e2, (long)rows);
     DSNT_CHECK_LAUNCH("dsnt_head_loss_reduce");
 }
@@ -916,7 +916,7 @@ extern "C" int dsnt_scale_by_scalar(float* x, const float* s, int64_t n, void* s
                  "dsnt_scale_by_scalar: n must be a positive multiple of 4, x 16-byte aligned");
     long gsz = (n / 4 + 255) / 256;
     if (gsz > 4096) gsz = 4096;
-    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, (float4*)x, s, (long)(n / 4));
+    DSNT_LAUNCH(scale_by_scalar_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, (float4*)x, s, (long)(n / 4));
     DSNT_CHECK_LAUNCH("dsnt_scale_by_scalar");
 }
 
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256) void fc2_fwd_kernel(const float* __restrict__ 
 extern "C" int dsnt_fc2_fwd(const float* hm, const float* w, const float* b, float* out, int64_t rows, int hw,
                             void* stream) {
     DSNT_REQUIRE(hm && w && out && rows > 0 && rows < (1LL << 31) && hw > 0, DSNT_ERR_ARG, "dsnt_fc2_fwd: bad argument");
-    hipLaunchKernelGGL(fc2_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, hm, w, b, out, hw);
+    DSNT_LAUNCH(fc2_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, hm, w, b, out, hw);
     DSNT_CHECK_LAUNCH("dsnt_fc2_fwd");
 }
 
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256) void fc2_bwd_kernel(const float* __restrict__ 
 extern "C" int dsnt_fc2_bwd(const float* g, const float* hm, const float* w, float* ghm, float* gw, float* gb,
                             int64_t rows, int hw, void* stream) {
     DSNT_REQUIRE(g && hm && w && gw && rows > 0 && rows < (1LL << 31) && hw > 0, DSNT_ERR_ARG, "dsnt_fc2_bwd: bad argument");
-    hipLaunchKernelGGL(fc2_bwd_kernel, dim3((hw + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, hm, w, ghm, gw, gb,
+    DSNT_LAUNCH(fc2_bwd_kernel, dim3((hw + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, hm, w, ghm, gw, gb,
                        (int)rows, hw);
     DSNT_CHECK_LAUNCH("dsnt_fc2_bwd");
 }

@@ -141,7 +141,7 @@ extern "C" int dsnt_encode_heatmaps(const float* target, float* out, int64_t row
                                     void* stream) {
     DSNT_REQUIRE(target && out, DSNT_ERR_ARG, "dsnt_encode_heatmaps: null tensor");
     if (int e = check_rows_hm("dsnt_encode_heatmaps", rows, h, w, sigma)) return e;
-    hipLaunchKernelGGL(encode_heatmaps_kernel, dim3((unsigned)rows), dim3(HB), 0, (hipStream_t)stream, target, out,
+    DSNT_LAUNCH(encode_heatmaps_kernel, dim3((unsigned)rows), dim3(HB), 0, (hipStream_t)stream, target, out,
                        h, w, bump_k(sigma));
     DSNT_CHECK_LAUNCH("dsnt_encode_heatmaps");
 }
@@ -150,7 +150,7 @@ extern "C" int dsnt_heatmap_mse_fwd(const float* hm, const float* target, float*
                                     int w, float sigma, void* stream) {
     DSNT_REQUIRE(hm && target && per_row, DSNT_ERR_ARG, "dsnt_heatmap_mse_fwd: null tensor");
     if (int e = check_rows_hm("dsnt_heatmap_mse_fwd", rows, h, w, sigma)) return e;
-    hipLaunchKernelGGL(heatmap_mse_fwd_kernel, dim3((unsigned)rows), dim3(HB), 0, (hipStream_t)stream, hm, target,
+    DSNT_LAUNCH(heatmap_mse_fwd_kernel, dim3((unsigned)rows), dim3(HB), 0, (hipStream_t)stream, hm, target,
                        per_row, h, w, bump_k(sigma));
     DSNT_CHECK_LAUNCH("dsnt_heatmap_mse_fwd");
 }
@@ -160,7 +160,7 @@ extern "C" int dsnt_heatmap_mse_bwd(const float* hm, const float* target, const 
     DSNT_REQUIRE(hm && target && gscale && dhm, DSNT_ERR_ARG, "dsnt_heatmap_mse_bwd: null tensor");
     if (int e = check_rows_hm("dsnt_heatmap_mse_bwd", rows, h, w, sigma)) return e;
     const float coef = (float)(2.0 / ((double)rows * h * w));
-    hipLaunchKernelGGL(heatmap_mse_bwd_kernel, dim3((unsigned)rows), dim3(HB), 0, (hipStream_t)stream, hm, target,
+    DSNT_LAUNCH(heatmap_mse_bwd_kernel, dim3((unsigned)rows), dim3(HB), 0, (hipStream_t)stream, hm, target,
                        gscale, dhm, h, w, bump_k(sigma), coef);
     DSNT_CHECK_LAUNCH("dsnt_heatmap_mse_bwd");
 }
@@ -169,7 +169,7 @@ extern "C" int dsnt_decode_heatmaps(const float* hm, float* coords, int64_t rows
                                     void* stream) {
     DSNT_REQUIRE(hm && coords, DSNT_ERR_ARG, "dsnt_decode_heatmaps: null tensor");
     if (int e = check_rows_hm("dsnt_decode_heatmaps", rows, h, w, 1.f)) return e;
-    hipLaunchKernelGGL(decode_heatmaps_kernel, dim3((unsigned)rows), dim3(HB), 0, (hipStream_t)stream, hm, coords, h,
+    DSNT_LAUNCH(decode_heatmaps_kernel, dim3((unsigned)rows), dim3(HB), 0, (hipStream_t)stream, hm, coords, h,
                        w, use_neighbours, (float)(2.0 / (double)w), (float)(2.0 / (double)h));
     DSNT_CHECK_LAUNCH("dsnt_decode_heatmaps");
 }

@@ -94,6 +94,7 @@ SIGNATURES = {
     'dsnt_bn_act_fwd': [P, P, P, I, P, L, I, P],
     'dsnt_bn_act_bwd_reduce': [P, P, P, P, P, P, I, P, L, I, P],
     'dsnt_bn_bwd_finalize': [P, I, L, I, P, P, I, P, P],
+    'dsnt_bn_eval_prep': [P, I, P],
     'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
     'dsnt_bn_act_bwd_apply_amax': [P, P, P, P, P, P, P, I, P, I, L, I, P, P],
     'dsnt_fill_zero': [P, L, P],
@@ -132,6 +133,15 @@ PLAIN = {
     'dsnt_last_error': (C.c_char_p, []),
     'dsnt_conv_fwd_bm': (I, [GP]),
     'dsnt_bn_tail_group': (I, []),
+    'dsnt_list_create': (P, []),
+    'dsnt_list_destroy': (None, [P]),
+    'dsnt_list_begin': (I, [P]),
+    'dsnt_list_end': (I, []),
+    'dsnt_list_sync': (I, [P, I, I]),
+    'dsnt_list_mark': (I, [P]),
+    'dsnt_list_segments': (I, [P]),
+    'dsnt_list_size': (I, [P]),
+    'dsnt_list_replay': (I, [P, I, C.POINTER(C.c_void_p), I]),
     'dsnt_conv_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_splits': (I, [GP]),

@@ -121,6 +121,7 @@ class Tape:
         self.use_f16x3 = self.use_bf16x6 and os.environ.get('DSNT_SPLIT', 'f16x3') == 'f16x3'
         self._f16_w_rows, self._f16_w_seen = [], set()
         self._f16_bn_rows = []
+        self._eval_bn_rows = []     # eval mode: every BatchNorm's vectors come from ONE table-driven launch per forward
         self._amax_buf, self._amax_used = None, 0      # zeroed at the start of every backward
         # DSNT_AMAX_ALL=0: only single-writer BN-backward outputs get a bound (A/B switch); default: bounds follow the
         # gradient through every writer that can report one (apply, axpy, pool / upsample backward) and through donations
@@ -143,6 +144,10 @@ class Tape:
         self._tail_group = self.lib.dsnt_bn_tail_group()
         self._tail_counters = torch.zeros(1 << 16, dtype=torch.int32, device=device)   # arrival tickets, self-resetting
         self._tail_used = 0
+        # replay from C (dsnt_list_*): a launch list is recorded once into the library and then issued by ONE call per
+        # segment instead of one ctypes call per launch (DSNT_C_REPLAY=0: the Python loop below)
+        self.c_replay = os.environ.get('DSNT_C_REPLAY', '1') != '0'
+        self._clists = {}
 
     # ------------------------------------------------------------------ buffers
     def empty(self, *shape, dtype=torch.float32):
@@ -221,6 +226,10 @@ class Tape:
             t = torch.tensor(self._f16_bn_rows, dtype=torch.int64).to(self.device)
             self._keep.append(t)
             self.f('dsnt_f16_prep_bn_bounds', t, len(self._f16_bn_rows))
+        if self._eval_bn_rows:
+            t = torch.tensor(self._eval_bn_rows, dtype=torch.int64).to(self.device)
+            self._keep.append(t)
+            self.f('dsnt_bn_eval_prep', t, len(self._eval_bn_rows))
         prep, self.fwd = self.fwd, saved
         self.fwd[pos:pos] = prep
 
@@ -389,6 +398,49 @@ class Tape:
                 self.bwd.append((None, k, 'bucket', 0))
             self.on_backward(mark)
 
+    def _compile(self, lst):
+        """Record `lst` into a C launch list: (handle, bucket ids after each segment)."""
+        lib = self.lib
+        h = lib.dsnt_list_create()
+        if not h:
+            raise RuntimeError('dsnt_list_create failed')
+        marks = []
+        try:
+            if self.use_lanes:
+                for lane in (1, 2):
+                    self._rc(lib.dsnt_list_sync(h, 0, lane), 'dsnt_list_sync')
+            self._rc(lib.dsnt_list_begin(h), 'dsnt_list_begin')
+            try:
+                for fn, args, name, lane in lst:
+                    if fn is None:
+                        if name == 'sync':
+                            self._rc(lib.dsnt_list_sync(h, args[0], args[1]), 'dsnt_list_sync')
+                        else:
+                            marks.append(args)
+                            lib.dsnt_list_mark(h)
+                        continue
+                    self._rc(fn(*args, C.c_void_p(lane)), name)          # recorded, not launched: `stream` = lane index
+            finally:
+                lib.dsnt_list_end()
+            if self.use_lanes:
+                for lane in (1, 2):
+                    self._rc(lib.dsnt_list_sync(h, lane, 0), 'dsnt_list_sync')
+        except Exception:
+            lib.dsnt_list_destroy(h)
+            raise
+        return h, marks
+
+    def _rc(self, rc, name):
+        if rc != 0:
+            raise RuntimeError('%s failed (%d): %s' % (name, rc, self.lib.dsnt_last_error().decode()))
+
+    def __del__(self):
+        try:
+            for h, _ in self._clists.values():
+                self.lib.dsnt_list_destroy(h)
+        except Exception:
+            pass
+
     def run(self, lst, bucket_hook=None, probe=None):
         """Replay a launch list.  `probe(entry)` (diagnostics / tests) is called before every launch."""
         main = torch.cuda.current_stream()
@@ -397,6 +449,21 @@ class Tape:
             self.wgrad_stream = torch.cuda.Stream()
         streams = (main, self.side_stream, self.wgrad_stream)
         ptrs = tuple(st.cuda_stream if st is not None else 0 for st in streams)
+        if self.c_replay and probe is None:
+            cl = self._clists.get(id(lst))
+            if cl is None:
+                cl = self._clists[id(lst)] = self._compile(lst)
+            h, marks = cl
+            arr = (C.c_void_p * 3)(*ptrs)
+            for seg in range(len(marks) + 1):
+                rc = self.lib.dsnt_list_replay(h, seg, arr, 3)
+                if rc != 0:
+                    torch.cuda.synchronize()
+                    self._tail_counters.zero_()
+                    self._rc(rc, 'dsnt_list_replay')
+                if seg < len(marks) and bucket_hook is not None:
+                    bucket_hook(marks[seg])
+            return
         if self.use_lanes:
             self.side_stream.wait_stream(main)
             self.wgrad_stream.wait_stream(main)
@@ -489,8 +556,11 @@ class Tape:
                 self.f('dsnt_bn_finalize', part, tiles, x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
                        bn.momentum, bn.eps, 1, n.mean, n.invstd, n.scale, n.shift)
         else:
-            self.f('dsnt_bn_finalize', None, 0, x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
-                   bn.momentum, bn.eps, 0, n.mean, n.invstd, n.scale, n.shift)
+            import struct
+            bits = struct.unpack('<I', struct.pack('<f', float(bn.eps)))[0]
+            self._eval_bn_rows.append([bn.gamma.data_ptr(), bn.beta.data_ptr(), bn.rmean.data_ptr(), bn.rvar.data_ptr(),
+                                       n.mean.data_ptr(), n.invstd.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
+                                       bn.C, bits])
         return n
 
     def bwd_tail(self, n, tiles):

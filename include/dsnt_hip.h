@@ -333,6 +333,10 @@ int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int C,
 int dsnt_bn_act_fwd(const float* x, const float* scale, const float* shift, int relu,
                     float* y, int64_t M, int C, void* stream);
 
+/* Eval-mode (running statistics) BatchNorm vectors of many layers in ONE launch: table rows of int64
+ * {gamma*, beta*, running_mean*, running_var*, mean*, invstd*, scale*, shift*, C, bits of float eps}; per row what
+ * dsnt_bn_finalize(training = 0) writes (inference.py:33-48 runs the model in eval mode). */
+int dsnt_bn_eval_prep(const int64_t* table, int rows, void* stream);
 /* Backward of y = relu?(bn(x)) given da = dL/dy, in three steps:
  *  reduce:   partial[tile][0][c] = sum dz, partial[tile][1][c] = sum dz*xhat,
  *            dz = da * (y > 0), xhat = (x - mean)*invstd;
@@ -430,6 +434,28 @@ int dsnt_sgd_step_guarded(float* p, const float* g, float* momentum_buf, int64_t
 /* flag[0] |= code if any of x[0..n) is NaN or +-inf (train.py:360 `np.isnan(loss.data[0])`, without the
  * device-to-host synchronisation: the caller reads the flag asynchronously); also flag[0] |= flag[1]. */
 int dsnt_nonfinite_flag(const float* x, int64_t n, int* flag, int code, void* stream);
+
+/* ------------------------------------------------------------------ launch lists
+ * The reference re-records its autograd graph and issues ~10^3 device ops from Python every step (train.py:355-384).
+ * Here a step is a fixed sequence of the entry points above; a launch list captures that sequence ONCE and replays it
+ * from C: between dsnt_list_begin and dsnt_list_end (per thread) every entry point validates its arguments as usual but
+ * records its kernel launches (arguments by value) instead of enqueueing them, and its `stream` argument is read as a
+ * LANE index 0..DSNT_MAX_LANES-1.  dsnt_list_sync appends "lane dst waits for everything lane src has been given so
+ * far" (an event the list owns); dsnt_list_mark ends a segment (the caller does host work there — e.g. starts an
+ * all-reduce — between replays) and returns the index of the segment that begins.  dsnt_list_replay enqueues one
+ * segment (-1: all) on the caller's streams, lane i -> streams[i].  A list holds pointers, not memory: the caller keeps
+ * every tensor it recorded alive and unchanged in address.  dsnt_amax (memset) cannot be recorded. */
+#define DSNT_MAX_LANES 8
+typedef struct dsnt_list dsnt_list;
+dsnt_list* dsnt_list_create(void);
+void dsnt_list_destroy(dsnt_list* l);
+int dsnt_list_begin(dsnt_list* l);
+int dsnt_list_end(void);
+int dsnt_list_sync(dsnt_list* l, int src_lane, int dst_lane);
+int dsnt_list_mark(dsnt_list* l);
+int dsnt_list_segments(const dsnt_list* l);
+int dsnt_list_size(const dsnt_list* l);
+int dsnt_list_replay(const dsnt_list* l, int segment, void* const* streams, int nstreams);
 
 /* ------------------------------------------------------------------ metrics
  * evaluator.py:66-81 + train.py:243-258: PCKh hits on device.

@@ -74,3 +74,24 @@ def test_missing_library_is_loud(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libdsnt_hip.so')
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         _lib.load()
+
+
+def test_launch_list_records_instead_of_launching():
+    """dsnt_list_*: between begin and end the entry points validate as usual and launch nothing; errors do not record."""
+    from dsnt import _lib
+    lib = _lib.load()
+    h = lib.dsnt_list_create()
+    assert h and lib.dsnt_list_size(h) == 0 and lib.dsnt_list_segments(h) == 1
+    assert lib.dsnt_list_end() != 0 and b'not recording' in lib.dsnt_last_error()
+    assert lib.dsnt_list_begin(h) == 0
+    assert lib.dsnt_list_begin(h) != 0                         # one recording per thread
+    g = _lib.ConvGeom(1, 8, 8, 6, 8, 8, 8, 1, 1, 1, 0, 1)     # invalid geometry: rejected, nothing recorded
+    assert lib.dsnt_conv_fwd(None, None, None, None, None, None, 0, None, None, None, C.byref(g), None) == 2
+    assert lib.dsnt_list_size(h) == 0
+    # a valid call records one launch without touching a device (pointers are only captured); stream = lane 1
+    assert lib.dsnt_axpy(C.c_void_p(4096), C.c_void_p(8192), 1.0, 0, 1024, C.c_void_p(1)) == 0
+    assert lib.dsnt_list_size(h) == 1
+    assert lib.dsnt_list_mark(h) == 1 and lib.dsnt_list_segments(h) == 2
+    assert lib.dsnt_list_end() == 0
+    assert lib.dsnt_list_replay(h, 5, None, 3) != 0            # bad arguments are refused before anything is enqueued
+    lib.dsnt_list_destroy(h)

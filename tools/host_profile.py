@@ -1,0 +1,32 @@
+"""Where does the HOST time of a train step go?  cProfile over 20 steps (enqueue only, GPU asynchronous)."""
+import cProfile, pstats, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'dsnt-pose2d_amd')]
+from dsnt.model import build_mpii_pose_model
+from dsnt import synthetic, optim
+dev = torch.device('cuda:0')
+model = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+synthetic.fill_state_dict(model, seed=0)
+model.cuda().train()
+x, target, mask = synthetic.batch(32, size=256, seed=1, mask_p=1.0)
+x, target, mask = x.to(dev), target.to(dev), mask.to(dev)
+model.hg._runner().ensure(dev)
+opt = optim.RMSprop(model, lr=2.5e-4)
+def step():
+    out = model(x)
+    loss = model.forward_loss(out, target, mask)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20):
+    step()
+    torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats('tottime').print_stats(18)
