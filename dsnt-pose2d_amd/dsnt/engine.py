@@ -96,7 +96,24 @@ class Tape:
         self.use_lanes = os.environ.get('DSNT_LANES', '1') != '0'
         self.side_stream = None
         self.wgrad_stream = None
-        self.wgrad_lane = 2 if (self.use_lanes and os.environ.get('DSNT_WGRAD_LANE', '0') != '0') else None
+        # weight gradients feed nothing downstream in backward.  The large ones (>= DSNT_WGRAD_LANE_ROWS output rows; 0 =
+        # all) go to a third lane: the chip then has work while the dependency chain walks the launch-bound
+        # low-resolution levels, and the main lane neither runs nor waits for the slab reductions (-0.9 ms/step on hg2).
+        # DSNT_WGRAD_LANE_RES=1 also moves convolutions with residual inputs, whose dY buffer is donated onwards and
+        # written again — the writer then has to wait for the lane (measured: +0.45 ms, off).
+        self.wgrad_lane = 2 if (self.use_lanes and os.environ.get('DSNT_WGRAD_LANE', '1') != '0') else None
+        self.wgrad_lane_rows = int(os.environ.get('DSNT_WGRAD_LANE_ROWS', '30000'))
+        self.wgrad_lane_res = os.environ.get('DSNT_WGRAD_LANE_RES', '0') != '0'
+        self.wgrad_lane_from = (0, 1) if os.environ.get('DSNT_WGRAD_LANE_SIDE', '1') != '0' else (0,)
+        self._wgrad_lane_reads = set()
+        # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
+        # phase: a `release point` is the backward of an up-sampling whose low-resolution operand has at most
+        # DSNT_WGRAD_RELEASE_ROWS rows.  Issued as they come, the weight gradients share the chip with the large
+        # data-gradient kernels and are gone by the time the small levels start; held back, they run beside them.
+        # Only while a release point is still ahead in the backward order (a ResNet has none: nothing is held back).
+        self.release_rows = int(os.environ.get('DSNT_WGRAD_RELEASE_ROWS', '8192'))
+        self._release_total, self._release_left = 0, 0
+        self._held = []
         self.acts = []          # every activation in creation order (debugging / introspection)
         self.dgrad_slots = []   # (conv params, dst offset) of every conv whose data gradient is needed
         self.dgrad_total = 0
@@ -127,6 +144,8 @@ class Tape:
         # gradient through every writer that can report one (apply, axpy, pool / upsample backward) and through donations
         self.amax_all = os.environ.get('DSNT_AMAX_ALL', '1') != '0'
         self._f16_dw_rows = []      # fp16x3 planes of the re-packed data-gradient weights
+        self._dgrad_pack = None     # arguments of the one re-packing launch (set by finish, emitted by emit_f16_prep)
+        self.prep_on_side_lane = os.environ.get('DSNT_PREP_LANE', '1') != '0'
         self.dgrad_planes16, self.dgrad_bounds = None, None
         # every fp16x3 launch with the tensors behind its operands and bounds: (list entry, {...}) — lets a test walk a
         # step launch by launch and hold each bound against the operand it must dominate (tests/test_bounds_gpu.py)
@@ -215,9 +234,21 @@ class Tape:
         assert n.abound is not None, 'fp16x3 backward needs the BN bound its forward conv registered'
         return n.abound
 
-    def emit_f16_prep(self, pos):
-        """Insert the fp16x3 preparation launches (weights, BN bounds) at position `pos` of the forward list."""
+    # launches that read weight planes or operand bounds: the preparation must have finished before the first of them
+    _PREP_CONSUMERS = ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_bf16x6_ex', 'dsnt_conv_fwd_bf16x6')
+
+    def emit_f16_prep(self, pos, head=()):
+        """Insert the per-step preparation launches at position `pos` of the forward list: fp16x3 weight planes and BN
+        operand bounds, eval-mode BN vectors and — weights do not change between a forward and its backward — the
+        re-packed / split data-gradient weights.  `head` = entries already on the list at `pos` that belong to the
+        preparation (the bf16 split of the arena).  With lanes, all of it runs on the side lane beside the stem
+        convolution (which reads fp32 weights) and the main lane waits right before the first launch that needs it."""
+        # (eval mode: the BN vectors are needed at once, and there is nothing to hide the launches behind)
+        side = 1 if (self.use_lanes and self.prep_on_side_lane and self.training) else 0
         saved, self.fwd = self.fwd, []
+        saved_lane, self.lane = self.lane, side
+        for fn, args, name, _ in head:
+            self.fwd.append((fn, args, name, side))
         if self._f16_w_rows:
             t = torch.tensor(self._f16_w_rows, dtype=torch.int64).to(self.device)
             self._keep.append(t)
@@ -230,8 +261,20 @@ class Tape:
             t = torch.tensor(self._eval_bn_rows, dtype=torch.int64).to(self.device)
             self._keep.append(t)
             self.f('dsnt_bn_eval_prep', t, len(self._eval_bn_rows))
+        if self._dgrad_pack is not None:
+            self.f('dsnt_conv_pack_dgrad_all', *self._dgrad_pack)
+        if self._f16_dw_rows:
+            t = torch.tensor(self._f16_dw_rows, dtype=torch.int64).to(self.device)
+            self._keep.append(t)
+            self.f('dsnt_f16_prep_weights', t, len(self._f16_dw_rows))
+        self.lane = saved_lane
         prep, self.fwd = self.fwd, saved
+        del self.fwd[pos:pos + len(head)]
         self.fwd[pos:pos] = prep
+        if side and prep:
+            first = next((i for i in range(pos + len(prep), len(self.fwd))
+                          if self.fwd[i][0] is not None and self.fwd[i][2] in self._PREP_CONSUMERS), len(self.fwd))
+            self.fwd.insert(first, (None, (side, 0, torch.cuda.Event()), 'sync', 0))
 
     def new_tail(self):
         """A disabled dsnt_bn_tail to hand to a statistics-producing launch; `claim_tail` switches it on."""
@@ -336,32 +379,42 @@ class Tape:
                 rows.append([src, dst, p.Cout, p.R, p.S, p.Cin])
             table = torch.tensor(rows, dtype=torch.int32).to(self.device)
             self._keep.append(table)
-            self.b('dsnt_conv_pack_dgrad_all', table, len(rows), self.param_arena, self.dgrad_f32,
-                   self.dgrad_planes, total)
+            # launched by the forward list's preparation (emit_f16_prep), off the backward's critical path
+            self._dgrad_pack = (table, len(rows), self.param_arena, self.dgrad_f32, self.dgrad_planes, total)
             self.dgrad_total = total
             if self.use_f16x3:
                 self.dgrad_planes16 = self.empty(2 * total, dtype=torch.float16)
                 self.dgrad_bounds = self.empty(64 * len(rows))
         prep_pos = len(self.bwd)
+        self._release_left = self._release_total
         for fn in reversed(self._bwd_emitters):
             fn()
         self._bwd_emitters = []
-        # fp16x3: zero the amax slots, split the re-packed data-gradient weights that some conv asked for
+        # fp16x3: zero the amax slots (the re-packed data-gradient weights are split by the forward list's preparation)
         saved, self.bwd = self.bwd, []
         if self._amax_used:
             self.b('dsnt_fill_zero', self._amax_buf, self._amax_used)
-        if self._f16_dw_rows:
-            t = torch.tensor(self._f16_dw_rows, dtype=torch.int64).to(self.device)
-            self._keep.append(t)
-            self.b('dsnt_f16_prep_weights', t, len(self._f16_dw_rows))
         prep, self.bwd = self.bwd, saved
         self.bwd[prep_pos:prep_pos] = prep
         if self._pending_reduce:          # convolutions outside every parameter bucket (stand-alone modules)
-            if self.wgrad_lane is not None:
-                self.sync_bwd(self.wgrad_lane, 0)
-            self.sync_bwd(1, 0)
-            self.lane = 0
+            self.lane = self._flush_lane()
             self.flush_wgrad()
+
+    def release_wgrads(self):
+        """Put the held-back weight-gradient launches on the backward list here."""
+        if self._held:
+            self.bwd.extend(self._held)
+            self._held = []
+
+    def _flush_lane(self):
+        """The lane that reduces a bucket's weight-gradient slabs, made to wait for every lane that wrote one.  With a
+        weight-gradient lane it is that lane — the main lane neither waits for the backlog of weight gradients nor
+        runs the reduction; without, the main lane."""
+        self.release_wgrads()
+        fl = self.wgrad_lane if self.wgrad_lane is not None else 0
+        for src in (0, 1):
+            self.sync_bwd(src, fl)
+        return fl
 
     def flush_wgrad(self):
         """Emit the one-launch reduction of every weight-gradient slab written since the last flush."""
@@ -389,13 +442,12 @@ class Tape:
         list the marker lands right after the last launch that writes bucket k's gradients."""
         if self.training:
             def mark():
-                if self.wgrad_lane is not None:
-                    self.sync_bwd(self.wgrad_lane, 0)     # the bucket's weight gradients are complete
-                self.sync_bwd(1, 0)
-                lane, self.lane = self.lane, 0
+                lane, self.lane = self.lane, self._flush_lane()
                 self.flush_wgrad()
+                # the marker carries the lane on which the bucket's gradients become complete: `run` calls the hook
+                # with that lane's stream current, so a collective started there orders itself after the reduction
+                self.bwd.append((None, k, 'bucket', self.lane))
                 self.lane = lane
-                self.bwd.append((None, k, 'bucket', 0))
             self.on_backward(mark)
 
     def _compile(self, lst):
@@ -416,7 +468,7 @@ class Tape:
                         if name == 'sync':
                             self._rc(lib.dsnt_list_sync(h, args[0], args[1]), 'dsnt_list_sync')
                         else:
-                            marks.append(args)
+                            marks.append((args, lane))
                             lib.dsnt_list_mark(h)
                         continue
                     self._rc(fn(*args, C.c_void_p(lane)), name)          # recorded, not launched: `stream` = lane index
@@ -445,8 +497,13 @@ class Tape:
         """Replay a launch list.  `probe(entry)` (diagnostics / tests) is called before every launch."""
         main = torch.cuda.current_stream()
         if self.use_lanes and self.side_stream is None:
+            # (stream priorities were tried — chain on high-priority streams, weight gradients on a normal one — and
+            # change nothing on this hardware)
             self.side_stream = torch.cuda.Stream()
             self.wgrad_stream = torch.cuda.Stream()
+        return self._run(lst, main, bucket_hook, probe)
+
+    def _run(self, lst, main, bucket_hook, probe):
         streams = (main, self.side_stream, self.wgrad_stream)
         ptrs = tuple(st.cuda_stream if st is not None else 0 for st in streams)
         if self.c_replay and probe is None:
@@ -462,7 +519,9 @@ class Tape:
                     self._tail_counters.zero_()
                     self._rc(rc, 'dsnt_list_replay')
                 if seg < len(marks) and bucket_hook is not None:
-                    bucket_hook(marks[seg])
+                    k, lane = marks[seg]
+                    with torch.cuda.stream(streams[lane]):
+                        bucket_hook(k)
             return
         if self.use_lanes:
             self.side_stream.wait_stream(main)
@@ -475,7 +534,8 @@ class Tape:
                     ev.record(streams[src])
                     streams[dst].wait_event(ev)
                 elif bucket_hook is not None:
-                    bucket_hook(args)
+                    with torch.cuda.stream(streams[lane]):
+                        bucket_hook(args)
                 continue
             if probe is not None:
                 probe(entry)
@@ -498,6 +558,9 @@ class Tape:
         if a.grad is None:
             a.grad = self.empty(a.N, a.H, a.W, a.C)
             acc = 0
+        elif a.grad.data_ptr() in self._wgrad_lane_reads:
+            self._wgrad_lane_reads.discard(a.grad.data_ptr())
+            self.sync_bwd(self.wgrad_lane, self.lane)        # a weight gradient on its own lane still reads this buffer
         if self.use_f16x3 and amax and (self.amax_all or (amax == 'apply' and acc == 0)):
             if a.grad_amax is None:
                 a.grad_amax = self.amax_slot()
@@ -652,9 +715,23 @@ class Tape:
             # the weight gradient feeds nothing downstream in backward: run it on its own lane so the
             # data-gradient chain never waits for it
             cur = self.lane
-            wl = self.wgrad_lane if self.wgrad_lane is not None else cur
+            wl = cur
+            if self.wgrad_lane is not None:
+                # DSNT_WGRAD_LANE_ROWS > 0: only the large main-lane convolutions whose dY nobody writes again (no
+                # residual inputs: the gradient buffer is not donated onwards) — their weight gradients then fill the
+                # chip while the main lane walks the launch-bound low-resolution levels
+                if self.wgrad_lane_rows == 0 or (cur in self.wgrad_lane_from and (self.wgrad_lane_res or (res1 is None and res2 is None)) and
+                                                 g.N * g.Ho * g.Wo >= self.wgrad_lane_rows):
+                    wl = self.wgrad_lane
+            hold = wl != cur and self._release_left > 0
+            if hold:
+                listed, self.bwd = self.bwd, self._held
             self.sync_bwd(cur, wl)
             self.lane = wl
+            if wl != cur:
+                # gy may be donated onwards and accumulated into by a later launch of another lane: that writer waits
+                # for the weight-gradient lane first (grad_target)
+                self._wgrad_lane_reads.add(gy.data_ptr())
             nws = self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g))
             w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
             if self.defer_reduce:
@@ -696,6 +773,8 @@ class Tape:
                 self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
                        p.gw, p.gb, 0, g)
             self.lane = cur
+            if hold:
+                self.bwd = listed
             if need_input_grad:
                 nw = p.w.numel()
                 pad_d = p.dil * (p.R - 1) - p.pad
@@ -845,7 +924,13 @@ class Tape:
         else:
             self.f('dsnt_upsample2_add_fwd', up.buf, low.buf, out.buf, up.N, up.H, up.W, up.C)
         if self.training:
+            point = self.wgrad_lane is not None and low.M <= self.release_rows
+            self._release_total += point
+
             def backward():
+                if point:
+                    self._release_left -= 1
+                    self.release_wgrads()
                 buf, acc = self.grad_target(low, amax=True)
                 if low.grad_amax is not None:
                     self.b('dsnt_upsample2_bwd_amax', out.grad, buf, acc, up.N, up.H, up.W, up.C, low.grad_amax)

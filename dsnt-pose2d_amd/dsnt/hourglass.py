@@ -200,14 +200,14 @@ class Program:
         P._bn = {}
 
         N, Cc, H, W = in_shape
+        prep_pos = len(tape.fwd)
         if tape.use_bf16x6:
             tape.f('dsnt_split_bf16x3', arena.params, arena.planes, arena.numel)
-        prep_pos = len(tape.fwd)
+        prep_head = tuple(tape.fwd[prep_pos:])
         self.in_nchw = tape.empty(N, Cc, H, W)
         x = tape.from_planar(self.in_nchw, _ceil4(Cc), 'input')
         self.in_act = x
         outs = root.trace(tape, x, P)
-        tape.emit_f16_prep(prep_pos)        # fp16x3: weight planes + operand bounds, before the first convolution
         single = not isinstance(outs, (list, tuple))
         self.single = single
         outs = [outs] if single else list(outs)
@@ -220,6 +220,9 @@ class Program:
         self.input_grad = input_grad and training
         if training:
             tape.finish()
+        # weight planes, operand bounds, data-gradient weights: before the first convolution that reads them
+        tape.emit_f16_prep(prep_pos, prep_head)
+        if training:
             if self.input_grad:
                 self.gx = tape.empty(N, Cc, H, W)
                 if x.grad is None:

@@ -1,0 +1,36 @@
+import sys, collections, ctypes as C
+sys.path.insert(0, '/root/repo/dsnt-pose2d_amd')
+import torch
+from dsnt.model import build_mpii_pose_model
+from dsnt.hourglass import Arena, Program
+from dsnt._lib import ConvGeom
+from dsnt import _lib
+_lib.ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+import dsnt.engine as E
+E._lib.ptr = _lib.ptr
+m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+m.train()
+root = m.hg if hasattr(m, 'hg') else m
+ar = Arena(root, torch.device('cpu'))
+prog = Program(root, ar, (32, 3, 256, 256), True, False)
+t = prog.tape
+def geom(args):
+    for a in args:
+        try:
+            o = a._obj
+        except AttributeError:
+            continue
+        if isinstance(o, ConvGeom):
+            return o
+    return None
+for nm, lst in (('fwd', t.fwd), ('bwd', t.bwd)):
+    cnt = collections.Counter()
+    for e in lst:
+        fn, args, name, lane = e
+        if fn is None: continue
+        g = geom(args)
+        if g is not None:
+            cnt[(name, g.H, g.Cin, g.Cout, g.R, g.stride, lane)] += 1
+    print(nm)
+    for k, v in sorted(cnt.items(), key=lambda kv: (-kv[0][1], kv[0][0])):
+        print('  ', v, k)

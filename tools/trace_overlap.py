@@ -20,7 +20,8 @@ for i, r in enumerate(rows):
     ev.append((r[0], 1, i)); ev.append((r[1], -1, i))
 ev.sort()
 active, last = set(), t0
-busy = multi = idle = 0
+busy = multi = idle = thin = 0
+thin_by = collections.Counter()
 excl = collections.Counter(); gap_after = collections.Counter(); tot = collections.Counter(); cnt = collections.Counter()
 last_ended = None
 for t, d, i in ev:
@@ -31,6 +32,9 @@ for t, d, i in ev:
     else:
         busy += dt
         if len(active) >= 2: multi += dt
+        if sum(rows[j][4] // max(1, rows[j][5]) for j in active) < 256:      # fewer workgroups in flight than CUs
+            thin += dt
+            for j in active: thin_by[rows[j][2]] += dt
         else: excl[rows[next(iter(active))][2]] += dt
     if d == 1: active.add(i)
     else: active.discard(i); last_ended = i
@@ -39,6 +43,8 @@ for r in rows: tot[r[2]] += r[1] - r[0]; cnt[r[2]] += 1
 ms = lambda x: x / steps / 1e6
 print('per step: wall %.3f ms | busy %.3f | idle %.3f | >=2 kernels in flight %.3f | sum of kernel durations %.3f | launches %d' % (
     ms(t1 - t0), ms(busy), ms(idle), ms(multi), ms(sum(tot.values())), len(rows) // steps))
+print('under-filled (all kernels in flight together < 256 workgroups): %.3f ms/step; by kernel: %s' % (
+    ms(thin), ', '.join('%s %.2f' % (k[:28], ms(v)) for k, v in thin_by.most_common(8))))
 small = sum(r[1] - r[0] for r in rows if r[4] // max(1, r[5]) < 256)
 print('kernels with < 256 workgroups: %d launches/step, %.3f ms/step' % (sum(1 for r in rows if r[4] // max(1, r[5]) < 256) // steps, ms(small)))
 print('%-58s %6s %8s %8s %8s' % ('kernel', 'n/step', 'total', 'alone', 'gap-after'))
