@@ -29,6 +29,7 @@ struct BnTailP {
     const float* gamma; const float* beta; float* rmean; float* rvar;
     float momentum, eps;
     float* o0; float* o1; float* o2; float* o3;
+    unsigned* amax;                    // independent of the tail: raise this 64-slot bound to max|output| (fp16x3 operand bounds)
 };
 
 // Write-through (sc1) store of a partial sum: visible to every XCD once the storing wave has drained vmcnt, so the
@@ -185,6 +186,7 @@ __device__ __forceinline__ void bn_tail_run(const BnTailP& t, float* partial, in
 static inline int bn_tail_fill(BnTailP& out, const dsnt_bn_tail* in, const char* who) {
     static_assert(sizeof(BnTailP) == sizeof(dsnt_bn_tail), "dsnt_bn_tail layout");
     out.counters = nullptr;
+    out.amax = in ? reinterpret_cast<unsigned*>(in->amax) : nullptr;
     if (!in || !in->counters) return DSNT_OK;
     DSNT_REQUIRE(in->level2 && in->out2 && (in->mode == 0 || in->mode == 1), DSNT_ERR_ARG, "%s: incomplete dsnt_bn_tail", who);
     DSNT_REQUIRE(in->mode == 1 || (in->out0 && in->out1 && in->out3), DSNT_ERR_ARG,

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(
     const bool active = rl < rpar;
     const long row0 = (long)blockIdx.x * TILE_ROWS;
     const long row1 = row0 + TILE_ROWS < M ? row0 + TILE_ROWS : M;
+    float am = 0.f;                                  // max |written value| (tail.amax: fp16x3 bound of a raw consumer)
     for (int cg0 = 0; cg0 < C4; cg0 += cgs) {
         const int cg = cg0 + cg_l;
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
     const long M = (long)N * Ho * Wo;
     const long row0 = (long)blockIdx.x * TILE_ROWS;
     const long row1 = row0 + TILE_ROWS < M ? row0 + TILE_ROWS : M;
+    float am = 0.f;                                  // max |written value| (tail.amax: fp16x3 bound of a raw consumer)
     for (int cg0 = 0; cg0 < C4; cg0 += cgs) {
         const int cg = cg0 + cg_l;
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
                     v = make_float4(u.x + l.x, u.y + l.y, u.z + l.z, u.w + l.w);
                 }
                 reinterpret_cast<float4*>(y)[r * C4 + cg] = v;
+                am = fmaxf(fmaxf(am, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
                 s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
             tail_store4(p1, make_float4(acc[4], acc[5], acc[6], acc[7]));
         }
     }
+    if (tail.amax) amax_commit(am, tail.amax);
     if (tail.counters) bn_tail_run<256>(tail, partial, (int)((M + TILE_ROWS - 1) / TILE_ROWS), C, M, blockIdx.x, 1, red);
 }
 

@@ -40,7 +40,8 @@ class BnTail(C.Structure):
     _fields_ = [('mode', C.c_int), ('accumulate', C.c_int), ('counters', C.c_void_p), ('level2', C.c_void_p),
                 ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
                 ('momentum', C.c_float), ('eps', C.c_float),
-                ('out0', C.c_void_p), ('out1', C.c_void_p), ('out2', C.c_void_p), ('out3', C.c_void_p)]
+                ('out0', C.c_void_p), ('out1', C.c_void_p), ('out2', C.c_void_p), ('out3', C.c_void_p),
+                ('amax', C.c_void_p)]
 
 
 TP = C.POINTER(BnTail)

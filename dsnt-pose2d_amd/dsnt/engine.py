@@ -32,7 +32,7 @@ BN_MOMENTUM = 0.1
 
 class Act:
     """An activation on the tape: NHWC buffer + lazily created gradient / batch statistics."""
-    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'stats_tail')
+    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'stats_tail', 'amax_tail')
 
     def __init__(self, buf, name=''):
         self.buf = buf
@@ -40,6 +40,7 @@ class Act:
         self.grad = None        # torch tensor once some backward op has written it
         self.stats = None       # (partial tensor, ntiles)
         self.stats_tail = None  # BnTail of the launch that writes `stats`: the first BatchNorm over this tensor claims it
+        self.amax_tail = None   # fp16x3: the dsnt_bn_tail of the producing launch if it can leave max|buf| (operand_amax)
         self.grad_amax = None   # fp16x3: device scalar max|grad| when ONE bn-backward apply wrote the whole gradient
         self.name = name
 
@@ -140,6 +141,8 @@ class Tape:
         self._f16_bn_rows = []
         self._eval_bn_rows = []     # eval mode: every BatchNorm's vectors come from ONE table-driven launch per forward
         self._amax_buf, self._amax_used = None, 0      # zeroed at the start of every backward
+        self.raw_f16 = os.environ.get('DSNT_RAW_F16', '1') != '0'      # A/B switch: bounds of raw operands from the producers' epilogues
+        self._famax_buf, self._famax_used, self._famax_of = None, 0, {}   # forward activations: zeroed at the start of every forward
         # DSNT_AMAX_ALL=0: only single-writer BN-backward outputs get a bound (A/B switch); default: bounds follow the
         # gradient through every writer that can report one (apply, axpy, pool / upsample backward) and through donations
         self.amax_all = os.environ.get('DSNT_AMAX_ALL', '1') != '0'
@@ -228,6 +231,25 @@ class Tape:
         self._amax_used += 64
         return self._amax_buf[self._amax_used - 64:self._amax_used]
 
+    def operand_amax(self, x):
+        """Bound slot for activation x used as a RAW fp16x3 operand (no BatchNorm in between: skip projections, `lin`
+        convolutions): the launch that produced x is asked — through its dsnt_bn_tail, read at launch time — to leave
+        max|x| there.  None if the producer cannot."""
+        t = x.amax_tail
+        if t is None or not self.use_f16x3 or not self.raw_f16:
+            return None
+        slot = self._famax_of.get(id(t))
+        if slot is None:
+            if self._famax_buf is None:
+                self._famax_buf = self.empty(64 * 256)
+            assert self._famax_used + 64 <= self._famax_buf.numel()
+            slot = self._famax_buf[self._famax_used:self._famax_used + 64]
+            self._famax_used += 64
+            t.amax = slot.data_ptr()
+            self._famax_of[id(t)] = slot
+            self._keep.append(t)
+        return slot
+
     def f16_bn_bound_bwd(self, n):
         """The same bound for a backward consumer.  The forward list computes it every step (emit_f16_prep) only if
         some forward conv asked for it before the list was closed; rows added later would be lost."""
@@ -267,6 +289,10 @@ class Tape:
             t = torch.tensor(self._f16_dw_rows, dtype=torch.int64).to(self.device)
             self._keep.append(t)
             self.f('dsnt_f16_prep_weights', t, len(self._f16_dw_rows))
+        self.lane = 0
+        if self._famax_used:
+            self.f('dsnt_fill_zero', self._famax_buf, self._famax_used)
+            self.fwd.insert(0, self.fwd.pop())      # main lane, first: every producer comes after it
         self.lane = saved_lane
         prep, self.fwd = self.fwd, saved
         del self.fwd[pos:pos + len(head)]
@@ -358,7 +384,7 @@ class Tape:
         if not self.use_lanes:
             return x
         xb = Act(x.buf, x.name + '/branch')
-        xb.stats, xb.stats_tail = x.stats, x.stats_tail
+        xb.stats, xb.stats_tail, xb.amax_tail = x.stats, x.stats_tail, x.amax_tail
         if self.training:
             def join_grad():
                 if xb.grad is not None:
@@ -683,16 +709,22 @@ class Tape:
             part = self.empty(tiles, 2, p.Cout)
             y.stats = (part, tiles)
             y.stats_tail = tail = self.new_tail()
+        if use6 and self.use_f16x3:
+            # the large-tile kernels can leave max|y| behind: a later consumer of the raw y claims it (operand_amax)
+            y.amax_tail = tail = tail if tail is not None else BnTail()
         r1 = res1.buf if res1 is not None else None
         r2 = res2.buf if res2 is not None else None
         if self.use_f16x3 and self.training and normed:
             self.f16_bn_bound(src)              # also for the weight gradient of convs whose forward is not fp16x3
-        use16 = use6 and self.use_f16x3 and self.training and normed and p.wq16 is not None
+        # fp16x3 needs a bound of the A operand: train-mode BatchNorm parameters, or the producer's max|x| for a raw x
+        x_amax = self.operand_amax(x) if (use6 and not normed and p.wq16 is not None) else None
+        use16 = use6 and self.use_f16x3 and p.wq16 is not None and ((self.training and normed) or x_amax is not None)
         if use16:
             self.f16_weights(p)
-            e = self.f('dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, self.f16_bn_bound(src), p.b, y.buf,
+            ab = self.f16_bn_bound(src) if normed else x_amax
+            e = self.f('dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, ab, p.b, y.buf,
                        sc, sh, relu, r1, r2, part, g, None, tail)
-            self.f16_uses.append((e, dict(kind='fwd', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=src.abound,
+            self.f16_uses.append((e, dict(kind='fwd', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
                                           w=p.w, w_bound=p.wb)))
         elif use6:
             self.f('dsnt_conv_fwd_bf16x6_ex', x.buf, p.wq, p.wq_stride, p.b, y.buf, sc, sh, relu, r1, r2, part, g,
@@ -741,8 +773,8 @@ class Tape:
                 grouped = (w6 and normed and res1 is None and res2 is None and wl == cur and
                            0 < g.N * g.Ho * g.Wo <= self.group_rows)
                 # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
-                w16 = w6 and self.use_f16x3 and normed and y.grad_amax is not None
-                ab = self.f16_bn_bound_bwd(src) if w16 else None
+                w16 = w6 and self.use_f16x3 and (normed or x_amax is not None) and y.grad_amax is not None
+                ab = (self.f16_bn_bound_bwd(src) if normed else x_amax) if w16 else None
                 if grouped:
                     desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
                     if w16:
@@ -834,8 +866,13 @@ class Tape:
                     dgrad(dz, None, part, bnb, tl)
                     self._norm_backward(src, dz, reduced=(part, tiles), finalised=tl is not None)
                 else:
-                    buf, acc = self.grad_target(x)
-                    dgrad(buf, buf if acc else None)
+                    # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
+                    buf, acc = self.grad_target(x, amax=bool(d6) and self.raw_f16)
+                    tl = None
+                    if x.grad_amax is not None:
+                        tl = BnTail()
+                        tl.amax = x.grad_amax.data_ptr()
+                    dgrad(buf, buf if acc else None, tail=tl)
             # identity branches last: gy is dead after the launches above (the weight-gradient lane
             # must have read it before anyone accumulates into the donated buffer)
             if res1 is not None or res2 is not None:
@@ -867,6 +904,8 @@ class Tape:
             tiles = (y.M + 127) // 128
             part = self.empty(tiles, 2, x.C)
             y.stats_tail = self.new_tail()
+            if self.use_f16x3 and y.M >= self.bf16x6_min_rows:
+                y.amax_tail = y.stats_tail = y.stats_tail if y.stats_tail is not None else BnTail()
             self.f('dsnt_maxpool2_fwd_stats', x.buf, y.buf, idx, part, x.N, x.H, x.W, x.C, y.stats_tail)
             y.stats = (part, tiles)
         else:
@@ -919,6 +958,8 @@ class Tape:
             tiles = (out.M + 127) // 128
             part = self.empty(tiles, 2, up.C)
             out.stats_tail = self.new_tail()
+            if self.use_f16x3 and out.M >= self.bf16x6_min_rows:
+                out.amax_tail = out.stats_tail = out.stats_tail if out.stats_tail is not None else BnTail()
             self.f('dsnt_upsample2_add_fwd_stats', up.buf, low.buf, out.buf, part, up.N, up.H, up.W, up.C, out.stats_tail)
             out.stats = (part, tiles)
         else:

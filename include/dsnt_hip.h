@@ -46,7 +46,12 @@ typedef enum {
  * level2:   [(mtiles + 31) / 32][2][C] doubles of scratch;
  * mode 0: gamma/beta (may be NULL), running_mean/var (both or neither), momentum, eps -> out0..3 = mean, invstd,
  *         scale, shift [C];  mode 1: out0 = dgamma, out1 = dbeta (either may be NULL; += if accumulate),
- *         out2 = coef [2][C] (sum dz / M, sum dz*xhat / M).  counters == NULL (or a NULL struct): no tail. */
+ *         out2 = coef [2][C] (sum dz / M, sum dz*xhat / M).  counters == NULL (or a NULL struct): no tail.
+ * amax (independent of the tail, may be NULL): a 64-float bound as dsnt_amax leaves it; the launch RAISES it to the
+ *         max |value| it writes to its output (atomic max on the bit patterns of non-negative floats: the caller zeroes
+ *         the 64 slots once per step) — the fp16x3 operand bound of a consumer that reads the output without a
+ *         BatchNorm in between (skip projections, `lin` convolutions: hourglass.py:45-48,120-135), or of a data
+ *         gradient written by a convolution epilogue.  Not with a bn_bwd_epilogue. */
 typedef struct {
     int mode, accumulate;
     unsigned* counters;
@@ -54,6 +59,7 @@ typedef struct {
     const float* gamma; const float* beta; float* running_mean; float* running_var;
     float momentum, eps;
     float* out0; float* out1; float* out2; float* out3;
+    float* amax;
 } dsnt_bn_tail;
 /* m-tiles whose partial rows one first-level reduction covers (32) */
 int dsnt_bn_tail_group(void);

@@ -4,7 +4,8 @@ launch by launch — hg2 batch 32 and hg8 batch 16 at 256 px (BASELINE configs 3
 and, right before every fp16x3 launch, hold each bound slot against the tensor it must dominate AS IT IS AT THAT
 MOMENT (gradient buffers are donated and accumulated into, so the end-of-step content is not what a consumer read):
 
-* A operands seen through a train-mode BatchNorm(+ReLU): max|relu?(x scale + shift)| <= the analytic bound;
+* A operands seen through a train-mode BatchNorm(+ReLU): max|relu?(x scale + shift)| <= the analytic bound; raw A
+  operands (skip projections, `lin` convolutions): max|x| <= the slot the producing launch's epilogue raised;
 * weights (forward layout and the re-packed data-gradient layout): max|w| <= the bound the prep launch wrote;
 * gradient operands (dY of data-gradient and weight-gradient launches): max|dY| <= the slot its writers raised.
 
@@ -40,7 +41,7 @@ def _train_step_with_probe(base, reg, batch):
     bad = []
 
     def amax_a(u):
-        v = u['x'] * u['sc'] + u['sh']
+        v = u['x'] * u['sc'] + u['sh'] if u['sc'] is not None else u['x'].clone()      # raw operand: the producer's amax
         if u['relu']:
             v = v.clamp_(min=0)
         return float(v.abs().max())

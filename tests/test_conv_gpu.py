@@ -756,3 +756,64 @@ def test_bn_tail_forward_matches_the_finalize_launch(kind):
     run(C.byref(tail_s))                                   # tickets re-armed themselves
     assert all(torch.equal(a, b) for a, b in zip(got, first)) and int(keep[0].abs().max()) == 0
     assert (rm - (0.9 * rm1 + 0.1 * first[0])).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize('path', ['f32', 'bf16x6', 'f16x3'])
+@pytest.mark.parametrize('k,with_res', [(1, True), (3, False)])
+def test_epilogue_leaves_the_bound_of_its_output(path, k, with_res):
+    """dsnt_bn_tail.amax: the launch raises a 64-slot bound to max|y| of what it wrote (bias and residual included) —
+    the fp16x3 operand bound of a consumer that reads y raw (skip projections / `lin` convolutions,
+    hourglass.py:45-48,120-135).  Exactly the maximum (a max is order-independent), never lowered, and a second
+    launch into the same slots keeps the larger value."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call, ConvGeom, BnTail
+    dev = torch.device('cuda:0')
+    N, H, Cin, Cout = 2, 32, 64, 128
+    g = ConvGeom(N, H, H, Cin, H, H, Cout, k, k, 1, k // 2, 1)
+    x = torch.randn(N, H, H, Cin, device=dev)
+    w = torch.randn(Cout, k, k, Cin, device=dev) * 0.1
+    b = torch.randn(Cout, device=dev)
+    res = torch.randn(N, H, H, Cout, device=dev) * 3 if with_res else None
+    y = torch.empty(N, H, H, Cout, device=dev)
+    slots = torch.zeros(64, device=dev)
+    t = BnTail()
+    t.amax = slots.data_ptr()
+
+    def launch(xx):
+        if path == 'f32':
+            call('dsnt_conv_fwd_ex', ptr(xx), ptr(w), ptr(b), ptr(y), None, None, 0, ptr(res) if with_res else None, None,
+                 None, C.byref(g), None, C.byref(t))
+        elif path == 'bf16x6':
+            planes = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=dev)
+            call('dsnt_split_bf16x3', ptr(w), ptr(planes), w.numel())
+            call('dsnt_conv_fwd_bf16x6_ex', ptr(xx), ptr(planes), w.numel(), ptr(b), ptr(y), None, None, 0,
+                 ptr(res) if with_res else None, None, None, C.byref(g), None, C.byref(t))
+        else:
+            wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+            call('dsnt_amax', ptr(w), w.numel(), ptr(wb))
+            call('dsnt_amax', ptr(xx), xx.numel(), ptr(ab))
+            planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+            call('dsnt_split_f16x2', ptr(w), ptr(planes), w.numel(), w.numel(), ptr(wb))
+            call('dsnt_conv_fwd_f16x3_ex', ptr(xx), ptr(planes), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), None, None,
+                 0, ptr(res) if with_res else None, None, None, C.byref(g), None, C.byref(t))
+        torch.cuda.synchronize()
+
+    if path != 'f32' and not _lib.fn('dsnt_conv_bf16x6_ok')(C.byref(g)):
+        pytest.skip('geometry not supported by the split-precision kernels')
+    launch(x)
+    first = float(y.abs().max())
+    assert float(slots.max()) == first and first > 0
+    launch(x * 0.25)                       # a smaller output: the bound stays
+    assert float(slots.max()) == first
+    launch(x * 4.0)                        # a larger one raises it
+    assert float(slots.max()) == float(y.abs().max()) > first
+    # a K-split-sized launch with amax set still reports (it is routed to the tile kernel)
+    if path == 'f32':
+        gs = ConvGeom(1, 8, 8, Cin, 8, 8, Cout, k, k, 1, k // 2, 1)
+        xs = torch.randn(1, 8, 8, Cin, device=dev)
+        ys = torch.empty(1, 8, 8, Cout, device=dev)
+        slots.zero_()
+        call('dsnt_conv_fwd_ex', ptr(xs), ptr(w), ptr(b), ptr(ys), None, None, 0, None, None, None, C.byref(gs), None,
+             C.byref(t))
+        torch.cuda.synchronize()
+        assert float(slots.max()) == float(ys.abs().max())
