@@ -30,6 +30,10 @@ struct BnTailP {
     float momentum, eps;
     float* o0; float* o1; float* o2; float* o3;
     unsigned* amax;                    // independent of the tail: raise this 64-slot bound to max|output| (fp16x3 operand bounds)
+    unsigned* amax_bn;                 // ... and this one to max|relu?(output * amax_scale[c] + amax_shift[c])|: the operand a
+    const float* amax_scale;           // consumer with an eval-mode BatchNorm prologue will form (vectors known before
+    const float* amax_shift;           // the producer runs)
+    int amax_relu, pad_;
 };
 
 // Write-through (sc1) store of a partial sum: visible to every XCD once the storing wave has drained vmcnt, so the
@@ -187,6 +191,11 @@ static inline int bn_tail_fill(BnTailP& out, const dsnt_bn_tail* in, const char*
     static_assert(sizeof(BnTailP) == sizeof(dsnt_bn_tail), "dsnt_bn_tail layout");
     out.counters = nullptr;
     out.amax = in ? reinterpret_cast<unsigned*>(in->amax) : nullptr;
+    out.amax_bn = in ? reinterpret_cast<unsigned*>(in->amax_bn) : nullptr;
+    out.amax_scale = in ? in->amax_scale : nullptr; out.amax_shift = in ? in->amax_shift : nullptr;
+    out.amax_relu = in ? in->amax_relu : 0; out.pad_ = 0;
+    DSNT_REQUIRE(!out.amax_bn || (out.amax_scale && out.amax_shift && dsnt_aligned16(out.amax_scale) && dsnt_aligned16(out.amax_shift)),
+                 DSNT_ERR_ARG, "%s: dsnt_bn_tail.amax_bn needs 16-byte aligned amax_scale / amax_shift", who);
     if (!in || !in->counters) return DSNT_OK;
     DSNT_REQUIRE(in->level2 && in->out2 && (in->mode == 0 || in->mode == 1), DSNT_ERR_ARG, "%s: incomplete dsnt_bn_tail", who);
     DSNT_REQUIRE(in->mode == 1 || (in->out0 && in->out1 && in->out3), DSNT_ERR_ARG,

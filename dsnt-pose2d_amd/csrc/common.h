@@ -83,8 +83,10 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
 // fp16x3 operand bounds: raise the 64-slot bound `amax` (see bound64 in conv.hip) to this 256-thread workgroup's
 // max |value|: wave shuffles, four LDS floats, ONE fire-and-forget integer atomic on the float bits per workgroup,
 // slot = workgroup index mod 64 (order-independent: the result is bit-reproducible).
-__device__ __forceinline__ void amax_commit(float am, unsigned* amax) {
-    __shared__ float amax_w[16];
+// (`which` = 0 / 1: two commits in a row use separate LDS floats, so the second needs no barrier against the first)
+__device__ __forceinline__ void amax_commit(float am, unsigned* amax, int which = 0) {
+    __shared__ float amax_w2[32];
+    float* amax_w = amax_w2 + 16 * which;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
     if ((threadIdx.x & 63) == 0) amax_w[threadIdx.x >> 6] = am;

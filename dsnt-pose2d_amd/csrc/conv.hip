@@ -156,7 +156,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
         bsh = *reinterpret_cast<const float4*>(p.bnb_shift + n0);
         bmu = *reinterpret_cast<const float4*>(p.bnb_mean + n0);
         bis = *reinterpret_cast<const float4*>(p.bnb_invstd + n0);
+    } else if (p.tail.amax_bn && vn) {         // (the two uses exclude each other: the registers are shared)
+        bsc = *reinterpret_cast<const float4*>(p.tail.amax_scale + n0);
+        bsh = *reinterpret_cast<const float4*>(p.tail.amax_shift + n0);
     }
+    const float am2lo = p.tail.amax_relu ? 0.f : -__builtin_inff();
+    float am2 = 0.f;                           // max |relu?(written value * scale + shift)| (p.tail.amax_bn)
     // fp16x3: the accumulators hold (A s_a)(W s_w); both scales are powers of two, the product is undone exactly
     const float osc = p.a_bound ? 1.f / (pow2_scale(bound64(p.a_bound)) * pow2_scale(bound64(p.w_bound))) : 1.f;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
@@ -198,6 +203,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
             v.z += bias4.z + r1[j].z + r2[j].z; v.w += bias4.w + r1[j].w + r2[j].w;
             *reinterpret_cast<float4*>(p.y + (size_t)m * p.Cout + n0) = v;
             am = fmaxf(fmaxf(am, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+            if (p.tail.amax_bn)
+                am2 = fmaxf(fmaxf(am2, fabsf(fmaxf(fmaf(v.x, bsc.x, bsh.x), am2lo))),
+                            fmaxf(fabsf(fmaxf(fmaf(v.y, bsc.y, bsh.y), am2lo)),
+                                  fmaxf(fabsf(fmaxf(fmaf(v.z, bsc.z, bsh.z), am2lo)), fabsf(fmaxf(fmaf(v.w, bsc.w, bsh.w), am2lo)))));
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
             s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
             s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
@@ -205,6 +214,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
     }
     }
     if (p.tail.amax) amax_commit(am, p.tail.amax);
+    if (p.tail.amax_bn) amax_commit(am2, p.tail.amax_bn, 1);
     if (p.stats) {
         __syncthreads();                       // every thread has read its part of Cs
         float* red = smem;                     // [RPP][BN][2]
@@ -1136,9 +1146,9 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
     p.mtiles = (p.M + BM - 1) / BM; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
     const bool pro = in_scale != nullptr;
-    DSNT_REQUIRE(!(p.tail.amax && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
+    DSNT_REQUIRE(!((p.tail.amax || p.tail.amax_bn) && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
     if (BM == 32 && p.M <= ksplit_rows() && p.Cin % 8 == 0 && (size_t)p.N * p.H * p.W * p.Cin * 4u < (1ull << 31) &&
-        (size_t)p.Cout * p.K * 4u < (1ull << 31) && !p.tail.amax) {       // (the K-split epilogue has no amax)
+        (size_t)p.Cout * p.K * 4u < (1ull << 31) && !p.tail.amax && !p.tail.amax_bn) {       // (the K-split epilogue has no amax)
         const int grid = p.mtiles * ((p.Cout + 31) / 32);
         if (pro) DSNT_LAUNCH(conv_ksplit_kernel<true>, dim3(grid), dim3(512), 0, st, p);
         else DSNT_LAUNCH(conv_ksplit_kernel<false>, dim3(grid), dim3(512), 0, st, p);
@@ -1482,7 +1492,7 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     const int BN = g->Cout <= 64 ? 64 : 128;
     p.mtiles = (p.M + 127) / 128; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
-    DSNT_REQUIRE(!(p.tail.amax && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
+    DSNT_REQUIRE(!((p.tail.amax || p.tail.amax_bn) && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
     p.a_bound = a_bound; p.w_bound = w_bound;
     if (a_bound) {                   // fp16x3: two fp16 weight planes, operand bounds in device memory
         if (conv3x3_halo_ok(g) && !g_force_gemm6) {

@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(
     const bool active = rl < rpar;
     const long row0 = (long)blockIdx.x * TILE_ROWS;
     const long row1 = row0 + TILE_ROWS < M ? row0 + TILE_ROWS : M;
-    float am = 0.f;                                  // max |written value| (tail.amax: fp16x3 bound of a raw consumer)
     for (int cg0 = 0; cg0 < C4; cg0 += cgs) {
         const int cg = cg0 + cg_l;
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
@@ -108,6 +107,8 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
     const long row0 = (long)blockIdx.x * TILE_ROWS;
     const long row1 = row0 + TILE_ROWS < M ? row0 + TILE_ROWS : M;
     float am = 0.f;                                  // max |written value| (tail.amax: fp16x3 bound of a raw consumer)
+    float am2 = 0.f;                                 // max |relu?(written value * scale + shift)| (tail.amax_bn)
+    const float am2lo = tail.amax_relu ? 0.f : -__builtin_inff();
     for (int cg0 = 0; cg0 < C4; cg0 += cgs) {
         const int cg = cg0 + cg_l;
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
@@ -138,11 +139,19 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
                 }
                 reinterpret_cast<float4*>(y)[r * C4 + cg] = v;
                 am = fmaxf(fmaxf(am, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+                if (tail.amax_bn) {
+                    const float4 bs = reinterpret_cast<const float4*>(tail.amax_scale)[cg];
+                    const float4 bh = reinterpret_cast<const float4*>(tail.amax_shift)[cg];
+                    am2 = fmaxf(fmaxf(am2, fabsf(fmaxf(fmaf(v.x, bs.x, bh.x), am2lo))),
+                                fmaxf(fabsf(fmaxf(fmaf(v.y, bs.y, bh.y), am2lo)),
+                                      fmaxf(fabsf(fmaxf(fmaf(v.z, bs.z, bh.z), am2lo)), fabsf(fmaxf(fmaf(v.w, bs.w, bh.w), am2lo)))));
+                }
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
                 s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
             }
         }
+        if (!partial) continue;                       // eval mode: only the operand bound is wanted (uniform)
         __syncthreads();
         float* mine = red + tid * 8;
         mine[0] = s1.x; mine[1] = s1.y; mine[2] = s1.z; mine[3] = s1.w;
@@ -160,6 +169,7 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
         }
     }
     if (tail.amax) amax_commit(am, tail.amax);
+    if (tail.amax_bn) amax_commit(am2, tail.amax_bn, 1);
     if (tail.counters) bn_tail_run<256>(tail, partial, (int)((M + TILE_ROWS - 1) / TILE_ROWS), C, M, blockIdx.x, 1, red);
 }
 
@@ -168,8 +178,9 @@ extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, f
     BnTailP tail;
     if (int e = bn_tail_fill(tail, g_tail, "dsnt_maxpool2_fwd_stats")) return e;
     DSNT_REQUIRE(!tail.counters || tail.mode == 0, DSNT_ERR_ARG, "dsnt_maxpool2_fwd_stats: dsnt_bn_tail must be mode 0");
-    DSNT_REQUIRE(x && y && idx && partial && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
+    DSNT_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
                  "dsnt_maxpool2_fwd_stats: bad argument");
+    DSNT_REQUIRE(partial || !tail.counters, DSNT_ERR_ARG, "dsnt_maxpool2_fwd_stats: a dsnt_bn_tail needs the partial sums");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_fwd_stats: H and W must be even (got %dx%d)", H, W);
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(partial) &&
                  (((uintptr_t)idx) & 3) == 0, DSNT_ERR_ALIGN, "dsnt_maxpool2_fwd_stats: alignment");
@@ -184,8 +195,9 @@ extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, f
     BnTailP tail;
     if (int e = bn_tail_fill(tail, g_tail, "dsnt_upsample2_add_fwd_stats")) return e;
     DSNT_REQUIRE(!tail.counters || tail.mode == 0, DSNT_ERR_ARG, "dsnt_upsample2_add_fwd_stats: dsnt_bn_tail must be mode 0");
-    DSNT_REQUIRE(up && low && out && partial && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
+    DSNT_REQUIRE(up && low && out && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
                  "dsnt_upsample2_add_fwd_stats: bad argument");
+    DSNT_REQUIRE(partial || !tail.counters, DSNT_ERR_ARG, "dsnt_upsample2_add_fwd_stats: a dsnt_bn_tail needs the partial sums");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_upsample2_add_fwd_stats: H and W must be even");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(up) && dsnt_aligned16(low) && dsnt_aligned16(out) &&
                  dsnt_aligned16(partial), DSNT_ERR_ALIGN, "dsnt_upsample2_add_fwd_stats: alignment");

@@ -41,7 +41,8 @@ class BnTail(C.Structure):
                 ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
                 ('momentum', C.c_float), ('eps', C.c_float),
                 ('out0', C.c_void_p), ('out1', C.c_void_p), ('out2', C.c_void_p), ('out3', C.c_void_p),
-                ('amax', C.c_void_p)]
+                ('amax', C.c_void_p), ('amax_bn', C.c_void_p), ('amax_scale', C.c_void_p), ('amax_shift', C.c_void_p),
+                ('amax_relu', C.c_int), ('reserved', C.c_int)]
 
 
 TP = C.POINTER(BnTail)

@@ -142,7 +142,7 @@ class Tape:
         self._eval_bn_rows = []     # eval mode: every BatchNorm's vectors come from ONE table-driven launch per forward
         self._amax_buf, self._amax_used = None, 0      # zeroed at the start of every backward
         self.raw_f16 = os.environ.get('DSNT_RAW_F16', '1') != '0'      # A/B switch: bounds of raw operands from the producers' epilogues
-        self._famax_buf, self._famax_used, self._famax_of = None, 0, {}   # forward activations: zeroed at the start of every forward
+        self._famax_buf, self._famax_used, self._famax_of, self._famax_bn_of = None, 0, {}, {}   # forward activations: zeroed at the start of every forward
         # DSNT_AMAX_ALL=0: only single-writer BN-backward outputs get a bound (A/B switch); default: bounds follow the
         # gradient through every writer that can report one (apply, axpy, pool / upsample backward) and through donations
         self.amax_all = os.environ.get('DSNT_AMAX_ALL', '1') != '0'
@@ -240,14 +240,35 @@ class Tape:
             return None
         slot = self._famax_of.get(id(t))
         if slot is None:
-            if self._famax_buf is None:
-                self._famax_buf = self.empty(64 * 256)
-            assert self._famax_used + 64 <= self._famax_buf.numel()
-            slot = self._famax_buf[self._famax_used:self._famax_used + 64]
-            self._famax_used += 64
+            slot = self._famax_slot()
             t.amax = slot.data_ptr()
             self._famax_of[id(t)] = slot
             self._keep.append(t)
+        return slot
+
+    def _famax_slot(self):
+        if self._famax_buf is None:
+            self._famax_buf = self.empty(64 * 256)
+        assert self._famax_used + 64 <= self._famax_buf.numel()
+        self._famax_used += 64
+        return self._famax_buf[self._famax_used - 64:self._famax_used]
+
+    def operand_amax_bn(self, n):
+        """Eval mode: bound slot for relu?(bn(x)) as an fp16x3 operand.  The BatchNorm vectors come from running
+        statistics (one dsnt_bn_eval_prep launch at the head of the forward), so the launch that produces x can form
+        the operand itself and leave its exact maximum (dsnt_bn_tail.amax_bn).  One BatchNorm per producer; None if
+        the producer cannot or is already taken by another BatchNorm."""
+        t = n.x.amax_tail
+        if t is None or not self.use_f16x3 or not self.raw_f16 or self.training:
+            return None
+        got = self._famax_bn_of.get(id(t))
+        if got is not None:
+            return got[1] if got[0] is n else None
+        slot = self._famax_slot()
+        t.amax_bn, t.amax_scale, t.amax_shift = slot.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr()
+        t.amax_relu = 1 if n.relu else 0
+        self._famax_bn_of[id(t)] = (n, slot)
+        self._keep.append(t)
         return slot
 
     def f16_bn_bound_bwd(self, n):
@@ -717,11 +738,13 @@ class Tape:
         if self.use_f16x3 and self.training and normed:
             self.f16_bn_bound(src)              # also for the weight gradient of convs whose forward is not fp16x3
         # fp16x3 needs a bound of the A operand: train-mode BatchNorm parameters, or the producer's max|x| for a raw x
-        x_amax = self.operand_amax(x) if (use6 and not normed and p.wq16 is not None) else None
+        x_amax = None
+        if use6 and p.wq16 is not None:
+            x_amax = self.operand_amax_bn(src) if normed else self.operand_amax(x)
         use16 = use6 and self.use_f16x3 and p.wq16 is not None and ((self.training and normed) or x_amax is not None)
         if use16:
             self.f16_weights(p)
-            ab = self.f16_bn_bound(src) if normed else x_amax
+            ab = self.f16_bn_bound(src) if (normed and self.training) else x_amax
             e = self.f('dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, ab, p.b, y.buf,
                        sc, sh, relu, r1, r2, part, g, None, tail)
             self.f16_uses.append((e, dict(kind='fwd', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
@@ -908,6 +931,9 @@ class Tape:
                 y.amax_tail = y.stats_tail = y.stats_tail if y.stats_tail is not None else BnTail()
             self.f('dsnt_maxpool2_fwd_stats', x.buf, y.buf, idx, part, x.N, x.H, x.W, x.C, y.stats_tail)
             y.stats = (part, tiles)
+        elif not self.training and self.use_f16x3 and y.M >= self.bf16x6_min_rows:
+            y.amax_tail = BnTail()        # no statistics in eval mode, but the next convolution's operand bound
+            self.f('dsnt_maxpool2_fwd_stats', x.buf, y.buf, idx, None, x.N, x.H, x.W, x.C, y.amax_tail)
         else:
             self.f('dsnt_maxpool2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
         if self.training:
@@ -962,6 +988,9 @@ class Tape:
                 out.amax_tail = out.stats_tail = out.stats_tail if out.stats_tail is not None else BnTail()
             self.f('dsnt_upsample2_add_fwd_stats', up.buf, low.buf, out.buf, part, up.N, up.H, up.W, up.C, out.stats_tail)
             out.stats = (part, tiles)
+        elif not self.training and self.use_f16x3 and out.M >= self.bf16x6_min_rows:
+            out.amax_tail = BnTail()
+            self.f('dsnt_upsample2_add_fwd_stats', up.buf, low.buf, out.buf, None, up.N, up.H, up.W, up.C, out.amax_tail)
         else:
             self.f('dsnt_upsample2_add_fwd', up.buf, low.buf, out.buf, up.N, up.H, up.W, up.C)
         if self.training:

@@ -51,7 +51,10 @@ typedef enum {
  *         max |value| it writes to its output (atomic max on the bit patterns of non-negative floats: the caller zeroes
  *         the 64 slots once per step) — the fp16x3 operand bound of a consumer that reads the output without a
  *         BatchNorm in between (skip projections, `lin` convolutions: hourglass.py:45-48,120-135), or of a data
- *         gradient written by a convolution epilogue.  Not with a bn_bwd_epilogue. */
+ *         gradient written by a convolution epilogue.  Not with a bn_bwd_epilogue.
+ * amax_bn (may be NULL): the same for max |relu?(value * amax_scale[c] + amax_shift[c])| — the operand a consumer with
+ *         an EVAL-mode BatchNorm(+ReLU) prologue will form from this output (inference.py:38-48: the vectors come from
+ *         running statistics, so they exist before the producer runs); amax_scale / amax_shift: [C], 16-byte aligned. */
 typedef struct {
     int mode, accumulate;
     unsigned* counters;
@@ -60,6 +63,7 @@ typedef struct {
     float momentum, eps;
     float* out0; float* out1; float* out2; float* out3;
     float* amax;
+    float* amax_bn; const float* amax_scale; const float* amax_shift; int amax_relu, reserved;
 } dsnt_bn_tail;
 /* m-tiles whose partial rows one first-level reduction covers (32) */
 int dsnt_bn_tail_group(void);
@@ -404,7 +408,8 @@ int dsnt_upsample2_bwd(const float* dout, float* dlow, int accumulate,
 
 /* The same two forward ops with the BatchNorm statistics of their output in the same pass (the next op of the
  * hourglass is a BatchNorm: hourglass.py:33,78-90): partial[ceil(M/128)][2][C] exactly as dsnt_bn_stats over the
- * stored result would give (bit-identical), M = output pixels. */
+ * stored result would give (bit-identical), M = output pixels.  partial may be NULL (eval mode: no statistics;
+ * tail->amax / amax_bn can still ask for the next convolution's fp16x3 operand bound). */
 int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* partial, int N, int H, int W, int C,
                             const dsnt_bn_tail* tail, void* stream);
 int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, float* out, float* partial, int N, int H, int W,

@@ -148,3 +148,50 @@ def test_nonfinite_guard_blocks_the_update_and_reports_asynchronously():
     with pytest.raises(NonFiniteError, match='non-finite gradient'):
         guard.sync()
     assert torch.isfinite(m.hg.arena.params).all().item()
+
+
+def test_eval_mode_fp16x3_bounds_come_from_the_producers():
+    """Eval mode has no batch statistics to bound relu(bn(x)) analytically: the launch that produces x forms the
+    consumer's operand from the (running-statistics) BatchNorm vectors and leaves its maximum (dsnt_bn_tail.amax_bn).
+    Walk a batch-8 eval forward of hg2: every fp16x3 launch's A bound equals max|operand| at that moment (to fp32
+    rounding) and most large convolutions are on fp16x3."""
+    from dsnt.model import build_mpii_pose_model
+    m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(m, seed=0)
+    m.to(DEV).eval()
+    x, _, _ = synthetic.batch(8, size=256, seed=1)
+    x = x.to(DEV)
+    runner = m.hg._runner()
+    with torch.no_grad():
+        ref = [o.clone() for o in m(x)]
+    prog = [p for p in runner.programs.values() if not p.training][0]
+    uses = {}
+    for entry, info in prog.tape.f16_uses:
+        uses.setdefault(id(entry), []).append(info)
+    seen, bad = [0], []
+
+    def probe(entry):
+        for u in uses.get(id(entry), ()):
+            torch.cuda.synchronize()
+            v = u['x'].double()
+            if u['sc'] is not None:
+                v = v * u['sc'].double() + u['sh'].double()
+                if u['relu']:
+                    v = v.clamp_(min=0)
+            got, bound = float(v.abs().max()), float(u['a_bound'].max())
+            seen[0] += 1
+            if not (got <= bound * (1 + 1e-6) and bound <= got * (1 + 1e-5) + 1e-30):
+                bad.append((u['name'], got, bound))
+            if not float(u['w'].abs().max()) <= float(u['w_bound'].max()):
+                bad.append((u['name'], 'W'))
+
+    runner.probe = probe
+    try:
+        with torch.no_grad():
+            out = m(x)
+    finally:
+        runner.probe = None
+    assert not bad, bad[:6]
+    assert seen[0] >= 20, seen           # batch 8: the 64x64 level (the 32x32 level is below the split-precision row threshold)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)           # probed (Python replay) and un-probed (C replay) runs agree bit for bit

@@ -778,6 +778,10 @@ def test_epilogue_leaves_the_bound_of_its_output(path, k, with_res):
     slots = torch.zeros(64, device=dev)
     t = BnTail()
     t.amax = slots.data_ptr()
+    # ... and the bound of the operand an eval-mode BatchNorm + ReLU consumer will form from y (amax_bn)
+    bsc, bsh = torch.randn(Cout, device=dev), torch.randn(Cout, device=dev)
+    slots_bn = torch.zeros(64, device=dev)
+    t.amax_bn, t.amax_scale, t.amax_shift, t.amax_relu = slots_bn.data_ptr(), bsc.data_ptr(), bsh.data_ptr(), 1
 
     def launch(xx):
         if path == 'f32':
@@ -803,6 +807,8 @@ def test_epilogue_leaves_the_bound_of_its_output(path, k, with_res):
     launch(x)
     first = float(y.abs().max())
     assert float(slots.max()) == first and first > 0
+    want_bn = float(torch.relu(y.double() * bsc.double() + bsh.double()).max())
+    assert abs(float(slots_bn.max()) - want_bn) <= 1e-6 * want_bn and want_bn > 0
     launch(x * 0.25)                       # a smaller output: the bound stays
     assert float(slots.max()) == first
     launch(x * 4.0)                        # a larger one raises it

@@ -9,10 +9,10 @@ _lib.ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 import dsnt.engine as E
 E._lib.ptr = _lib.ptr
 m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
-m.train()
+m.train() if len(sys.argv) < 2 else m.eval()
 root = m.hg if hasattr(m, 'hg') else m
 ar = Arena(root, torch.device('cpu'))
-prog = Program(root, ar, (32, 3, 256, 256), True, False)
+prog = Program(root, ar, (32, 3, 256, 256), len(sys.argv) < 2, False)
 t = prog.tape
 def geom(args):
     for a in args:
