@@ -9,23 +9,30 @@
 
 #define TILE_ROWS 128
 
+// Thread mapping of the tile kernels below, shared so that their sums stay bit-identical to each other: a workgroup
+// covers `cgs` float4 column groups x (256 / cgs) row lanes of one 128-row tile.  Large tensors: all columns in one
+// workgroup (up to 256 groups per pass).  Small ones (fewer than 256 tiles — the low-resolution hourglass levels, where
+// a 4..64-workgroup launch is pure latency): 16 column groups per workgroup, the rest of the columns on gridDim.y, so a
+// thread walks 8 rows instead of 32 and the launch has 4x (C = 256) the workgroups.
+static inline int tile_cgs(long tiles, int C4) { return tiles < 256 && C4 > 16 && C4 % 16 == 0 ? 16 : (C4 < 256 ? C4 : 256); }
+static inline unsigned tile_grid_y(long tiles, int C4) { const int c = tile_cgs(tiles, C4); return c == 16 && C4 > 16 ? C4 / 16 : 1; }
+
 // ---------------------------------------------------------------- per-channel tile reductions
 // MODE 0: (sum x, sum x^2)          MODE 1: (sum dz, sum dz*xhat) for y = relu?(bn(x))
 template <int MODE>
 __global__ __launch_bounds__(256) void tile_reduce_kernel(
     const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, int relu, float* __restrict__ partial, long M, int C) {
+    const float* __restrict__ invstd, int relu, float* __restrict__ partial, long M, int C, int cgs) {
     __shared__ float red[256 * 8];
     const int tid = threadIdx.x;
     const int C4 = C >> 2;
-    const int cgs = C4 < 256 ? C4 : 256;      // column groups handled per pass
-    const int rpar = 256 / cgs;               // row lanes
+    const int rpar = 256 / cgs;               // row lanes (cgs = column groups handled per pass: tile_cgs)
     const int cg_l = tid % cgs, rl = tid / cgs;
     const bool active = rl < rpar;
     const long row0 = (long)blockIdx.x * TILE_ROWS;
     const long row1 = row0 + TILE_ROWS < M ? row0 + TILE_ROWS : M;
-    for (int cg0 = 0; cg0 < C4; cg0 += cgs) {
+    for (int cg0 = blockIdx.y * cgs; cg0 < C4; cg0 += cgs * gridDim.y) {
         const int cg = cg0 + cg_l;
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
         if (active && cg < C4) {
@@ -82,8 +89,8 @@ extern "C" int dsnt_bn_stats(const float* x, float* partial, int64_t M, int C, v
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(partial), DSNT_ERR_ALIGN,
                  "dsnt_bn_stats: C %% 4 and 16-byte alignment required");
     const int tiles = (int)((M + TILE_ROWS - 1) / TILE_ROWS);
-    DSNT_LAUNCH(tile_reduce_kernel<0>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, x,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial, (long)M, C);
+    DSNT_LAUNCH(tile_reduce_kernel<0>, dim3(tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, 0, partial, (long)M, C, tile_cgs(tiles, C / 4));
     DSNT_CHECK_LAUNCH("dsnt_bn_stats");
 }
 
@@ -95,11 +102,11 @@ extern "C" int dsnt_bn_stats(const float* x, float* partial, int64_t M, int C, v
 template <int OP>
 __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                             float* __restrict__ y, unsigned char* __restrict__ idx,
-                                                            float* partial, int N, int Ho, int Wo, int C, BnTailP tail) {
+                                                            float* partial, int N, int Ho, int Wo, int C, int cgs,
+                                                            BnTailP tail) {
     __shared__ __attribute__((aligned(16))) float red[256 * 8];
     const int tid = threadIdx.x;
     const int C4 = C >> 2;
-    const int cgs = C4 < 256 ? C4 : 256;
     const int rpar = 256 / cgs;
     const int cg_l = tid % cgs, rl = tid / cgs;
     const bool active = rl < rpar;
@@ -109,46 +116,68 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
     float am = 0.f;                                  // max |written value| (tail.amax: fp16x3 bound of a raw consumer)
     float am2 = 0.f;                                 // max |relu?(written value * scale + shift)| (tail.amax_bn)
     const float am2lo = tail.amax_relu ? 0.f : -__builtin_inff();
-    for (int cg0 = 0; cg0 < C4; cg0 += cgs) {
+    for (int cg0 = blockIdx.y * cgs; cg0 < C4; cg0 += cgs * gridDim.y) {
         const int cg = cg0 + cg_l;
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
         if (active && cg < C4) {
-            for (long r = row0 + rl; r < row1; r += rpar) {
-                const int ow = (int)(r % Wo);
-                const long t = r / Wo;
-                const int oh = (int)(t % Ho), n = (int)(t / Ho);
-                float4 v;
-                if (OP == 0) {
-                    const int W = Wo * 2;
-                    const float4* base = reinterpret_cast<const float4*>(a) + (((long)n * (Ho * 2) + 2 * oh) * W + 2 * ow) * C4 + cg;
-                    const float4 v0 = base[0], v1 = base[C4], v2 = base[(long)W * C4], v3 = base[(long)W * C4 + C4];
-                    v = v0;
-                    uchar4 k = make_uchar4(0, 0, 0, 0);
+            // batches of UB rows: every load of the batch is issued before the first use (a workgroup of a small level
+            // is pure latency: 32 dependent iterations took 64 us on the 32x32 -> 16x16 pool), rows are then consumed in
+            // the same order as before — the sums stay bit-identical to tile_reduce_kernel<0>
+            constexpr int UB = 4;
+            float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), bh = bs;
+            if (tail.amax_bn) {
+                bs = reinterpret_cast<const float4*>(tail.amax_scale)[cg];
+                bh = reinterpret_cast<const float4*>(tail.amax_shift)[cg];
+            }
+            for (long rb = row0 + rl; rb < row1; rb += (long)UB * rpar) {
+                float4 in[UB][OP == 0 ? 4 : 2];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const long r = rb + (long)u * rpar < row1 ? rb + (long)u * rpar : row1 - 1;     // clamped: never used
+                    const int ow = (int)(r % Wo);
+                    const long t = r / Wo;
+                    const int oh = (int)(t % Ho), n = (int)(t / Ho);
+                    if (OP == 0) {
+                        const int W = Wo * 2;
+                        const float4* base = reinterpret_cast<const float4*>(a) + (((long)n * (Ho * 2) + 2 * oh) * W + 2 * ow) * C4 + cg;
+                        in[u][0] = base[0]; in[u][1] = base[C4];
+                        in[u][OP == 0 ? 2 : 0] = base[(long)W * C4]; in[u][OP == 0 ? 3 : 1] = base[(long)W * C4 + C4];
+                    } else {
+                        in[u][0] = reinterpret_cast<const float4*>(a)[r * C4 + cg];
+                        in[u][1] = reinterpret_cast<const float4*>(b)[(((long)n * (Ho >> 1) + (oh >> 1)) * (Wo >> 1) + (ow >> 1)) * C4 + cg];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const long r = rb + (long)u * rpar;
+                    if (r >= row1) break;
+                    float4 v;
+                    if (OP == 0) {
+                        const float4 v1 = in[u][1], v2 = in[u][OP == 0 ? 2 : 0], v3 = in[u][OP == 0 ? 3 : 1];
+                        v = in[u][0];
+                        uchar4 k = make_uchar4(0, 0, 0, 0);
 #define POOL_STEP(V, P)                                  \
-                    if (V.x > v.x || V.x != V.x) { v.x = V.x; k.x = P; } \
-                    if (V.y > v.y || V.y != V.y) { v.y = V.y; k.y = P; } \
-                    if (V.z > v.z || V.z != V.z) { v.z = V.z; k.z = P; } \
-                    if (V.w > v.w || V.w != V.w) { v.w = V.w; k.w = P; }
-                    POOL_STEP(v1, 1) POOL_STEP(v2, 2) POOL_STEP(v3, 3)
+                        if (V.x > v.x || V.x != V.x) { v.x = V.x; k.x = P; } \
+                        if (V.y > v.y || V.y != V.y) { v.y = V.y; k.y = P; } \
+                        if (V.z > v.z || V.z != V.z) { v.z = V.z; k.z = P; } \
+                        if (V.w > v.w || V.w != V.w) { v.w = V.w; k.w = P; }
+                        POOL_STEP(v1, 1) POOL_STEP(v2, 2) POOL_STEP(v3, 3)
 #undef POOL_STEP
-                    reinterpret_cast<uchar4*>(idx)[r * C4 + cg] = k;
-                } else {
-                    const float4 u = reinterpret_cast<const float4*>(a)[r * C4 + cg];
-                    const float4 l = reinterpret_cast<const float4*>(b)[(((long)n * (Ho >> 1) + (oh >> 1)) * (Wo >> 1) + (ow >> 1)) * C4 + cg];
-                    v = make_float4(u.x + l.x, u.y + l.y, u.z + l.z, u.w + l.w);
+                        reinterpret_cast<uchar4*>(idx)[r * C4 + cg] = k;
+                    } else {
+                        const float4 uu = in[u][0], l = in[u][1];
+                        v = make_float4(uu.x + l.x, uu.y + l.y, uu.z + l.z, uu.w + l.w);
+                    }
+                    reinterpret_cast<float4*>(y)[r * C4 + cg] = v;
+                    am = fmaxf(fmaxf(am, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
+                    if (tail.amax_bn)
+                        am2 = fmaxf(fmaxf(am2, fabsf(fmaxf(fmaf(v.x, bs.x, bh.x), am2lo))),
+                                    fmaxf(fabsf(fmaxf(fmaf(v.y, bs.y, bh.y), am2lo)),
+                                          fmaxf(fabsf(fmaxf(fmaf(v.z, bs.z, bh.z), am2lo)), fabsf(fmaxf(fmaf(v.w, bs.w, bh.w), am2lo)))));
+                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                    s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+                    s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
                 }
-                reinterpret_cast<float4*>(y)[r * C4 + cg] = v;
-                am = fmaxf(fmaxf(am, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
-                if (tail.amax_bn) {
-                    const float4 bs = reinterpret_cast<const float4*>(tail.amax_scale)[cg];
-                    const float4 bh = reinterpret_cast<const float4*>(tail.amax_shift)[cg];
-                    am2 = fmaxf(fmaxf(am2, fabsf(fmaxf(fmaf(v.x, bs.x, bh.x), am2lo))),
-                                fmaxf(fabsf(fmaxf(fmaf(v.y, bs.y, bh.y), am2lo)),
-                                      fmaxf(fabsf(fmaxf(fmaf(v.z, bs.z, bh.z), am2lo)), fabsf(fmaxf(fmaf(v.w, bs.w, bh.w), am2lo)))));
-                }
-                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
-                s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
             }
         }
         if (!partial) continue;                       // eval mode: only the operand bound is wanted (uniform)
@@ -170,7 +199,7 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
     }
     if (tail.amax) amax_commit(am, tail.amax);
     if (tail.amax_bn) amax_commit(am2, tail.amax_bn, 1);
-    if (tail.counters) bn_tail_run<256>(tail, partial, (int)((M + TILE_ROWS - 1) / TILE_ROWS), C, M, blockIdx.x, 1, red);
+    if (tail.counters) bn_tail_run<256>(tail, partial, (int)((M + TILE_ROWS - 1) / TILE_ROWS), C, M, blockIdx.x, (int)gridDim.y, red);
 }
 
 extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* partial, int N, int H, int W,
@@ -185,8 +214,9 @@ extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, f
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(partial) &&
                  (((uintptr_t)idx) & 3) == 0, DSNT_ERR_ALIGN, "dsnt_maxpool2_fwd_stats: alignment");
     const long M = (long)N * (H / 2) * (W / 2);
-    DSNT_LAUNCH(tile_op_stats_kernel<0>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
-                       (hipStream_t)stream, x, nullptr, y, idx, partial, N, H / 2, W / 2, C, tail);
+    const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+    DSNT_LAUNCH(tile_op_stats_kernel<0>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, nullptr, y, idx, partial, N, H / 2, W / 2, C, tile_cgs(tiles, C / 4), tail);
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_fwd_stats");
 }
 
@@ -202,8 +232,9 @@ extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, f
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(up) && dsnt_aligned16(low) && dsnt_aligned16(out) &&
                  dsnt_aligned16(partial), DSNT_ERR_ALIGN, "dsnt_upsample2_add_fwd_stats: alignment");
     const long M = (long)N * H * W;
-    DSNT_LAUNCH(tile_op_stats_kernel<1>, dim3((unsigned)((M + TILE_ROWS - 1) / TILE_ROWS)), dim3(256), 0,
-                       (hipStream_t)stream, up, low, out, nullptr, partial, N, H, W, C, tail);
+    const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
+    DSNT_LAUNCH(tile_op_stats_kernel<1>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0,
+                       (hipStream_t)stream, up, low, out, nullptr, partial, N, H, W, C, tile_cgs(tiles, C / 4), tail);
     DSNT_CHECK_LAUNCH("dsnt_upsample2_add_fwd_stats");
 }
 
@@ -217,8 +248,8 @@ extern "C" int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const flo
                  dsnt_aligned16(invstd), DSNT_ERR_ALIGN,
                  "dsnt_bn_act_bwd_reduce: C %% 4 and 16-byte alignment required");
     const int tiles = (int)((M + TILE_ROWS - 1) / TILE_ROWS);
-    DSNT_LAUNCH(tile_reduce_kernel<1>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, da, x,
-                       scale, shift, mean, invstd, relu, partial, (long)M, C);
+    DSNT_LAUNCH(tile_reduce_kernel<1>, dim3(tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0, (hipStream_t)stream, da, x,
+                       scale, shift, mean, invstd, relu, partial, (long)M, C, tile_cgs(tiles, C / 4));
     DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_reduce");
 }
 
