@@ -2611,14 +2611,22 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
     wgrad_fill(p, x, in_scale, in_shift, in_relu, dy, ws, g, a_bound, g_bound);
     hipStream_t st = (hipStream_t)stream;
     const int grid = p.ktiles * p.ntiles * p.splits;
+    // DSNT_WGRAD_SHARE_CHIP (bit 1 of `accumulate`): the launch runs beside a dependency chain on another stream.  Its
+    // workgroups live as long as the kernel (one wave of ~2 per CU), and two of them fill a CU's registers: the chain's
+    // small kernels (a 16-workgroup BatchNorm finalise) then wait for the whole weight gradient to end — 150 us seen.
+    // Asking for more than half of the LDS keeps it to ONE workgroup per CU and the other half of every CU free.
+    const bool share = (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0;
+    accumulate &= 1;
+    const int share_lds = 88 * 1024;
     if (bf16x6) {
-        const int lds = 2 * 2 * 3 * 128 * PITCH6 * 2;
+        const int lds_full = 2 * 2 * 3 * 128 * PITCH6 * 2;
+        const int lds = share ? share_lds : lds_full;
         static bool attr_done = false;
         if (!attr_done) {
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_full);
+            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_full);
             attr_done = true;
         }
         // DSNT_WGRAD_KERNEL=unified: the variant without the loader / MFMA role split (A/B switch; same speed)
@@ -2627,16 +2635,16 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
         if (a_bound) {              // fp16x3 (role-split kernel; its two fp16 planes need 2/3 of the LDS)
             static bool attr16 = false;
             if (!attr16) {
-                hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
+                hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
                 attr16 = true;
             }
-            const int lds16 = 2 * 2 * 2 * 128 * PITCH6 * 2;
+            const int lds16 = share ? share_lds : 2 * 2 * 2 * 128 * PITCH6 * 2;
             if (in_scale) DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<true, true>), dim3(grid), dim3(512), lds16, st, p);
             else DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<false, true>), dim3(grid), dim3(512), lds16, st, p);
         } else if (unified) {
-            if (in_scale) DSNT_LAUNCH(conv_wgrad_bf16x6u_kernel<true>, dim3(grid), dim3(256), lds, st, p);
-            else DSNT_LAUNCH(conv_wgrad_bf16x6u_kernel<false>, dim3(grid), dim3(256), lds, st, p);
+            if (in_scale) DSNT_LAUNCH(conv_wgrad_bf16x6u_kernel<true>, dim3(grid), dim3(256), lds_full, st, p);
+            else DSNT_LAUNCH(conv_wgrad_bf16x6u_kernel<false>, dim3(grid), dim3(256), lds_full, st, p);
         } else if (in_scale) DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<true, false>), dim3(grid), dim3(512), lds, st, p);
         else DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<false, false>), dim3(grid), dim3(512), lds, st, p);
     } else if (in_scale)

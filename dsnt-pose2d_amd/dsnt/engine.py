@@ -106,6 +106,7 @@ class Tape:
         self.wgrad_lane_rows = int(os.environ.get('DSNT_WGRAD_LANE_ROWS', '30000'))
         self.wgrad_lane_res = os.environ.get('DSNT_WGRAD_LANE_RES', '0') != '0'
         self.wgrad_lane_from = (0, 1) if os.environ.get('DSNT_WGRAD_LANE_SIDE', '1') != '0' else (0,)
+        self.wgrad_share = os.environ.get('DSNT_WGRAD_SHARE', '1') != '0'
         self._wgrad_lane_reads = set()
         # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
         # phase: a `release point` is the backward of an up-sampling whose low-resolution operand has at most
@@ -788,6 +789,7 @@ class Tape:
                 # for the weight-gradient lane first (grad_target)
                 self._wgrad_lane_reads.add(gy.data_ptr())
             nws = self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g))
+            share = 2 if (wl != cur and self.wgrad_share) else 0      # DSNT_WGRAD_SHARE_CHIP: one workgroup per CU beside the chain
             w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
             if self.defer_reduce:
                 ws = self.empty(nws)         # lives until the bucket's reduction
@@ -814,12 +816,12 @@ class Tape:
                         self._pending_group_uses.append(dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu,
                                                              a_bound=ab, g=gy, g_bound=y.grad_amax))
                 elif w16:
-                    e = self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, 0, ab, y.grad_amax, g)
+                    e = self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, share, ab, y.grad_amax, g)
                     self.f16_uses.append((e, dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
                                                   g=gy, g_bound=y.grad_amax)))
                 else:
                     self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
-                           None, None, 0, g)
+                           None, None, share if w6 else 0, g)
                 self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
                                              self.lib.dsnt_conv_wgrad_splits(C.byref(g)), p.Cout * g.R * g.S * g.Cin,
                                              p.Cout, 0])

@@ -256,9 +256,13 @@ int dsnt_conv_pack_dgrad_all(const int* table, int nconv, const float* params, f
 
 /* Weight / bias gradient: dw[Cout][R][S][Cin] = sum_m act(x)[m, (r,s,c)] * dy[m, cout],
  * dbias[cout] = sum_m dy.  `ws` is caller workspace of dsnt_conv_wgrad_ws_floats() floats.
- * accumulate != 0 adds into dw/dbias instead of overwriting.
+ * accumulate: bit 0 adds into dw/dbias instead of overwriting; bit 1 (DSNT_WGRAD_SHARE_CHIP, split-precision kernels):
+ * the launch shares the chip with a dependency chain on another stream (loss.backward() of bin/train.py:380: weight
+ * gradients feed nothing downstream) and keeps to ONE workgroup per CU, so that the chain's small kernels find a slot
+ * instead of waiting for the whole weight gradient to retire.
  * dw == NULL (and dbias == NULL): only the split-M partial slabs are written to `ws`; the caller keeps `ws`
  * alive and reduces later with dsnt_wgrad_reduce_all (one launch for many convolutions). */
+#define DSNT_WGRAD_SHARE_CHIP 2
 int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g);
 int dsnt_conv_wgrad(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                     const float* dy, float* ws, float* dw, float* dbias, int accumulate,

@@ -99,3 +99,44 @@ def test_eval_forward_shards_like_replicas(setup):
         assert (whole - halves).abs().max().item() <= 5e-6
     finally:
         m.train()
+
+
+def test_every_activation_and_gradient_is_bit_reproducible():
+    """Ten forward/backward passes of the full-size hg2 step from the same state: every activation buffer, every
+    statistics partial and every gradient buffer of the launch lists is bit-identical from pass to pass — three lanes
+    run concurrently, so this is the test that catches a missing lane dependency or a kernel that is only deterministic
+    when it has the chip to itself (one was found this way: tools/determinism_fwd.py)."""
+    from dsnt.model import build_mpii_pose_model
+    m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(m, seed=0)
+    m.to(DEV).train()
+    x, t, k = synthetic.batch(32, size=256, seed=1, mask_p=0.9)
+    x, t, k = x.to(DEV), t.to(DEV), k.to(DEV)
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        loss = m.forward_loss(m(x), t, k)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item()
+
+    run()
+    prog = [p for p in m.hg._runner().programs.values() if p.training][0]
+    acts = prog.tape.acts
+
+    def snap():
+        loss = run()
+        return (loss, [a.buf.clone() for a in acts], [a.stats[0].clone() if a.stats is not None else None for a in acts],
+                [a.grad.clone() if a.grad is not None else None for a in acts],
+                torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone())
+
+    ref = snap()
+    for rep in range(9):
+        cur = snap()
+        assert cur[0] == ref[0], rep
+        for kind in (1, 2, 3):
+            bad = [(i, acts[i].name) for i in range(len(acts))
+                   if ref[kind][i] is not None and not torch.equal(ref[kind][i], cur[kind][i])]
+            assert not bad, (rep, ('activation', 'statistics', 'gradient')[kind - 1], bad[:4])
+        assert torch.equal(ref[4], cur[4]), rep

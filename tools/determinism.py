@@ -1,0 +1,33 @@
+"""Two train-mode forward/backward passes from the same state must give bit-identical gradients.  Prints, per
+parameter, the ones that differ:  python tools/determinism.py [base] [batch] [repeats]"""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'dsnt-pose2d_amd')]
+from dsnt.model import build_mpii_pose_model
+from dsnt import synthetic
+base = sys.argv[1] if len(sys.argv) > 1 else 'hg2'
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+m = build_mpii_pose_model(base=base, output_strat='dsnt', reg='js')
+synthetic.fill_state_dict(m, seed=0)
+m.cuda().train()
+x, t, k = synthetic.batch(batch, size=256, seed=1, mask_p=0.9)
+x, t, k = x.cuda(), t.cuda(), k.cuda()
+def step():
+    for p in m.parameters():
+        p.grad = None
+    loss = m.forward_loss(m(x), t, k)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.item(), {n: p.grad.clone() for n, p in m.named_parameters()}
+l0, g0 = step()
+bad_total = 0
+for r in range(reps):
+    l1, g1 = step()
+    bad = [(n, float((g0[n] - g1[n]).abs().max()), float(g0[n].abs().max())) for n in g0 if not torch.equal(g0[n], g1[n])]
+    bad_total += len(bad)
+    print('repeat %d: loss equal %s, %d of %d parameters differ' % (r, l0 == l1, len(bad), len(g0)))
+    for n, d, s in bad[:12]:
+        print('   %-40s max|diff| %.3e of %.3e' % (n, d, s))
+print('DETERMINISTIC' if bad_total == 0 else 'NOT DETERMINISTIC')
