@@ -258,7 +258,9 @@ extern "C" int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const flo
 // Combine tile partials: 16 channels x 64 tile-lanes per 1024-thread block (the kernel is pure
 // latency: many independent loads in flight matter, not bandwidth), fp64 accumulation.
 // MODE 0: forward statistics.  MODE 1: backward sums.
+#ifndef FIN_T
 #define FIN_T 1024
+#endif
 #define FIN_P (FIN_T / 16)
 template <int MODE>
 __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
