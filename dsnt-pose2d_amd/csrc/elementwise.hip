@@ -98,12 +98,14 @@ extern "C" int dsnt_bn_stats(const float* x, float* partial, int64_t M, int C, v
 // workgroup per 128 output rows (pixels), same thread mapping, accumulation order and partial format as
 // tile_reduce_kernel<0>, so the sums are bit-identical to a separate dsnt_bn_stats over the stored tensor (which
 // cost one more read of it: 18 launches per hg2 step).  OP 0: y = maxpool2(a) (+ arg-max byte), a is [N][2Ho][2Wo][C];
-// OP 1: y = a + upsample2(b), b is [N][Ho/2][Wo/2][C].  Ho, Wo: OUTPUT size.
+// OP 1: y = a + upsample2(b), b is [N][Ho/2][Wo/2][C].  OP 2: y = relu?(a * bn_scale + bn_shift) (the stem's materialised
+// BatchNorm + ReLU, hourglass.py:157-159).  Ho, Wo: OUTPUT size.
 template <int OP>
 __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                             float* __restrict__ y, unsigned char* __restrict__ idx,
                                                             float* partial, int N, int Ho, int Wo, int C, int cgs,
-                                                            BnTailP tail) {
+                                                            BnTailP tail, const float* __restrict__ bn_scale = nullptr,
+                                                            const float* __restrict__ bn_shift = nullptr, int bn_relu = 0) {
     __shared__ __attribute__((aligned(16))) float red[256 * 8];
     const int tid = threadIdx.x;
     const int C4 = C >> 2;
@@ -133,6 +135,11 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
             }
             for (long rb = row0 + rl; rb < row1; rb += (long)UB * rpar) {
                 float4 in[UB][OP == 0 ? 4 : 2];
+                float4 osc = make_float4(0.f, 0.f, 0.f, 0.f), osh = osc;
+                if (OP == 2) {
+                    osc = reinterpret_cast<const float4*>(bn_scale)[cg];
+                    osh = reinterpret_cast<const float4*>(bn_shift)[cg];
+                }
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
                     const long r = rb + (long)u * rpar < row1 ? rb + (long)u * rpar : row1 - 1;     // clamped: never used
@@ -144,9 +151,11 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
                         const float4* base = reinterpret_cast<const float4*>(a) + (((long)n * (Ho * 2) + 2 * oh) * W + 2 * ow) * C4 + cg;
                         in[u][0] = base[0]; in[u][1] = base[C4];
                         in[u][OP == 0 ? 2 : 0] = base[(long)W * C4]; in[u][OP == 0 ? 3 : 1] = base[(long)W * C4 + C4];
-                    } else {
+                    } else if (OP == 1) {
                         in[u][0] = reinterpret_cast<const float4*>(a)[r * C4 + cg];
                         in[u][1] = reinterpret_cast<const float4*>(b)[(((long)n * (Ho >> 1) + (oh >> 1)) * (Wo >> 1) + (ow >> 1)) * C4 + cg];
+                    } else {
+                        in[u][0] = reinterpret_cast<const float4*>(a)[r * C4 + cg];
                     }
                 }
 #pragma unroll
@@ -166,9 +175,14 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
                         POOL_STEP(v1, 1) POOL_STEP(v2, 2) POOL_STEP(v3, 3)
 #undef POOL_STEP
                         reinterpret_cast<uchar4*>(idx)[r * C4 + cg] = k;
-                    } else {
+                    } else if (OP == 1) {
                         const float4 uu = in[u][0], l = in[u][1];
                         v = make_float4(uu.x + l.x, uu.y + l.y, uu.z + l.z, uu.w + l.w);
+                    } else {
+                        const float4 xv = in[u][0];
+                        v = make_float4(fmaf(xv.x, osc.x, osh.x), fmaf(xv.y, osc.y, osh.y), fmaf(xv.z, osc.z, osh.z),
+                                        fmaf(xv.w, osc.w, osh.w));
+                        if (bn_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     }
                     reinterpret_cast<float4*>(y)[r * C4 + cg] = v;
                     am = fmaxf(fmaxf(am, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
@@ -238,6 +252,24 @@ extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, f
     DSNT_LAUNCH(tile_op_stats_kernel<1>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0,
                        (hipStream_t)stream, up, low, out, nullptr, partial, N, H, W, C, tile_cgs(tiles, C / 4), tail);
     DSNT_CHECK_LAUNCH("dsnt_upsample2_add_fwd_stats");
+}
+
+extern "C" int dsnt_bn_act_fwd_stats(const float* x, const float* scale, const float* shift, int relu, float* y,
+                                     float* partial, int64_t M, int C, const dsnt_bn_tail* g_tail, void* stream) {
+    BnTailP tail;
+    if (int e = bn_tail_fill(tail, g_tail, "dsnt_bn_act_fwd_stats")) return e;
+    DSNT_REQUIRE(!tail.counters || tail.mode == 0, DSNT_ERR_ARG, "dsnt_bn_act_fwd_stats: dsnt_bn_tail must be mode 0");
+    DSNT_REQUIRE(x && scale && shift && y && M > 0 && C > 0, DSNT_ERR_ARG, "dsnt_bn_act_fwd_stats: bad argument");
+    DSNT_REQUIRE(partial || !tail.counters, DSNT_ERR_ARG, "dsnt_bn_act_fwd_stats: a dsnt_bn_tail needs the partial sums");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(scale) && dsnt_aligned16(shift) &&
+                 dsnt_aligned16(partial), DSNT_ERR_ALIGN, "dsnt_bn_act_fwd_stats: alignment");
+    const long tiles = ((long)M + TILE_ROWS - 1) / TILE_ROWS;
+    // rows are flat here: N = 1, Ho = 1, Wo = M would overflow int for nothing — the kernel only needs M = N*Ho*Wo
+    DSNT_REQUIRE(M < (1ll << 31), DSNT_ERR_SHAPE, "dsnt_bn_act_fwd_stats: M too large");
+    DSNT_LAUNCH(tile_op_stats_kernel<2>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, nullptr, y, nullptr, partial, 1, 1, (int)M, C, tile_cgs(tiles, C / 4), tail,
+                       scale, shift, relu);
+    DSNT_CHECK_LAUNCH("dsnt_bn_act_fwd_stats");
 }
 
 extern "C" int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const float* scale,

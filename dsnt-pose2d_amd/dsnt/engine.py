@@ -914,7 +914,22 @@ class Tape:
         """Materialised y = relu?(bn(x)) (the stem: hourglass.py:157-159)."""
         n = self.norm(x, bn, relu)
         y = self.act(x.N, x.H, x.W, x.C, name)
-        self.f('dsnt_bn_act_fwd', x.buf, n.scale, n.shift, 1 if n.relu else 0, y.buf, x.M, x.C)
+        big = self.use_f16x3 and y.M >= self.bf16x6_min_rows
+        if self.training and self.fuse_op_stats:
+            # the statistics of y (the first Bottleneck's BatchNorm reads it next) and the bound of its raw consumer
+            # (that Bottleneck's skip projection) ride in the same pass
+            tiles = (y.M + 127) // 128
+            part = self.empty(tiles, 2, x.C)
+            y.stats_tail = self.new_tail()
+            if big:
+                y.amax_tail = y.stats_tail = y.stats_tail if y.stats_tail is not None else BnTail()
+            self.f('dsnt_bn_act_fwd_stats', x.buf, n.scale, n.shift, 1 if n.relu else 0, y.buf, part, x.M, x.C, y.stats_tail)
+            y.stats = (part, tiles)
+        elif not self.training and big:
+            y.amax_tail = BnTail()
+            self.f('dsnt_bn_act_fwd_stats', x.buf, n.scale, n.shift, 1 if n.relu else 0, y.buf, None, x.M, x.C, y.amax_tail)
+        else:
+            self.f('dsnt_bn_act_fwd', x.buf, n.scale, n.shift, 1 if n.relu else 0, y.buf, x.M, x.C)
         if self.training:
             def backward():
                 self._norm_backward(n, y.grad)

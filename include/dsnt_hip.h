@@ -418,6 +418,11 @@ int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* parti
                             const dsnt_bn_tail* tail, void* stream);
 int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, float* out, float* partial, int N, int H, int W,
                                  int C, const dsnt_bn_tail* tail, void* stream);
+/* y = relu?(x * scale + shift) (dsnt_bn_act_fwd: the stem's materialised BatchNorm + ReLU, hourglass.py:157-159) with the
+ * statistics of y in the same pass — the first Bottleneck's BatchNorm reads y next — and, through tail->amax / amax_bn, the
+ * fp16x3 bound of the skip projection that reads y raw.  partial: [ceil(M/128)][2][C], may be NULL. */
+int dsnt_bn_act_fwd_stats(const float* x, const float* scale, const float* shift, int relu, float* y, float* partial,
+                          int64_t M, int C, const dsnt_bn_tail* tail, void* stream);
 
 /* y (+)= a*x, flat; n % 4 == 0 not required. */
 int dsnt_axpy(const float* x, float* y, float a, int accumulate, int64_t n, void* stream);
