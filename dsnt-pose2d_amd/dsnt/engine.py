@@ -95,6 +95,7 @@ class Tape:
         # skip branch of every hourglass level runs beside the low-resolution recursion)
         self.lane = 0
         self.use_lanes = os.environ.get('DSNT_LANES', '1') != '0'
+        self.fuse_join = os.environ.get('DSNT_FUSE_JOIN', '1') != '0'      # hourglass.Hourglass._level
         self.side_stream = None
         self.wgrad_stream = None
         # weight gradients feed nothing downstream in backward.  The large ones (>= DSNT_WGRAD_LANE_ROWS output rows; 0 =
@@ -385,12 +386,12 @@ class Tape:
         self._bwd_emitters.append(emit)
 
     # ------------------------------------------------------------------ lanes
-    def sync(self, src, dst):
-        """`dst` lane waits for everything emitted so far on `src`; mirrored in backward."""
+    def sync(self, src, dst, bwd=True):
+        """`dst` lane waits for everything emitted so far on `src`; mirrored in backward unless bwd=False."""
         if not self.use_lanes:
             return
         self.fwd.append((None, (src, dst, torch.cuda.Event()), 'sync', 0))
-        if self.training:
+        if self.training and bwd:
             self._bwd_emitters.append(
                 lambda: self.bwd.append((None, (dst, src, torch.cuda.Event()), 'sync', 0)))
 
@@ -399,15 +400,16 @@ class Tape:
         if self.use_lanes and src != dst:
             self.bwd.append((None, (src, dst, torch.cuda.Event()), 'sync', 0))
 
-    def branch(self, x):
+    def branch(self, x, join=True):
         """Alias of activation x for a branch traced on the side lane: same buffer and statistics,
         private gradient (the two lanes must not accumulate into one buffer concurrently); the
-        private gradient is added to x's after the lanes have joined in backward."""
+        private gradient is added to x's after the lanes have joined in backward (join=False: the
+        caller hands it over itself — Hourglass._level)."""
         if not self.use_lanes:
             return x
         xb = Act(x.buf, x.name + '/branch')
         xb.stats, xb.stats_tail, xb.amax_tail = x.stats, x.stats_tail, x.amax_tail
-        if self.training:
+        if self.training and join:
             def join_grad():
                 if xb.grad is not None:
                     self.grad_identity(x, xb.grad, donate=False, g_amax=xb.grad_amax)
