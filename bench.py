@@ -313,12 +313,26 @@ def infer_bench(model, x, batch, world, rank, args):
                           'parallelism': 'replicas%d' % world},
                'flip_tta_images_per_sec': round(world * batch / res['flip_tta'], 1),
                'note': 'not the BASELINE metric (that is the train step: default workload)'}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_JSON_OUT, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
 
+# The contract is ONE JSON line on stdout.  Libraries write to file descriptor 1 behind Python's back (RCCL prints a version
+# banner when its first communicator comes up), so the process's stdout is pointed at stderr and the line goes to a private
+# duplicate of the original descriptor.
+_JSON_OUT = sys.stdout
+
+
+def _claim_stdout():
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
+
 def main():
+    _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -449,7 +463,7 @@ def main():
         # the last line on stdout
         sys.stdout.flush()
         C.CDLL(None).fflush(None)       # RCCL's banner sits in the C stdio buffer until exit otherwise
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_JSON_OUT, flush=True)
 
 
 if __name__ == '__main__':
