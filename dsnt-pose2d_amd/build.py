@@ -41,9 +41,14 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, bdir, os.path.splitext(src)[0] + '.o')
         objs.append(o)
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
-            extra = ['-fno-slp-vectorize'] if src == 'conv.hip' else []     # no v_pk_*_f32 beside the MFMAs
+            # No SLP vectorisation anywhere.  conv.hip: v_pk_*_f32 beside the MFMAs cost more issue time than they save.
+            # Everywhere else: a pool kernel whose row sums the vectoriser had packed (v_pk_add_f32 with op_sel on a
+            # v_mov_b64'd register pair) lost a term in about one launch in ten — only while other kernels shared its
+            # CUs; the same source built without the vectoriser was bit-reproducible in 80 of 80 passes
+            # (tools/determinism_fwd.py, DESIGN.md "round 2").
+            extra = ['-fno-slp-vectorize'] if (src == 'conv.hip' or not os.environ.get('DSNT_SLP')) else []   # DSNT_SLP=1: A/B only
             if src == 'heatmap.hip':      # the reference's separately rounded fp32 coordinate steps: no FMA contraction
-                extra = ['-ffp-contract=off']
+                extra = extra + ['-ffp-contract=off']
             cmd = [hipcc] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', s, '-o', o]
             jobs.append(cmd)
     def run(cmd):

@@ -122,12 +122,13 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
         const int cg = cg0 + cg_l;
         float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
         if (active && cg < C4) {
-            // One row per iteration.  (A variant that issued the loads of FOUR rows before the first use was 2x faster on
-            // the small levels and bit-exact alone, but inside a train step — other lanes' kernels resident on the same
-            // CUs — about one launch in ten lost one row lane's s1.w (137 VGPRs, no scratch; never reproduced stand-alone,
-            // tools/determinism_fwd.py found it).  Not understood, so not shipped: the small-tensor mapping below gives
-            // most of the gain.)
-            constexpr int UB = 1;
+            // batches of UB rows: every load of the batch is issued before the first use (a workgroup of a small level is
+            // pure latency), rows are then consumed in the same order as one by one — the sums stay bit-identical to
+            // tile_reduce_kernel<0>.  (Built WITHOUT the SLP vectoriser: see build.py.)
+#ifndef DSNT_TILE_UB
+#define DSNT_TILE_UB 1        // measured: 4 is no faster once small tensors use the 16-lane mapping
+#endif
+            constexpr int UB = DSNT_TILE_UB;
             float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), bh = bs;
             if (tail.amax_bn) {
                 bs = reinterpret_cast<const float4*>(tail.amax_scale)[cg];
