@@ -443,32 +443,67 @@ extern "C" int dsnt_bn_act_fwd(const float* x, const float* scale, const float* 
     DSNT_CHECK_LAUNCH("dsnt_bn_act_fwd");
 }
 
+// FIXED: the grid stride is a multiple of C/4, so a thread stays on ONE channel group — its six per-channel vectors are
+// loaded once instead of with every element (they were two thirds of the kernel's load instructions), and two elements are
+// in flight per iteration.  Same arithmetic, element for element.
+struct BnApplyVec { float4 sc, sh, mu, is, c0, c1; };
+__device__ __forceinline__ float4 bn_apply_one(const float4 g, const float4 xv, const BnApplyVec& v, int relu) {
+    float4 dz = g;
+    if (relu) {
+        if (fmaf(xv.x, v.sc.x, v.sh.x) <= 0.f) dz.x = 0.f;
+        if (fmaf(xv.y, v.sc.y, v.sh.y) <= 0.f) dz.y = 0.f;
+        if (fmaf(xv.z, v.sc.z, v.sh.z) <= 0.f) dz.z = 0.f;
+        if (fmaf(xv.w, v.sc.w, v.sh.w) <= 0.f) dz.w = 0.f;
+    }
+    float4 o;
+    o.x = v.sc.x * (dz.x - v.c0.x - (xv.x - v.mu.x) * v.is.x * v.c1.x);
+    o.y = v.sc.y * (dz.y - v.c0.y - (xv.y - v.mu.y) * v.is.y * v.c1.y);
+    o.z = v.sc.z * (dz.z - v.c0.z - (xv.z - v.mu.z) * v.is.z * v.c1.z);
+    o.w = v.sc.w * (dz.w - v.c0.w - (xv.w - v.mu.w) * v.is.w * v.c1.w);
+    return o;
+}
+template <bool FIXED>
 __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const float4* __restrict__ x,
                                         const float4* __restrict__ scale, const float4* __restrict__ shift,
                                         const float4* __restrict__ mean, const float4* __restrict__ invstd,
                                         const float4* __restrict__ coef, int relu, float4* dx,
                                         int accumulate, long n4, int C4, unsigned* __restrict__ amax) {
     float am = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % C4);
-        const float4 g = da[i], xv = x[i], sc = scale[cg], sh = shift[cg], mu = mean[cg],
-                     is = invstd[cg], c0 = coef[cg], c1 = coef[C4 + cg];
-        float4 dz = g;
-        if (relu) {
-            if (fmaf(xv.x, sc.x, sh.x) <= 0.f) dz.x = 0.f;
-            if (fmaf(xv.y, sc.y, sh.y) <= 0.f) dz.y = 0.f;
-            if (fmaf(xv.z, sc.z, sh.z) <= 0.f) dz.z = 0.f;
-            if (fmaf(xv.w, sc.w, sh.w) <= 0.f) dz.w = 0.f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    auto vec = [&](int cg) {
+        BnApplyVec v;
+        v.sc = scale[cg]; v.sh = shift[cg]; v.mu = mean[cg]; v.is = invstd[cg]; v.c0 = coef[cg]; v.c1 = coef[C4 + cg];
+        return v;
+    };
+    auto amx = [&](const float4 o) { am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am); };
+    if (FIXED) {
+        const BnApplyVec v = vec((int)(i % C4));
+        for (; i + stride < n4; i += 2 * stride) {
+            const float4 g0 = da[i], x0 = x[i], g1 = da[i + stride], x1 = x[i + stride];
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+            if (accumulate) { p0 = dx[i]; p1 = dx[i + stride]; }
+            float4 o0 = bn_apply_one(g0, x0, v, relu), o1 = bn_apply_one(g1, x1, v, relu);
+            if (accumulate) {
+                o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
+                o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+            }
+            dx[i] = o0; dx[i + stride] = o1;
+            amx(o0); amx(o1);
         }
-        float4 o;
-        o.x = sc.x * (dz.x - c0.x - (xv.x - mu.x) * is.x * c1.x);
-        o.y = sc.y * (dz.y - c0.y - (xv.y - mu.y) * is.y * c1.y);
-        o.z = sc.z * (dz.z - c0.z - (xv.z - mu.z) * is.z * c1.z);
-        o.w = sc.w * (dz.w - c0.w - (xv.w - mu.w) * is.w * c1.w);
-        if (accumulate) { const float4 p = dx[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-        dx[i] = o;
-        am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am);
+        if (i < n4) {
+            float4 o = bn_apply_one(da[i], x[i], v, relu);
+            if (accumulate) { const float4 p = dx[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+            dx[i] = o;
+            amx(o);
+        }
+    } else {
+        for (; i < n4; i += stride) {
+            float4 o = bn_apply_one(da[i], x[i], vec((int)(i % C4)), relu);
+            if (accumulate) { const float4 p = dx[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+            dx[i] = o;
+            amx(o);
+        }
     }
     if (amax) amax_commit(am, amax);      // max |dx| for the fp16x3 consumers
 }
@@ -509,10 +544,17 @@ static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* s
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(da) && dsnt_aligned16(x) && dsnt_aligned16(dx) &&
                  dsnt_aligned16(coef), DSNT_ERR_ALIGN, "dsnt_bn_act_bwd_apply: alignment");
     const long n4 = (long)M * C / 4;
-    DSNT_LAUNCH(bn_act_bwd_apply_kernel, dim3(flat_grid(n4, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
-                       (const float4*)shift, (const float4*)mean, (const float4*)invstd,
-                       (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax);
+    const int grid = flat_grid(n4, 256);
+    if (((long)grid * 256) % (C / 4) == 0)
+        DSNT_LAUNCH(bn_act_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0,
+                    (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
+                    (const float4*)shift, (const float4*)mean, (const float4*)invstd,
+                    (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax);
+    else
+        DSNT_LAUNCH(bn_act_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0,
+                    (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
+                    (const float4*)shift, (const float4*)mean, (const float4*)invstd,
+                    (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax);
     DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_apply");
 }
 
