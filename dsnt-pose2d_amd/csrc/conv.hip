@@ -1590,33 +1590,50 @@ extern "C" int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t 
 //   dsnt_f16_prep_bn_bounds: row {gamma float*, beta float*, out float*, C, float bits of sqrt(M)}: out =
 //     max_c(|gamma_c| sqrt(M) + |beta_c|) >= every |relu?(bn(x))| of a train-mode BatchNorm over M samples
 //     (|(x - mean) / std| <= sqrt(M - 1) for the biased batch variance).
-__global__ __launch_bounds__(256) void f16_prep_weights_kernel(const long long* __restrict__ table) {
-    __shared__ float red[4];
+// (1024 threads and four independent loads per thread and pass: one workgroup walks a whole tensor, so the launch lasts as
+// long as its largest row — 130 us for a 3x3 128->128 filter with 256 threads and one load in flight, and proportionally longer
+// on hg8, where the stem convolution no longer covers it.)
+#define PREP_T 1024
+__global__ __launch_bounds__(PREP_T) void f16_prep_weights_kernel(const long long* __restrict__ table) {
+    __shared__ float red[PREP_T / 64];
     const long long* t = table + (size_t)blockIdx.x * 5;
     const float4* src = reinterpret_cast<const float4*>(t[0]);
     uint2* dst = reinterpret_cast<uint2*>(t[1]);
     float* bound = reinterpret_cast<float*>(t[2]);
     const long n4 = (long)t[3] / 4, stride4 = (long)t[4] / 4;
     float m = 0.f;
-    for (long i = threadIdx.x; i < n4; i += 256) {
+    long i = threadIdx.x;
+    for (; i + 3 * PREP_T < n4; i += 4 * PREP_T) {
+        const float4 v0 = src[i], v1 = src[i + PREP_T], v2 = src[i + 2 * PREP_T], v3 = src[i + 3 * PREP_T];
+        m = fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))), m);
+        m = fmaxf(fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))), m);
+        m = fmaxf(fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))), m);
+        m = fmaxf(fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w))), m);
+    }
+    for (; i < n4; i += PREP_T) {
         const float4 v = src[i];
         m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
     }
     m = block_max(m, red);
     if (threadIdx.x < DSNT_BOUND_SLOTS) bound[threadIdx.x] = m;
     const float sc = pow2_scale(m);
-    for (long i = threadIdx.x; i < n4; i += 256) {
-        float4 v = src[i];
+    auto put = [&](long j, float4 v) {
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         uint2 a, b;
         split4h(v, a, b);
-        dst[i] = a; dst[stride4 + i] = b;
+        dst[j] = a; dst[stride4 + j] = b;
+    };
+    i = threadIdx.x;
+    for (; i + 3 * PREP_T < n4; i += 4 * PREP_T) {
+        const float4 v0 = src[i], v1 = src[i + PREP_T], v2 = src[i + 2 * PREP_T], v3 = src[i + 3 * PREP_T];
+        put(i, v0); put(i + PREP_T, v1); put(i + 2 * PREP_T, v2); put(i + 3 * PREP_T, v3);
     }
+    for (; i < n4; i += PREP_T) put(i, src[i]);
 }
 
 extern "C" int dsnt_f16_prep_weights(const int64_t* table, int rows, void* stream) {
     DSNT_REQUIRE(table && rows > 0, DSNT_ERR_ARG, "dsnt_f16_prep_weights: bad argument");
-    DSNT_LAUNCH(f16_prep_weights_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const long long*)table);
+    DSNT_LAUNCH(f16_prep_weights_kernel, dim3(rows), dim3(PREP_T), 0, (hipStream_t)stream, (const long long*)table);
     DSNT_CHECK_LAUNCH("dsnt_f16_prep_weights");
 }
 
