@@ -792,6 +792,76 @@ extern "C" int dsnt_nhwc_to_nchw(const float* src, float* dst, int N, int C, int
     DSNT_CHECK_LAUNCH("dsnt_nhwc_to_nchw");
 }
 
+// ---------------------------------------------------------------- 7x7 / stride 2 stem as a 4x4 / stride 1 convolution
+// The stem (hourglass.py:106 / torchvision's conv1: 7x7, stride 2, pad 3 on a 3-channel image) has K = 7*7*4 = 196 with four
+// channels per tap — nothing the 16-channel K-steps of the split-precision kernels can use, so it ran on the fp32 MFMA at a
+// third of that pipe's peak.  Space-to-depth turns it into an ordinary convolution: 2x2 pixel blocks become 16 channels
+// ((dy*2+dx)*4 + c), the 7x7 filter — extended by a zero row and column at the TOP / LEFT to 8x8 — becomes 4x4 block taps at
+// block offsets -2..+1, and with one zero block row / column in front of the image that is a 4x4, stride 1, pad 1 convolution
+// on [N][H/2+1][W/2+1][16]: K = 256 (23 % zeros), every large-tile fp16x3 / bf16x6 kernel applies.
+//   dst[n][1+i][1+j][(dy*2+dx)*4 + c] = src[n][c][2i+dy][2j+dx]   (c < C <= 4; channel C..3, block row 0, block column 0: zero)
+__global__ void s2d_input_kernel(const float* __restrict__ src, float4* __restrict__ dst, int N, int C, int H, int W,
+                                 unsigned* __restrict__ amax) {
+    const int Hb = H / 2 + 1, Wb = W / 2 + 1;
+    const long total = (long)N * Hb * Wb * 4;             // one float4 (= one pixel of a block) per item
+    float am = 0.f;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(t & 3);                       // dy*2 + dx
+        long b = t >> 2;
+        const int j = (int)(b % Wb); b /= Wb;
+        const int i = (int)(b % Hb);
+        const long n = b / Hb;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i > 0 && j > 0) {
+            const int y = 2 * (i - 1) + (q >> 1), x = 2 * (j - 1) + (q & 1);
+            const float* s0 = src + ((n * C) * H + y) * (long)W + x;
+            v.x = s0[0];
+            if (C > 1) v.y = s0[(long)H * W];
+            if (C > 2) v.z = s0[2l * H * W];
+            if (C > 3) v.w = s0[3l * H * W];
+        }
+        dst[t] = v;
+        am = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), am);
+    }
+    if (amax) amax_commit(am, amax);
+}
+
+extern "C" int dsnt_s2d_input(const float* src_nchw, float* dst, int N, int C, int H, int W, const dsnt_bn_tail* tail,
+                              void* stream) {
+    DSNT_REQUIRE(src_nchw && dst && N > 0 && C > 0 && C <= 4 && H > 0 && W > 0, DSNT_ERR_ARG, "dsnt_s2d_input: bad argument");
+    DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_s2d_input: H and W must be even (got %dx%d)", H, W);
+    DSNT_REQUIRE(dsnt_aligned16(dst), DSNT_ERR_ALIGN, "dsnt_s2d_input: dst must be 16-byte aligned");
+    const long total = (long)N * (H / 2 + 1) * (W / 2 + 1) * 4;
+    DSNT_LAUNCH(s2d_input_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src_nchw, (float4*)dst, N, C,
+                H, W, (unsigned*)(tail ? tail->amax : nullptr));
+    DSNT_CHECK_LAUNCH("dsnt_s2d_input");
+}
+
+// w2[co][R][S][(dy*2+dx)*4 + c] = w[co][2R+dy-1][2S+dx-1][c] (OHWI, 4 stored channels; 0 outside the 7x7);  back != 0: the
+// inverse gather for the weight gradient, dw[co][r][s][c] = dw2[co][(r+1)/2][(s+1)/2][(((r+1)&1)*2 + ((s+1)&1))*4 + c].
+__global__ void s2d_weights_kernel(const float* __restrict__ w, float* __restrict__ w2, int Cout, int back) {
+    const int total = back ? Cout * 49 * 4 : Cout * 256;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        if (back) {
+            const int c = t & 3, rs = (t >> 2) % 49, co = (t >> 2) / 49;
+            const int r = rs / 7 + 1, s_ = rs % 7 + 1;
+            w2[t] = w[((co * 4 + (r >> 1)) * 4 + (s_ >> 1)) * 16 + ((r & 1) * 2 + (s_ & 1)) * 4 + c];
+        } else {
+            const int k = t & 15, S = (t >> 4) & 3, R = (t >> 6) & 3, co = t >> 8;
+            const int c = k & 3, dx = (k >> 2) & 1, dy = k >> 3;
+            const int r = 2 * R + dy - 1, s_ = 2 * S + dx - 1;
+            w2[t] = (r >= 0 && s_ >= 0) ? w[((co * 7 + r) * 7 + s_) * 4 + c] : 0.f;
+        }
+    }
+}
+
+extern "C" int dsnt_s2d_weights(const float* w, float* w2, int Cout, int back, void* stream) {
+    DSNT_REQUIRE(w && w2 && Cout > 0, DSNT_ERR_ARG, "dsnt_s2d_weights: bad argument");
+    const int total = back ? Cout * 196 : Cout * 256;
+    DSNT_LAUNCH(s2d_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, w2, Cout, back);
+    DSNT_CHECK_LAUNCH("dsnt_s2d_weights");
+}
+
 // ---------------------------------------------------------------- optimiser (flat arena)
 // `flag` (nullable, int[2]): the step's non-finite guard.  flag[0] != 0 at kernel start = an earlier check on this
 // stream fired (non-finite loss): nothing is updated.  A non-finite gradient element is skipped and raises

@@ -51,12 +51,14 @@ class Act:
 
 class ConvParams:
     """Views into the parameter / gradient arenas for one convolution (weights are OHWI)."""
-    __slots__ = ('w', 'b', 'gw', 'gb', 'Cout', 'R', 'S', 'Cin', 'stride', 'pad', 'dil', 'wq', 'wq_stride', 'wq16', 'wb')
+    __slots__ = ('w', 'b', 'gw', 'gb', 'Cout', 'R', 'S', 'Cin', 'stride', 'pad', 'dil', 'wq', 'wq_stride', 'wq16', 'wb',
+                 'post_reduce')
 
     def __init__(self, w, b, gw, gb, stride=1, pad=0, dil=1):
         self.w, self.b, self.gw, self.gb = w, b, gw, gb
         self.wq, self.wq_stride = None, 0      # bf16x6 planes of w (plane 0 view, plane stride)
         self.wq16, self.wb = None, None        # fp16x3: fp16 planes (same stride) and the device scalar max|w|
+        self.post_reduce = None                # (name, args) launched after the slab reduction that writes gw (stem_s2d)
         self.Cout, self.R, self.S, self.Cin = w.shape
         self.stride, self.pad, self.dil = stride, pad, dil
 
@@ -144,6 +146,8 @@ class Tape:
         self._eval_bn_rows = []     # eval mode: every BatchNorm's vectors come from ONE table-driven launch per forward
         self._amax_buf, self._amax_used = None, 0      # zeroed at the start of every backward
         self.raw_f16 = os.environ.get('DSNT_RAW_F16', '1') != '0'      # A/B switch: bounds of raw operands from the producers' epilogues
+        self._planar_src, self._prep_exempt, self._post_reduce = {}, set(), []
+        self.stem_s2d_on = os.environ.get('DSNT_STEM_S2D', '1') != '0'
         self._famax_buf, self._famax_used, self._famax_of, self._famax_bn_of = None, 0, {}, {}   # forward activations: zeroed at the start of every forward
         # DSNT_AMAX_ALL=0: only single-writer BN-backward outputs get a bound (A/B switch); default: bounds follow the
         # gradient through every writer that can report one (apply, axpy, pool / upsample backward) and through donations
@@ -322,7 +326,8 @@ class Tape:
         self.fwd[pos:pos] = prep
         if side and prep:
             first = next((i for i in range(pos + len(prep), len(self.fwd))
-                          if self.fwd[i][0] is not None and self.fwd[i][2] in self._PREP_CONSUMERS), len(self.fwd))
+                          if self.fwd[i][0] is not None and self.fwd[i][2] in self._PREP_CONSUMERS
+                          and id(self.fwd[i]) not in self._prep_exempt), len(self.fwd))
             self.fwd.insert(first, (None, (side, 0, torch.cuda.Event()), 'sync', 0))
 
     def new_tail(self):
@@ -486,6 +491,9 @@ class Tape:
         self._keep.append(table)
         blocks = max((r[4] // 4 + (r[5] + 3) // 4 + 63) // 64 for r in rows)
         self.b('dsnt_wgrad_reduce_all', table, len(rows), blocks)
+        for nm, args in self._post_reduce:          # gradients that are reduced in another layout than the parameter's
+            self.b(nm, *args)
+        self._post_reduce = []
 
     def mark_bucket(self, k):
         """Forward position where parameter bucket k starts being used: in the (reversed) backward
@@ -824,6 +832,8 @@ class Tape:
                 else:
                     self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
                            None, None, share if w6 else 0, g)
+                if p.post_reduce is not None:
+                    self._post_reduce.append(p.post_reduce)
                 self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
                                              self.lib.dsnt_conv_wgrad_splits(C.byref(g)), p.Cout * g.R * g.S * g.Cin,
                                              p.Cout, 0])
@@ -1047,5 +1057,39 @@ class Tape:
         """Logical NCHW input [N, C, H, W] -> NHWC Act with channels zero-padded to Cpad."""
         N, Cc, H, W = src_nchw.shape
         a = self.act(N, H, W, Cpad, name)
-        self.f('dsnt_nchw_to_nhwc', src_nchw, a.buf, N, Cc, H * W, Cpad)
+        e = self.f('dsnt_nchw_to_nhwc', src_nchw, a.buf, N, Cc, H * W, Cpad)
+        self._planar_src[id(a)] = (src_nchw, e)
         return a
+
+    def stem_s2d(self, x, p, name='stem'):
+        """The 7x7 / stride 2 / pad 3 convolution of a planar (<= 4 channel) input as a 4x4 / stride 1 / pad 1 convolution
+        on its space-to-depth form (csrc/elementwise.hip: dsnt_s2d_input / dsnt_s2d_weights): K = 256 in 16-channel steps,
+        so the stem runs on the split-precision matrix-core kernels like every other large convolution instead of the
+        fp32 MFMA (245 -> ~80 us at batch 32).  Returns None if it does not apply (the caller then uses `conv`)."""
+        got = self._planar_src.get(id(x))
+        if (got is None or not self.use_f16x3 or not self.stem_s2d_on or p.R != 7 or p.S != 7 or p.stride != 2 or p.pad != 3
+                or p.dil != 1 or x.C != 4 or x.H % 2 or x.W % 2 or x.N * (x.H // 2) * (x.W // 2) < self.bf16x6_min_rows):
+            return None
+        src, entry = got
+        self.fwd.remove(entry)                      # the NHWC copy of the image is not needed
+        xs = self.act(x.N, x.H // 2 + 1, x.W // 2 + 1, 16, 'input_s2d')
+        xs.amax_tail = BnTail()
+        self.f('dsnt_s2d_input', src, xs.buf, x.N, src.shape[1], x.H, x.W, xs.amax_tail)
+        n = p.Cout * 256
+        w2, gw2 = self.empty(p.Cout, 4, 4, 16), self.empty(p.Cout, 4, 4, 16)
+        p2 = ConvParams(w2, p.b, gw2, p.gb, 1, 1, 1)
+        p2.wq, p2.wq_stride = self.empty(3 * n, dtype=torch.bfloat16), n
+        p2.wq16, p2.wb = self.empty(2 * n, dtype=torch.float16), self.empty(64)
+        p2.post_reduce = ('dsnt_s2d_weights', (gw2, p.gw, p.Cout, 1))
+        # the re-packed filter and its planes: tiny launches on the MAIN lane right before the convolution (the table-driven
+        # preparation of all other weights runs on the side lane beside it)
+        self.f('dsnt_s2d_weights', p.w, w2, p.Cout, 0)
+        self.f('dsnt_split_bf16x3', w2, p2.wq, n)
+        row = torch.tensor([[w2.data_ptr(), p2.wq16.data_ptr(), p2.wb.data_ptr(), n, n]], dtype=torch.int64).to(self.device)
+        self._keep.append(row)
+        self.f('dsnt_f16_prep_weights', row, 1)
+        self._f16_w_seen.add(p2.wq16.data_ptr())    # (prepared here, not by the table-driven launch)
+        mark = len(self.fwd)
+        y = self.conv(xs, p2, want_stats=True, need_input_grad=False, name=name)
+        self._prep_exempt.update(id(e) for e in self.fwd[mark:])
+        return y

@@ -495,7 +495,8 @@ class HourglassNet(TapeModule):
             raise RuntimeError('dsnt: hourglass input must be a multiple of 64 pixels '
                                '(stem /4, four 2x2 poolings), got %dx%d' % (x.H, x.W))
         t.mark_bucket(0)
-        x = t.conv(x, P.conv(self.conv1), want_stats=True, need_input_grad=False, name='stem')
+        stem = P.conv(self.conv1)
+        x = t.stem_s2d(x, stem) or t.conv(x, stem, want_stats=True, need_input_grad=False, name='stem')
         x = t.bn_act(x, P.bn(self.bn1), relu=True, name='stem_act')
         x = _trace_seq(self.layer1, t, x, P)
         x = t.maxpool2(x)

@@ -424,6 +424,14 @@ int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, float* out, 
 int dsnt_bn_act_fwd_stats(const float* x, const float* scale, const float* shift, int relu, float* y, float* partial,
                           int64_t M, int C, const dsnt_bn_tail* tail, void* stream);
 
+/* The 7x7 / stride 2 / pad 3 stem convolution on a C <= 4 channel image (hourglass.py:106; torchvision resnet conv1) as a
+ * 4x4 / stride 1 / pad 1 convolution: dsnt_s2d_input writes the image as [N][H/2+1][W/2+1][16] (2x2 pixel blocks -> 16 channels,
+ * one zero block row / column in front; tail->amax, if given, receives max|image| as the fp16x3 operand bound);
+ * dsnt_s2d_weights re-packs OHWI [Cout][7][7][4] weights into [Cout][4][4][16] (back = 0) or gathers a [Cout][4][4][16] weight
+ * gradient back into [Cout][7][7][4] (back = 1).  Any convolution entry point then runs the stem with K = 256. */
+int dsnt_s2d_input(const float* src_nchw, float* dst, int N, int C, int H, int W, const dsnt_bn_tail* tail, void* stream);
+int dsnt_s2d_weights(const float* w, float* w2, int Cout, int back, void* stream);
+
 /* y (+)= a*x, flat; n % 4 == 0 not required. */
 int dsnt_axpy(const float* x, float* y, float a, int accumulate, int64_t n, void* stream);
 

@@ -841,3 +841,44 @@ def test_epilogue_leaves_the_bound_of_its_output(path, k, with_res):
              C.byref(t))
         torch.cuda.synchronize()
         assert float(slots.max()) == float(ys.abs().max())
+
+
+def test_stem_as_space_to_depth_convolution():
+    """The 7x7 / stride 2 / pad 3 stem (hourglass.py:106) as a 4x4 / stride 1 / pad 1 convolution on the space-to-depth image
+    (dsnt_s2d_input + dsnt_s2d_weights): same result as F.conv2d on the original tensors, max|image| as the operand bound,
+    and the gradient gather (back = 1) is the adjoint of the filter re-packing."""
+    from dsnt._lib import ptr, call, ConvGeom, BnTail
+    dev = torch.device('cuda:0')
+    torch.manual_seed(7)
+    N, Cc, H, W, Cout = 2, 3, 32, 48, 8
+    x = torch.randn(N, Cc, H, W, device=dev)
+    w = torch.randn(Cout, Cc, 7, 7, device=dev) * 0.1
+    b = torch.randn(Cout, device=dev)
+    want = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=3)
+    w_ohwi = torch.zeros(Cout, 7, 7, 4, device=dev)
+    w_ohwi[..., :Cc] = w.permute(0, 2, 3, 1)
+    xs = torch.full((N, H // 2 + 1, W // 2 + 1, 16), float('nan'), device=dev)
+    slots = torch.zeros(64, device=dev)
+    t = BnTail()
+    t.amax = slots.data_ptr()
+    call('dsnt_s2d_input', ptr(x), ptr(xs), N, Cc, H, W, C.byref(t))
+    w2 = torch.full((Cout, 4, 4, 16), float('nan'), device=dev)
+    call('dsnt_s2d_weights', ptr(w_ohwi), ptr(w2), Cout, 0)
+    torch.cuda.synchronize()
+    assert float(slots.max()) == float(x.abs().max())
+    assert float(xs[:, 0].abs().max()) == 0 and float(xs[:, :, 0].abs().max()) == 0 and not torch.isnan(xs).any()
+    assert float(w2[:, 0, :, :8].abs().max()) == 0 and float(w2[:, :, 0, 0:4].abs().max()) == 0    # the added zero row / column
+    g = ConvGeom(N, H // 2 + 1, W // 2 + 1, 16, H // 2, W // 2, Cout, 4, 4, 1, 1, 1)
+    y = torch.empty(N, H // 2, W // 2, Cout, device=dev)
+    call('dsnt_conv_fwd', ptr(xs), ptr(w2), ptr(b), ptr(y), None, None, 0, None, None, None, C.byref(g))
+    torch.cuda.synchronize()
+    err = (y.permute(0, 3, 1, 2).double() - want).abs().max().item()
+    assert err <= 2e-5 * want.abs().max().item(), err
+    # adjoint: <repack(w), g2> == <w, gather(g2)>
+    g2 = torch.randn(Cout, 4, 4, 16, device=dev)
+    back = torch.full((Cout, 7, 7, 4), float('nan'), device=dev)
+    call('dsnt_s2d_weights', ptr(g2), ptr(back), Cout, 1)
+    torch.cuda.synchronize()
+    lhs = float((w2.double() * g2.double()).sum())
+    rhs = float((w_ohwi.double() * back.double()).sum())
+    assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs)) and not torch.isnan(back).any()
