@@ -1637,6 +1637,50 @@ extern "C" int dsnt_f16_prep_weights(const int64_t* table, int rows, void* strea
     DSNT_CHECK_LAUNCH("dsnt_f16_prep_weights");
 }
 
+// The stem's per-step weight preparation in ONE small launch (one 256-thread workgroup; 16 K values): the [Cout][4][4][16]
+// space-to-depth form of the OHWI [Cout][7][7][4] filter (dsnt_s2d_weights, back = 0), its maximum, and its fp16 (two) and
+// bf16 (three) planes — instead of three launches, one of them a 1024-thread workgroup that waits for a free CU at the head of
+// every step.
+__global__ __launch_bounds__(256) void s2d_weights_prep_kernel(const float* __restrict__ w, float* __restrict__ w2,
+                                                               uint2* __restrict__ p16, uint2* __restrict__ p6,
+                                                               float* __restrict__ bound, int Cout) {
+    __shared__ float red[4];
+    const int n4 = Cout * 64;                     // float4 groups of w2: [Cout][4][4][4 blocks-of-4]
+    auto fetch = [&](int q) {                     // group q = ((co*4 + R)*4 + S)*4 + (dy*2+dx): four channels of one tap
+        const int d = q & 3, S = (q >> 2) & 3, R = (q >> 4) & 3, co = q >> 6;
+        const int r = 2 * R + (d >> 1) - 1, s_ = 2 * S + (d & 1) - 1;
+        return (r >= 0 && s_ >= 0) ? *reinterpret_cast<const float4*>(w + ((co * 7 + r) * 7 + s_) * 4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float m = 0.f;
+    for (int q = threadIdx.x; q < n4; q += 256) {
+        const float4 v = fetch(q);
+        m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
+    }
+    m = block_max(m, red);
+    if (threadIdx.x < DSNT_BOUND_SLOTS) bound[threadIdx.x] = m;
+    const float sc = pow2_scale(m);
+    for (int q = threadIdx.x; q < n4; q += 256) {
+        const float4 v = fetch(q);
+        if (w2) reinterpret_cast<float4*>(w2)[q] = v;
+        uint2 a, b, c;
+        split4(v, a, b, c);
+        p6[q] = a; p6[n4 + q] = b; p6[2 * n4 + q] = c;
+        split4h(make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc), a, b);
+        p16[q] = a; p16[n4 + q] = b;
+    }
+}
+
+extern "C" int dsnt_s2d_weights_prep(const float* w, float* w2, void* planes16, void* planes_bf16, float* bound, int Cout,
+                                     void* stream) {
+    DSNT_REQUIRE(w && planes16 && planes_bf16 && bound && Cout > 0, DSNT_ERR_ARG, "dsnt_s2d_weights_prep: bad argument");
+    DSNT_REQUIRE(dsnt_aligned16(w) && (!w2 || dsnt_aligned16(w2)) && (((uintptr_t)planes16) & 7u) == 0 &&
+                 (((uintptr_t)planes_bf16) & 7u) == 0, DSNT_ERR_ALIGN, "dsnt_s2d_weights_prep: alignment");
+    DSNT_LAUNCH(s2d_weights_prep_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, w2, (uint2*)planes16, (uint2*)planes_bf16,
+                bound, Cout);
+    DSNT_CHECK_LAUNCH("dsnt_s2d_weights_prep");
+}
+
 __global__ __launch_bounds__(64) void f16_prep_bn_bounds_kernel(const long long* __restrict__ table) {
     const long long* t = table + (size_t)blockIdx.x * 5;
     const float* gamma = reinterpret_cast<const float*>(t[0]);

@@ -110,6 +110,7 @@ SIGNATURES = {
     'dsnt_bn_act_fwd_stats': [P, P, P, I, P, P, L, I, TP, P],
     'dsnt_s2d_input': [P, P, I, I, I, I, TP, P],
     'dsnt_s2d_weights': [P, P, I, I, P],
+    'dsnt_s2d_weights_prep': [P, P, P, P, P, I, P],
     'dsnt_maxpool3s2_fwd': [P, P, P, I, I, I, I, P],
     'dsnt_maxpool3s2_bwd': [P, P, P, I, I, I, I, I, P],
     'dsnt_bn_add_act_fwd': [P, P, P, P, I, P, L, I, P],

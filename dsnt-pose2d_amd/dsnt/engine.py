@@ -1081,13 +1081,9 @@ class Tape:
         p2.wq, p2.wq_stride = self.empty(3 * n, dtype=torch.bfloat16), n
         p2.wq16, p2.wb = self.empty(2 * n, dtype=torch.float16), self.empty(64)
         p2.post_reduce = ('dsnt_s2d_weights', (gw2, p.gw, p.Cout, 1))
-        # the re-packed filter and its planes: tiny launches on the MAIN lane right before the convolution (the table-driven
+        # the re-packed filter and its planes: one tiny launch on the MAIN lane right before the convolution (the table-driven
         # preparation of all other weights runs on the side lane beside it)
-        self.f('dsnt_s2d_weights', p.w, w2, p.Cout, 0)
-        self.f('dsnt_split_bf16x3', w2, p2.wq, n)
-        row = torch.tensor([[w2.data_ptr(), p2.wq16.data_ptr(), p2.wb.data_ptr(), n, n]], dtype=torch.int64).to(self.device)
-        self._keep.append(row)
-        self.f('dsnt_f16_prep_weights', row, 1)
+        self.f('dsnt_s2d_weights_prep', p.w, w2, p2.wq16, p2.wq, p2.wb, p.Cout)
         self._f16_w_seen.add(p2.wq16.data_ptr())    # (prepared here, not by the table-driven launch)
         mark = len(self.fwd)
         y = self.conv(xs, p2, want_stats=True, need_input_grad=False, name=name)

@@ -431,6 +431,9 @@ int dsnt_bn_act_fwd_stats(const float* x, const float* scale, const float* shift
  * gradient back into [Cout][7][7][4] (back = 1).  Any convolution entry point then runs the stem with K = 256. */
 int dsnt_s2d_input(const float* src_nchw, float* dst, int N, int C, int H, int W, const dsnt_bn_tail* tail, void* stream);
 int dsnt_s2d_weights(const float* w, float* w2, int Cout, int back, void* stream);
+/* dsnt_s2d_weights (back = 0) + the filter's maximum (bound[64]) + its two fp16 planes (scaled as dsnt_split_f16x2 does,
+ * plane stride Cout*256) + its three bf16 planes (dsnt_split_bf16x3 layout) in one launch; w2 (fp32 copy) may be NULL. */
+int dsnt_s2d_weights_prep(const float* w, float* w2, void* planes16, void* planes_bf16, float* bound, int Cout, void* stream);
 
 /* y (+)= a*x, flat; n % 4 == 0 not required. */
 int dsnt_axpy(const float* x, float* y, float a, int accumulate, int64_t n, void* stream);

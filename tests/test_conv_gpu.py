@@ -874,6 +874,19 @@ def test_stem_as_space_to_depth_convolution():
     torch.cuda.synchronize()
     err = (y.permute(0, 3, 1, 2).double() - want).abs().max().item()
     assert err <= 2e-5 * want.abs().max().item(), err
+    # the one-launch per-step form: re-packed filter + bound + fp16 / bf16 planes, identical to the separate launches
+    n = Cout * 256
+    w2b = torch.empty_like(w2)
+    p16, p6, bnd = (torch.empty(2 * n, dtype=torch.float16, device=dev), torch.empty(3 * n, dtype=torch.bfloat16, device=dev),
+                    torch.zeros(64, device=dev))
+    call('dsnt_s2d_weights_prep', ptr(w_ohwi), ptr(w2b), ptr(p16), ptr(p6), ptr(bnd), Cout)
+    q16, q6, bnd2 = torch.empty_like(p16), torch.empty_like(p6), torch.zeros(64, device=dev)
+    call('dsnt_split_bf16x3', ptr(w2), ptr(q6), n)
+    call('dsnt_amax', ptr(w2), n, ptr(bnd2))
+    call('dsnt_split_f16x2', ptr(w2), ptr(q16), n, n, ptr(bnd2))
+    torch.cuda.synchronize()
+    assert torch.equal(w2b, w2) and float(bnd.max()) == float(w2.abs().max()) == float(bnd2.max())
+    assert torch.equal(p16.view(torch.int16), q16.view(torch.int16)) and torch.equal(p6.view(torch.int16), q6.view(torch.int16))
     # adjoint: <repack(w), g2> == <w, gather(g2)>
     g2 = torch.randn(Cout, 4, 4, 16, device=dev)
     back = torch.full((Cout, 7, 7, 4), float('nan'), device=dev)
