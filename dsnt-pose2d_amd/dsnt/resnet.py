@@ -125,7 +125,8 @@ def trace_fcn(fcn, hm_conv, t, x, P):
     """`hm_conv(fcn(x))` (reference model.py:138-141) for fcn = Sequential(conv1, bn1, relu, maxpool, layer1, ...)."""
     conv1, bn1 = fcn[0], fcn[1]
     t.mark_bucket(0)        # one gradient bucket: its all-reduce starts when the stem's weight gradient is done
-    x = t.conv(x, P.conv(conv1), want_stats=True, need_input_grad=False, name='stem')
+    stem = P.conv(conv1)
+    x = t.stem_s2d(x, stem) or t.conv(x, stem, want_stats=True, need_input_grad=False, name='stem')
     x = t.bn_act(x, P.bn(bn1), relu=True, name='stem_act')
     x = t.maxpool3s2(x, name='pool')
     for layer in list(fcn)[4:]:
