@@ -106,7 +106,7 @@ class Tape:
         # DSNT_WGRAD_LANE_RES=1 also moves convolutions with residual inputs, whose dY buffer is donated onwards and
         # written again — the writer then has to wait for the lane (measured: +0.45 ms, off).
         self.wgrad_lane = 2 if (self.use_lanes and os.environ.get('DSNT_WGRAD_LANE', '1') != '0') else None
-        self.wgrad_lane_rows = int(os.environ.get('DSNT_WGRAD_LANE_ROWS', '30000'))
+        self.wgrad_lane_rows = int(os.environ.get('DSNT_WGRAD_LANE_ROWS', '16000'))
         self.wgrad_lane_res = os.environ.get('DSNT_WGRAD_LANE_RES', '0') != '0'
         self.wgrad_lane_from = (0, 1) if os.environ.get('DSNT_WGRAD_LANE_SIDE', '1') != '0' else (0,)
         self.wgrad_share = os.environ.get('DSNT_WGRAD_SHARE', '1') != '0'
