@@ -100,6 +100,12 @@ class Tape:
         self.fuse_join = os.environ.get('DSNT_FUSE_JOIN', '1') != '0'      # hourglass.Hourglass._level
         self.side_stream = None
         self.wgrad_stream = None
+        # lanes 3.. : more side lanes (the skip branches of the hourglass levels alternate over them: an inner level's
+        # branch, which the main lane needs back first, does not queue behind the outer level's large kernels)
+        self.side_lanes = (1,) + tuple(range(3, 3 + max(0, int(os.environ.get('DSNT_SIDE_LANES', '2')) - 1)))
+        self.n_lanes = 3 + len(self.side_lanes) - 1
+        self.chain_lanes = (0,) + self.side_lanes
+        self.more_streams = ()
         # weight gradients feed nothing downstream in backward.  The large ones (>= DSNT_WGRAD_LANE_ROWS output rows; 0 =
         # all) go to a third lane: the chip then has work while the dependency chain walks the launch-bound
         # low-resolution levels, and the main lane neither runs nor waits for the slab reductions (-0.9 ms/step on hg2).
@@ -108,7 +114,7 @@ class Tape:
         self.wgrad_lane = 2 if (self.use_lanes and os.environ.get('DSNT_WGRAD_LANE', '1') != '0') else None
         self.wgrad_lane_rows = int(os.environ.get('DSNT_WGRAD_LANE_ROWS', '16000'))
         self.wgrad_lane_res = os.environ.get('DSNT_WGRAD_LANE_RES', '0') != '0'
-        self.wgrad_lane_from = (0, 1) if os.environ.get('DSNT_WGRAD_LANE_SIDE', '1') != '0' else (0,)
+        self.wgrad_lane_from = self.chain_lanes if os.environ.get('DSNT_WGRAD_LANE_SIDE', '1') != '0' else (0,)
         self.wgrad_share = os.environ.get('DSNT_WGRAD_SHARE', '1') != '0'
         self._wgrad_lane_reads = set()
         # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
@@ -467,7 +473,7 @@ class Tape:
         runs the reduction; without, the main lane."""
         self.release_wgrads()
         fl = self.wgrad_lane if self.wgrad_lane is not None else 0
-        for src in (0, 1):
+        for src in self.chain_lanes:
             self.sync_bwd(src, fl)
         return fl
 
@@ -517,7 +523,7 @@ class Tape:
         marks = []
         try:
             if self.use_lanes:
-                for lane in (1, 2):
+                for lane in range(1, self.n_lanes):
                     self._rc(lib.dsnt_list_sync(h, 0, lane), 'dsnt_list_sync')
             self._rc(lib.dsnt_list_begin(h), 'dsnt_list_begin')
             try:
@@ -533,7 +539,7 @@ class Tape:
             finally:
                 lib.dsnt_list_end()
             if self.use_lanes:
-                for lane in (1, 2):
+                for lane in range(1, self.n_lanes):
                     self._rc(lib.dsnt_list_sync(h, lane, 0), 'dsnt_list_sync')
         except Exception:
             lib.dsnt_list_destroy(h)
@@ -559,19 +565,20 @@ class Tape:
             # change nothing on this hardware)
             self.side_stream = torch.cuda.Stream()
             self.wgrad_stream = torch.cuda.Stream()
+            self.more_streams = tuple(torch.cuda.Stream() for _ in range(self.n_lanes - 3))
         return self._run(lst, main, bucket_hook, probe)
 
     def _run(self, lst, main, bucket_hook, probe):
-        streams = (main, self.side_stream, self.wgrad_stream)
+        streams = (main, self.side_stream, self.wgrad_stream) + self.more_streams
         ptrs = tuple(st.cuda_stream if st is not None else 0 for st in streams)
         if self.c_replay and probe is None:
             cl = self._clists.get(id(lst))
             if cl is None:
                 cl = self._clists[id(lst)] = self._compile(lst)
             h, marks = cl
-            arr = (C.c_void_p * 3)(*ptrs)
+            arr = (C.c_void_p * len(ptrs))(*ptrs)
             for seg in range(len(marks) + 1):
-                rc = self.lib.dsnt_list_replay(h, seg, arr, 3)
+                rc = self.lib.dsnt_list_replay(h, seg, arr, len(ptrs))
                 if rc != 0:
                     torch.cuda.synchronize()
                     self._tail_counters.zero_()
@@ -584,6 +591,8 @@ class Tape:
         if self.use_lanes:
             self.side_stream.wait_stream(main)
             self.wgrad_stream.wait_stream(main)
+            for st in self.more_streams:
+                st.wait_stream(main)
         for entry in lst:
             fn, args, name, lane = entry
             if fn is None:
@@ -606,6 +615,8 @@ class Tape:
         if self.use_lanes:
             main.wait_stream(self.side_stream)
             main.wait_stream(self.wgrad_stream)
+            for st in self.more_streams:
+                main.wait_stream(st)
 
     # ------------------------------------------------------------------ gradient plumbing
     def grad_target(self, a, amax=False):

@@ -404,22 +404,25 @@ class Hourglass(TapeModule):
             # the pool's backward is emitted — the main lane then waits for the side lane, takes the branch's gradient
             # buffer over as x's and the pool's backward ACCUMULATES into it (no separate x.grad += branch.grad pass:
             # 400 MB at 64 x 64).  Launch order within a lane is unchanged.
+            # (DSNT_SIDE_LANES side lanes, alternating by level: the inner levels' branches — which the main lane needs back first —
+            # do not queue behind the outer level's large kernels)
+            side = t.side_lanes[n % len(t.side_lanes)]
             xb = t.branch(x, join=False)
-            t.sync(0, 1, bwd=False)
+            t.sync(0, side, bwd=False)
             pooled = t.maxpool2(x)
 
             def take_branch_gradient():         # registered after the pool: runs right before the pool's backward
-                t.sync_bwd(1, 0)
+                t.sync_bwd(side, 0)
                 if xb.grad is not None:
                     t.grad_identity(x, xb.grad, donate=True, g_amax=xb.grad_amax)
             t.on_backward(take_branch_gradient)
             low = _trace_seq(g[1], t, pooled, P)
             low = self._level(n - 1, t, low, P) if n > 1 else _trace_seq(g[3], t, low, P)
             low = _trace_seq(g[2], t, low, P)
-            t.lane = 1
+            t.lane = side
             up1 = _trace_seq(g[0], t, xb, P)
             t.lane = 0
-            t.sync(1, 0)
+            t.sync(side, 0)
             return t.upsample2_add(up1, low)
         xb = t.branch(x)
         t.sync(0, 1)
