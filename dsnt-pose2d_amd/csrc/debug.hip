@@ -184,3 +184,41 @@ extern "C" int dsnt_debug_starve(float* out, long long* out_cycles, int blocks, 
 #undef LAUNCH_STARVE
     DSNT_CHECK_LAUNCH("dsnt_debug_starve");
 }
+
+// How much does a chip-wide grid barrier cost?  (fusing the sub-32x32 hourglass levels into persistent
+// launches replaces ~5 us kernel boundaries by grid barriers — worth it only if a barrier is much cheaper.)
+// `blocks` co-resident workgroups (the caller keeps blocks <= CUs) run `iters` barriers: one lane per workgroup adds to a
+// counter with an agent-scope release, then polls it with agent-scope acquire loads until every workgroup of the round has
+// arrived; a __syncthreads on both sides makes it a workgroup-wide barrier.  A bounded spin (2^16 polls) turns a lost
+// workgroup into a wrong result instead of a hang.  out[0] = polls of workgroup 0 (diagnostic).
+__global__ void grid_barrier_kernel(unsigned* counter, int iters, float* out) {
+    unsigned polls = 0;
+    for (int it = 1; it <= iters; ++it) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)it * gridDim.x;
+            int guard = 0;
+            while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want && ++guard < (1 << 16)) {
+                ++polls;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out) out[0] = (float)polls;
+}
+
+extern "C" int dsnt_debug_grid_barrier(unsigned* counter, int blocks, int threads, int iters, float* out, void* stream) {
+    DSNT_REQUIRE(counter && blocks > 0 && blocks <= 256 && threads > 0 && threads <= 1024 && iters > 0, DSNT_ERR_ARG,
+                 "dsnt_debug_grid_barrier: bad argument (at most 256 workgroups: they must be co-resident)");
+    DSNT_LAUNCH(grid_barrier_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, counter, iters, out);
+    DSNT_CHECK_LAUNCH("dsnt_debug_grid_barrier");
+}
+
+__global__ void empty_kernel(float* out) { if (out && threadIdx.x == 0 && blockIdx.x == 0) out[1] = 1.f; }
+extern "C" int dsnt_debug_empty(int blocks, int threads, float* out, void* stream) {
+    DSNT_REQUIRE(blocks > 0 && threads > 0 && threads <= 1024, DSNT_ERR_ARG, "dsnt_debug_empty: bad argument");
+    DSNT_LAUNCH(empty_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, out);
+    DSNT_CHECK_LAUNCH("dsnt_debug_empty");
+}

@@ -131,6 +131,8 @@ SIGNATURES = {
     'dsnt_debug_coexec': [P, I, I, I, P],
     'dsnt_debug_bf16_peak': [P, I, I, I, I, P],
     'dsnt_debug_starve': [P, P, I, I, I, I, P],
+    'dsnt_debug_grid_barrier': [P, I, I, I, P, P],
+    'dsnt_debug_empty': [I, I, P, P],
     'dsnt_debug_force_gemm6': [I],
 }
 # entry points without the status/stream convention

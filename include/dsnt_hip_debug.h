@@ -31,6 +31,11 @@ int dsnt_debug_force_gemm6(int on);
 int dsnt_debug_starve(float* out, long long* out_cycles, int blocks, int mfma_iters, int valu_n, int prio,
                       void* stream);
 
+/* Cost of a chip-wide grid barrier vs a kernel boundary (tools/grid_barrier.py): `blocks` (<= 256, co-resident) workgroups run
+ * `iters` barriers on `counter` (one uint32, zero before the launch); dsnt_debug_empty is the dependent-launch yardstick. */
+int dsnt_debug_grid_barrier(unsigned* counter, int blocks, int threads, int iters, float* out, void* stream);
+int dsnt_debug_empty(int blocks, int threads, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
