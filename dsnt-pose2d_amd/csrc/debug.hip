@@ -209,6 +209,39 @@ __global__ void grid_barrier_kernel(unsigned* counter, int iters, float* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && out) out[0] = (float)polls;
 }
 
+// Two-level form: one counter per XCD (workgroups are dealt round-robin to the 8 XCDs, so blockIdx.x & 7 is the XCD of a
+// launch that starts on an idle chip — a grouping key, not a placement guarantee), the last arriver of a group adds to the top
+// counter, everybody polls the top counter.  counter[0] = top, counter[16 * (1 + g)] = group g (own cache lines).
+__global__ void grid_barrier2_kernel(unsigned* counter, int iters, float* out) {
+    unsigned polls = 0;
+    const int g = blockIdx.x & 7;
+    const unsigned gsize = (gridDim.x >> 3) + ((unsigned)g < (gridDim.x & 7u) ? 1u : 0u);
+    const unsigned ngroups = gridDim.x < 8 ? gridDim.x : 8;
+    for (int it = 1; it <= iters; ++it) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(counter + 16 * (1 + g), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1 == (unsigned)it * gsize)
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)it * ngroups;
+            int guard = 0;
+            while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want && ++guard < (1 << 16)) {
+                ++polls;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && out) out[0] = (float)polls;
+}
+
+extern "C" int dsnt_debug_grid_barrier2(unsigned* counter, int blocks, int threads, int iters, float* out, void* stream) {
+    DSNT_REQUIRE(counter && blocks > 0 && blocks <= 256 && threads > 0 && threads <= 1024 && iters > 0, DSNT_ERR_ARG,
+                 "dsnt_debug_grid_barrier2: bad argument (counter: 16 * 9 zeroed uint32; at most 256 workgroups)");
+    DSNT_LAUNCH(grid_barrier2_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, counter, iters, out);
+    DSNT_CHECK_LAUNCH("dsnt_debug_grid_barrier2");
+}
+
 extern "C" int dsnt_debug_grid_barrier(unsigned* counter, int blocks, int threads, int iters, float* out, void* stream) {
     DSNT_REQUIRE(counter && blocks > 0 && blocks <= 256 && threads > 0 && threads <= 1024 && iters > 0, DSNT_ERR_ARG,
                  "dsnt_debug_grid_barrier: bad argument (at most 256 workgroups: they must be co-resident)");

@@ -132,6 +132,7 @@ SIGNATURES = {
     'dsnt_debug_bf16_peak': [P, I, I, I, I, P],
     'dsnt_debug_starve': [P, P, I, I, I, I, P],
     'dsnt_debug_grid_barrier': [P, I, I, I, P, P],
+    'dsnt_debug_grid_barrier2': [P, I, I, I, P, P],
     'dsnt_debug_empty': [I, I, P, P],
     'dsnt_debug_force_gemm6': [I],
 }

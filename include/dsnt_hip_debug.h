@@ -34,6 +34,8 @@ int dsnt_debug_starve(float* out, long long* out_cycles, int blocks, int mfma_it
 /* Cost of a chip-wide grid barrier vs a kernel boundary (tools/grid_barrier.py): `blocks` (<= 256, co-resident) workgroups run
  * `iters` barriers on `counter` (one uint32, zero before the launch); dsnt_debug_empty is the dependent-launch yardstick. */
 int dsnt_debug_grid_barrier(unsigned* counter, int blocks, int threads, int iters, float* out, void* stream);
+/* two-level form: counter = 16 * 9 zeroed uint32 (top + one per XCD, each on its own cache line) */
+int dsnt_debug_grid_barrier2(unsigned* counter, int blocks, int threads, int iters, float* out, void* stream);
 int dsnt_debug_empty(int blocks, int threads, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -33,6 +33,17 @@ for threads in (256, 512):
         t = timed(go)
         print('grid barrier: %3d workgroups x %4d threads: %.2f us per barrier (polls by workgroup 0: %.0f per barrier)' % (
             blocks, threads, 1e6 * t / iters, float(out[0]) / iters))
+bar2 = _lib.fn('dsnt_debug_grid_barrier2')
+for blocks in (64, 128, 256):
+    cnt = torch.zeros(16 * 9, dtype=torch.int32, device=dev)
+    def go():
+        cnt.zero_()
+        assert bar2(ptr(cnt), blocks, 256, iters, ptr(out), st) == 0
+    go()
+    torch.cuda.synchronize()
+    assert int(cnt[0].item()) == iters * min(blocks, 8), (int(cnt[0].item()), iters)
+    t = timed(go)
+    print('two-level grid barrier (one counter per XCD): %3d workgroups: %.2f us per barrier' % (blocks, 1e6 * t / iters))
 for blocks, threads in ((1, 64), (8, 1024), (64, 256), (256, 256)):
     n = 2000
     def go():
