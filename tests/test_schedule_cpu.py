@@ -1,0 +1,76 @@
+"""The launch lists of the full-size hg2 train step, traced on the CPU (no kernel is launched: only the engine's list building
+runs, with the device check of `_lib.ptr` bypassed): the SCHEDULE the measurements in DESIGN.md §3 "round 2" rely on —
+which lane carries what, where lanes wait for each other, which launches were fused away."""
+import ctypes as C
+import collections
+
+import pytest
+import torch
+
+
+@pytest.fixture(scope='module')
+def tape(monkeypatch_module):
+    from dsnt import _lib
+    import dsnt.engine as E
+    monkeypatch_module.setattr(_lib, 'ptr', lambda t: C.c_void_p(t.data_ptr()) if t is not None else None)
+    monkeypatch_module.setattr(E._lib, 'ptr', _lib.ptr)
+    from dsnt.model import build_mpii_pose_model
+    from dsnt.hourglass import Arena, Program
+    m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+    m.train()
+    ar = Arena(m.hg, torch.device('cpu'))
+    return Program(m.hg, ar, (32, 3, 256, 256), True, False).tape
+
+
+@pytest.fixture(scope='module')
+def monkeypatch_module():
+    mp = pytest.MonkeyPatch()
+    yield mp
+    mp.undo()
+
+
+def _launches(lst):
+    return [(name, lane, args) for fn, args, name, lane in lst if fn is not None]
+
+
+def test_forward_list_preparation_runs_beside_the_stem(tape):
+    fwd = tape.fwd
+    names = [(e[2], e[3]) for e in fwd]
+    assert names[0] == ('dsnt_fill_zero', 0)                      # the forward's bound slots, before any producer
+    prep = [n for n, lane in names if lane == 1 and n in ('dsnt_split_bf16x3', 'dsnt_f16_prep_weights',
+                                                            'dsnt_f16_prep_bn_bounds', 'dsnt_conv_pack_dgrad_all')]
+    assert prep == ['dsnt_split_bf16x3', 'dsnt_f16_prep_weights', 'dsnt_f16_prep_bn_bounds', 'dsnt_conv_pack_dgrad_all',
+                    'dsnt_f16_prep_weights']
+    # the main lane runs the stem (its own one-launch weight preparation, the space-to-depth image, the convolution, the
+    # BatchNorm + ReLU with statistics) BEFORE it waits for the side lane's preparation
+    first_sync = next(i for i, e in enumerate(fwd) if e[2] == 'sync' and e[1][0] == 1 and e[1][1] == 0)
+    before = [e[2] for e in fwd[:first_sync] if e[3] == 0 and e[0] is not None]
+    assert before[:5] == ['dsnt_fill_zero', 'dsnt_s2d_input', 'dsnt_s2d_weights_prep', 'dsnt_conv_fwd_f16x3_ex', 'dsnt_bn_finalize']
+    assert 'dsnt_bn_act_fwd_stats' in before and before.count('dsnt_conv_fwd_f16x3_ex') == 1
+    assert 'dsnt_nchw_to_nhwc' not in [e[2] for e in fwd]         # the NHWC copy of the image is gone
+    assert {e[3] for e in fwd if e[0] is not None} == {0, 1, 3}     # two side lanes for the skip branches
+
+
+def test_backward_list_lanes_and_fusions(tape):
+    bwd = _launches(tape.bwd)
+    by_lane = collections.Counter(lane for _, lane, _ in bwd)
+    assert set(by_lane) == {0, 1, 2, 3}
+    wg = [(n, lane, a) for n, lane, a in bwd if n in ('dsnt_conv_wgrad_f16x3', 'dsnt_conv_wgrad_bf16x6')]
+    on_lane2 = [x for x in wg if x[1] == 2]
+    assert len(on_lane2) >= 25 and all(x[2][8] == 2 for x in on_lane2)          # DSNT_WGRAD_SHARE_CHIP in `accumulate`
+    assert all(x[2][8] == 0 for x in wg if x[1] != 2)
+    # slab reductions, grouped small weight gradients and the gradient-bucket markers live on the weight-gradient lane
+    assert all(lane == 2 for n, lane, _ in bwd if n in ('dsnt_wgrad_reduce_all', 'dsnt_conv_wgrad_group'))
+    marks = [(e[1], e[3]) for e in tape.bwd if e[0] is None and e[2] == 'bucket']
+    assert marks == [(2, 2), (1, 2), (0, 2)]
+    # every skip branch's gradient is joined inside the pool's backward: accumulate = 1 there, two axpy launches left
+    pools = [a for n, _, a in bwd if n.startswith('dsnt_maxpool2_bwd')]
+    assert len(pools) == 9 and sum(1 for a in pools if a[3] == 1) == 8
+    assert sum(1 for n, _, _ in bwd if n.startswith('dsnt_axpy')) == 2
+    # nothing of the per-step weight preparation is left at the head of the backward list
+    assert [n for n, _, _ in bwd[:3]][0] == 'dsnt_fill_zero' and 'dsnt_conv_pack_dgrad_all' not in [n for n, _, _ in bwd]
+
+
+def test_launch_counts_stay_bounded(tape):
+    nf, nb = len(_launches(tape.fwd)), len(_launches(tape.bwd))
+    assert nf <= 235 and nb <= 400, (nf, nb)
