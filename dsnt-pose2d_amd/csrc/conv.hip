@@ -18,10 +18,11 @@
 // MFMAs of step s (register staging: the A operand needs per-element BN/ReLU/padding).
 #include "common.h"
 #include "bn_tail.h"
+#include "conv_split.h"
+#include "wgrad3.h"
 #include <string.h>
 #include <stdlib.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 32
 #define PITCH 36
@@ -75,36 +76,6 @@ extern "C" int dsnt_debug_set_timeline(long long* buf, int block) {
     return DSNT_OK;
 }
 
-__device__ __forceinline__ void xcd_remap(int bid, int nwg, int& out) {
-    // Blocks are dealt round-robin over the 8 XCDs; give every XCD a contiguous run of
-    // tiles so neighbouring tiles (shared halo rows, shared A rows across n-tiles) meet in
-    // one L2.  Bijective for any nwg (cdna guide §5, "XCD swizzle must be bijective").
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
-    out = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-}
-
-// fp16x3 operand scale (see the fp16x3 notes further down):
-// 2^k with bound * 2^k in [2^13, 2^14)  (bound = m 2^E, 1 <= m < 2  ->  k = 13 - E); zero / tiny bounds are clamped
-__device__ __host__ __forceinline__ float pow2_scale(float bound) {
-    unsigned bits;
-    memcpy(&bits, &bound, 4);
-    int E = (int)((bits & 0x7fffffffu) >> 23) - 127;
-    E = E < -100 ? -100 : (E > 100 ? 100 : E);
-    const unsigned sb = (unsigned)(127 + 13 - E) << 23;
-    float sc;
-    memcpy(&sc, &sb, 4);
-    return sc;
-}
-// A bound lives in DSNT_BOUND_SLOTS floats; its value is their maximum.  Producers that find it with atomics (the
-// BN-backward apply kernel: thousands of workgroups) spread them over the slots by workgroup index: one hot address
-// serialised the read-modify-writes and cost the apply kernel 30 %.
-#define DSNT_BOUND_SLOTS 64
-__device__ __forceinline__ float bound64(const float* __restrict__ p) {
-    float b = p[threadIdx.x & 63];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
-    return b;
-}
 
 // Shared epilogue of the forward / data-gradient kernels (fp32 and bf16x6 variants).
 // HALO: the tile's 128 rows are an 8 x 16 patch of output pixels starting at row `mbase` (row r of the
@@ -602,20 +573,6 @@ __device__ __forceinline__ void split4(const float4 v, uint2& p1, uint2& p2, uin
 // 64x too large costs nothing measurable; overflow would be fatal, underflow only costs absolute error
 // <= 2^-40 * bound).  Bounds live in device memory: BN+ReLU operands from the BN parameters (|gamma| sqrt(M) + |beta|),
 // weights and BN-backward outputs from an amax their producer wrote.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_f16(float lo, float hi) {
-    unsigned r;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-// 4 (already scaled) floats -> two planes of 4 fp16: 3 VALU instructions per element
-__device__ __forceinline__ void split4h(const float4 v, uint2& p1, uint2& p2) {
-    p1.x = pk_f16(v.x, v.y); p1.y = pk_f16(v.z, v.w);
-    const f16x2v a0 = __builtin_bit_cast(f16x2v, p1.x), a1 = __builtin_bit_cast(f16x2v, p1.y);
-    p2.x = pk_f16(v.x - (float)a0.x, v.y - (float)a0.y);
-    p2.y = pk_f16(v.z - (float)a1.x, v.w - (float)a1.y);
-}
 // the MFMAs of one 32x32 accumulator and one 16-wide K step, smallest terms first
 template <bool F16>
 __device__ __forceinline__ void mma_split(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
@@ -2652,8 +2609,43 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
     DSNT_REQUIRE(dsnt_conv_wgrad_bf16x6_ok(g), DSNT_ERR_SHAPE,
                  "dsnt_conv_wgrad_f16x3: geometry not supported (need Wo %% 4 == 0, tensors < 2 GiB)");
     DSNT_REQUIRE(a_bound && g_bound, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: both operand bounds are required");
+    // 3x3 / stride 1 convolutions: the halo kernel (wgrad3.hip) — every operand element staged once for all nine taps
+    const Wg3Plan pl = dsnt_wg3_plan(g);
+    if (pl.ok) {
+        if (int e = check_geom(g, "dsnt_conv_wgrad_f16x3")) return e;
+        DSNT_REQUIRE(x && dy && ws, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: null tensor");
+        DSNT_REQUIRE(dw || !dbias, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: dbias without dw");
+        DSNT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DSNT_ERR_ARG,
+                     "dsnt_conv_wgrad_f16x3: in_scale/in_shift must be given together");
+        DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(dy) && dsnt_aligned16(ws) && (!dw || dsnt_aligned16(dw)),
+                     DSNT_ERR_ALIGN, "dsnt_conv_wgrad_f16x3: tensors must be 16-byte aligned");
+        hipStream_t st = (hipStream_t)stream;
+        dsnt_wg3_launch(pl, x, in_scale, in_shift, in_relu, dy, ws, a_bound, g_bound, g, st);
+        if (dw) {
+            const int CK = g->Cout * 9 * g->Cin;
+            const int total = CK / 4 + (g->Cout + 3) / 4;
+            DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias, pl.nslabs, CK,
+                        g->Cout, accumulate & 1);
+        }
+        DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_f16x3");
+    }
     return conv_wgrad_impl(x, in_scale, in_shift, in_relu, dy, ws, dw, dbias, accumulate, g, stream, true, a_bound, g_bound);
 }
+
+// Plan of dsnt_conv_wgrad_f16x3 (the halo kernel cuts the pixels into its own slabs): number of slabs to reduce and
+// workspace floats; equal to dsnt_conv_wgrad_splits / _ws_floats where the implicit-GEMM kernel runs.
+extern "C" int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g) {
+    if (!g) return 0;
+    const Wg3Plan pl = dsnt_wg3_plan(g);
+    return pl.ok ? pl.nslabs : dsnt_conv_wgrad_splits(g);
+}
+extern "C" int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g) {
+    if (!g) return 0;
+    const Wg3Plan pl = dsnt_wg3_plan(g);
+    if (!pl.ok) return dsnt_conv_wgrad_ws_floats(g);
+    return (int64_t)pl.nslabs * g->Cout * (9 * g->Cin) + (int64_t)pl.nslabs * g->Cout;
+}
+extern "C" int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g) { return g ? dsnt_wg3_plan(g).ok : 0; }
 
 static int conv_wgrad_impl(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                            const float* dy, float* ws, float* dw, float* dbias, int accumulate,

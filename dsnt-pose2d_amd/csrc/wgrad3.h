@@ -1,0 +1,23 @@
+// Internal interface of the halo weight-gradient kernels (wgrad3.hip), used by the dispatch in conv.hip.
+#pragma once
+#include "common.h"
+
+// Plan of one launch: which instantiation, how the pixels are cut into slabs.  ok == 0: geometry not supported.
+struct Wg3Plan {
+    int ok;
+    int cfg;            // 0: 128 output channels per workgroup (9 taps per wave), 1: 64 (taps split over two wave groups)
+    int WS;             // strip width in pixels (16, 32 or 64)
+    int strips;         // W / WS
+    int rps;            // output rows per slab (divides H)
+    int hsplits;        // H / rps
+    int kchunks;        // Cin / 64
+    int nchunks;        // Cout / (128 or 64)
+    int nslabs;         // N * hsplits * strips: slabs ws[nslabs][Cout][K] (+ [nslabs][Cout] bias partials)
+    int blocks;         // workgroups
+    int lds;            // dynamic LDS bytes
+};
+Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g);
+// enqueue (or record) the launch; tensors as dsnt_conv_wgrad_f16x3 (in_scale / in_shift may be null)
+void dsnt_wg3_launch(const Wg3Plan& pl, const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                     const float* dy, float* ws, const float* a_bound, const float* g_bound, const dsnt_conv_geom* g,
+                     hipStream_t st);

@@ -305,6 +305,15 @@ int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, const float* in
 int dsnt_conv_wgrad_desc_f16x3(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                                const float* dy, float* ws, const float* a_bound, const float* g_bound,
                                const dsnt_conv_geom* g, void* desc_out);
+/* 3x3 / stride 1 / pad 1 convolutions with Cin % 64 == 0, Cout % 64 == 0 and W in {16, 32, 64, 128, ...}
+ * (dsnt_conv_wgrad_halo_ok != 0: conv2 of every Bottleneck, /root/reference/src/dsnt/hourglass.py:22-23) run
+ * dsnt_conv_wgrad_f16x3 as a HALO kernel: a workgroup owns 64 input channels x all nine taps x 128 output channels of a
+ * strip of pixel rows, so each operand element is BatchNorm-transformed and split once instead of nine times.  It cuts
+ * the pixels into its own slabs: size `ws` with dsnt_conv_wgrad_f16x3_ws_floats and reduce
+ * dsnt_conv_wgrad_f16x3_splits slabs (both fall back to the plain plan for every other geometry). */
+int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g);
+int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g);
+int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g);
 
 /* ----------------------------------------------------- heat-map matching ("gauss" output strategy)
  * Rows = (image, joint) maps of h x w floats, target = normalised coordinates [rows][2].

@@ -509,6 +509,76 @@ def test_wgrad_f16x3(case, pro):
     assert (db16.cpu().double() - b.grad).abs().max().item() <= 3e-5 * b.grad.abs().max().item()
 
 
+HALO_CASES = [
+    # N, H, W, Cin, Cout: 3x3 / stride 1 / pad 1 shapes of the halo weight gradient (csrc/wgrad3.hip)
+    (2, 64, 64, 128, 128),     # the dominant shape: 64 channels x 9 taps x 128 columns per workgroup, W = 64
+    (1, 32, 32, 128, 128),     # W = 32
+    (2, 16, 16, 128, 256),     # W = 16, two 128-column chunks
+    (2, 32, 32, 256, 128),     # four 64-channel chunks
+    (2, 16, 16, 64, 64),       # 64 output channels: taps split over two wave groups
+    (1, 128, 128, 64, 64),     # the stem Bottleneck: two 64-pixel strips with real halo columns
+    (1, 128, 64, 64, 128),     # H != W
+    (3, 8, 16, 64, 128),       # H = 8: a slab is a whole image
+]
+
+
+@pytest.mark.parametrize('case', HALO_CASES)
+@pytest.mark.parametrize('pro,relu', [(True, 1), (True, 0), (False, 0)])
+def test_wgrad_halo_f16x3(case, pro, relu):
+    """The halo weight gradient (every 3x3 Bottleneck conv2, hourglass.py:22-23) vs fp64 autograd, same bars as
+    test_wgrad_f16x3, and its slab plan: dsnt_conv_wgrad_f16x3_splits slabs reduced by dsnt_wgrad_reduce_all equal
+    the reduction inside the call bit for bit."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    N, H, W, Cin, Cout = case
+    dev = torch.device('cuda:0')
+    tag = 'h' + '_'.join(map(str, case))
+    g = _geom(N, H, W, Cin, Cout, 3, 3, 1, 1, 1)
+    assert _lib.fn('dsnt_conv_wgrad_halo_ok')(C.byref(g)) == 1
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=1)
+    sc = synthetic.tensor(tag + 's', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'h', (Cin,), seed=1, scale=0.3)
+    act = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) if pro else x
+    act = (F.relu(act) if relu else act).double()
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(act, w, b, padding=1)
+    gy = synthetic.tensor(tag + 'g', tuple(y.shape), seed=2) * 1e-4
+    y.backward(gy.double())
+    xd, gyd, scd, shd = _nhwc(x).to(dev), _nhwc(gy).to(dev), sc.to(dev), sh.to(dev)
+    ab, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ab.fill_(act.abs().max().item() * 16.0)
+    call('dsnt_amax', ptr(gyd), gyd.numel(), ptr(gb))
+    nws = _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g))
+    splits = _lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g))
+    assert nws == splits * Cout * (9 * Cin + 1)
+    ws = torch.full((nws,), float('nan'), device=dev)
+    dw16, dw32 = torch.empty(Cout, 3, 3, Cin, device=dev), torch.empty(Cout, 3, 3, Cin, device=dev)
+    db16, db32 = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+    args = (ptr(xd), ptr(scd) if pro else None, ptr(shd) if pro else None, relu, ptr(gyd))
+    call('dsnt_conv_wgrad_f16x3', *args, ptr(ws), ptr(dw16), ptr(db16), 0, ptr(ab), ptr(gb), C.byref(g))
+    assert bool(torch.isfinite(ws).all()), 'a slab element was never written'
+    ws32 = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev)
+    call('dsnt_conv_wgrad', *args, ptr(ws32), ptr(dw32), ptr(db32), 0, C.byref(g))
+    ref = w.grad.permute(0, 2, 3, 1)
+    scale = ref.abs().max().item()
+    e16 = (dw16.cpu().double() - ref).abs().max().item()
+    e32 = (dw32.cpu().double() - ref).abs().max().item()
+    assert e16 <= 3e-5 * scale and e16 <= max(4 * e32, 2e-6 * scale), (e16, e32)
+    assert (db16.cpu().double() - b.grad).abs().max().item() <= 3e-5 * b.grad.abs().max().item()
+    # slabs only + the table-driven reduction: the same bits; accumulate adds
+    ws2 = torch.empty(nws, device=dev)
+    dw2, db2 = torch.zeros_like(dw16), torch.zeros_like(db16)
+    call('dsnt_conv_wgrad_f16x3', *args, ptr(ws2), None, None, 0, ptr(ab), ptr(gb), C.byref(g))
+    assert torch.equal(ws, ws2)
+    table = torch.tensor([[ws2.data_ptr(), dw2.data_ptr(), db2.data_ptr(), splits, Cout * 9 * Cin, Cout, 0]],
+                         dtype=torch.int64).to(dev)
+    call('dsnt_wgrad_reduce_all', ptr(table), 1, (Cout * 9 * Cin // 4 + (Cout + 3) // 4 + 63) // 64)
+    assert torch.equal(dw2, dw16) and torch.equal(db2, db16)
+    call('dsnt_conv_wgrad_f16x3', *args, ptr(ws), ptr(dw16), ptr(db16), 1, ptr(ab), ptr(gb), C.byref(g))
+    assert (dw16.cpu().double() - 2 * ref).abs().max().item() <= 6e-5 * scale
+
+
 def test_f16x3_preparation_launches():
     """The per-step table-driven launches of the fp16x3 path: weight planes + bounds of several tensors at once equal
     the single-tensor entry points; the BatchNorm bound is max_c(|gamma_c| sqrt(M) + |beta_c|) in all 64 slots; the
