@@ -2620,7 +2620,8 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
         DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(dy) && dsnt_aligned16(ws) && (!dw || dsnt_aligned16(dw)),
                      DSNT_ERR_ALIGN, "dsnt_conv_wgrad_f16x3: tensors must be 16-byte aligned");
         hipStream_t st = (hipStream_t)stream;
-        dsnt_wg3_launch(pl, x, in_scale, in_shift, in_relu, dy, ws, a_bound, g_bound, g, st);
+        dsnt_wg3_launch(pl, x, in_scale, in_shift, in_relu, dy, ws, a_bound, g_bound, g, st,
+                        (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
         if (dw) {
             const int CK = g->Cout * 9 * g->Cin;
             const int total = CK / 4 + (g->Cout + 3) / 4;

@@ -5,7 +5,9 @@
 // Plan of one launch: which instantiation, how the pixels are cut into slabs.  ok == 0: geometry not supported.
 struct Wg3Plan {
     int ok;
-    int cfg;            // 0: 128 output channels per workgroup (9 taps per wave), 1: 64 (taps split over two wave groups)
+    int cfg;            // 0: 64 x 128 channels per workgroup (9 taps per wave), 1: 64 x 64 (taps split over two wave
+                        // groups); a cfg-0 launch that SHARES the chip runs as 32 x 128 four-wave workgroups instead
+                        // (same slabs: twice the channel chunks)
     int WS;             // strip width in pixels (16, 32 or 64)
     int strips;         // W / WS
     int rps;            // output rows per slab (divides H)
@@ -17,7 +19,8 @@ struct Wg3Plan {
     int lds;            // dynamic LDS bytes
 };
 Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g);
-// enqueue (or record) the launch; tensors as dsnt_conv_wgrad_f16x3 (in_scale / in_shift may be null)
+// enqueue (or record) the launch; tensors as dsnt_conv_wgrad_f16x3 (in_scale / in_shift may be null); share =
+// DSNT_WGRAD_SHARE_CHIP: the launch runs beside a dependency chain on another stream
 void dsnt_wg3_launch(const Wg3Plan& pl, const float* x, const float* in_scale, const float* in_shift, int in_relu,
                      const float* dy, float* ws, const float* a_bound, const float* g_bound, const dsnt_conv_geom* g,
-                     hipStream_t st);
+                     hipStream_t st, bool share);

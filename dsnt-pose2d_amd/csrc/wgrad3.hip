@@ -45,7 +45,7 @@ __device__ __forceinline__ f16x8 wg3_tr_frag(WG3_LDS unsigned char* base, int of
     return __builtin_bit_cast(f16x8, v);
 }
 
-template <int KC, int NT, int WS, int TAP0, int NTAPS>
+template <int KC, int NT, int WS, int TAP0, int NTAPS, int STAGE_AT>
 __device__ __forceinline__ void wg3_body(const Wg3P& p, unsigned char* smem, const int kc, const int nt,
                                          const bool first_group) {
     constexpr int GS = WS / 16;                       // 16-pixel steps per row
@@ -54,7 +54,8 @@ __device__ __forceinline__ void wg3_body(const Wg3P& p, unsigned char* smem, con
     constexpr int PLSZ = KC * SUBSZ;                  // one plane of one slot
     constexpr int SLOTSZ = 2 * PLSZ;                  // two planes
     constexpr int UNITS = WS * 8 * KC;                // float4 units of one input row
-    constexpr int NPASS = (UNITS + 511) / 512;
+    constexpr int NTH = 64 * KC * NT * (NTAPS == 9 ? 1 : 2);   // threads of the workgroup
+    constexpr int NPASS = (UNITS + NTH - 1) / NTH;
     const unsigned OOB = 0xF0000000u;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -84,7 +85,7 @@ __device__ __forceinline__ void wg3_body(const Wg3P& p, unsigned char* smem, con
     float4 sc[NPASS], sh[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-        const int u = tid + 512 * i;
+        const int u = tid + NTH * i;
         act[i] = u < UNITS;
         const int sub = (u / (WS * 8)) % KC, px = (u >> 3) & (WS - 1), ch4 = u & 7;
         const int c = c0 + 32 * sub + 4 * ch4;
@@ -184,7 +185,7 @@ __device__ __forceinline__ void wg3_body(const Wg3P& p, unsigned char* smem, con
 
     // ---- prologue: zero pixels (whole-width strips), input rows oh0-1, oh0, oh0+1 into their slots
     if (!halo_cols) {
-        for (int u = tid; u < 4 * 2 * KC * 2 * 8; u += 512) {
+        for (int u = tid; u < 4 * 2 * KC * 2 * 8; u += NTH) {
             const int e = u & 7, side = (u >> 3) & 1, rest = u >> 4;          // rest = (slot, plane, sub)
             *reinterpret_cast<uint2*>(smem + rest * SUBSZ + (side ? (WS + 1) * 64 : 0) + e * 8) = make_uint2(0u, 0u);
         }
@@ -202,15 +203,19 @@ __device__ __forceinline__ void wg3_body(const Wg3P& p, unsigned char* smem, con
 
     for (int t = 0; t < p.rps; ++t) {
         const int oh = oh0 + t;
-        // input row oh+2 (loaded during the previous row) -> slot of row oh+2; start the loads of row oh+3
-        if (t + 1 < p.rps) store(RA, (oh + 3) & 3);
-        issue(RA, t + 2 < p.rps ? oh + 3 : -8);
         // filter row r reads input row oh-1+r = slot (oh + r) & 3
         WG3_LDS unsigned char* ab[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) ab[r] = lds0 + (lane_a + (unsigned)(((oh + r) & 3) * SLOTSZ));
 #pragma unroll
         for (int g = 0; g < GS; ++g) {
+            // input row oh+2 (loaded during the previous row) -> slot of row oh+2; start the loads of row oh+3.
+            // Waves 0..3 do this at the head of the row, waves 4..7 (their partners on the four SIMDs) in the middle:
+            // the halves then run half a step apart and one's VALU work meets the other's MFMAs (STAGE_AT)
+            if (g == STAGE_AT) {
+                if (t + 1 < p.rps) store(RA, (oh + 3) & 3);
+                issue(RA, t + 2 < p.rps ? oh + 3 : -8);
+            }
             // dY of this step: scale, split into two fp16 planes (element j = pixel 8 lh + j: the MFMA's k order).
             // (only matrix instructions and LDS reads may cross into the previous step: hipcc otherwise hoists these
             // multiplies — and with them the wait for loads issued a moment ago — up under the previous step's MFMAs)
@@ -218,10 +223,10 @@ __device__ __forceinline__ void wg3_body(const Wg3P& p, unsigned char* smem, con
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = Graw[j] * sg;
-            // bias partial: sum of the SCALED values (exact, unscaled at the end); every wave keeps it — a branch here
-            // would cut the row into basic blocks and hand the placement of the loads below back to hipcc
+            // bias partial; every wave keeps it — a branch here would cut the row into basic blocks and hand the
+            // placement of the loads below back to hipcc
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bsum += v[j];
+            for (int j = 0; j < 8; ++j) bsum += Graw[j];
             wg3_u32x4 h1, h2;
             {
                 uint2 a, b, c, d;
@@ -265,31 +270,44 @@ __device__ __forceinline__ void wg3_body(const Wg3P& p, unsigned char* smem, con
     // bias partial of this slab: column sums of dY (first channel chunk, first tap group only)
     if (first_group && kch == 0) {
         bsum += __shfl_xor(bsum, 32, 64);
-        if (lh == 0) p.ws[(size_t)p.nslabs * p.Cout * p.K + (size_t)slab * p.Cout + n] = bsum * (1.f / sg);
+        if (lh == 0) p.ws[(size_t)p.nslabs * p.Cout * p.K + (size_t)slab * p.Cout + n] = bsum;
     }
 }
 
 // CFG 0: 64 input channels x 128 output channels per workgroup, wave = (kc, nt), nine taps each;
-// CFG 1: 64 x 64, wave = (kc, nt, tap group): taps 0..4 / 5..8
+// CFG 1: 64 x 64, wave = (kc, nt, tap group): taps 0..4 / 5..8;
+// CFG 2: 32 x 128 with FOUR waves (wave = nt): half the registers of a CU, so that a launch beside a dependency chain
+//        on another stream (DSNT_WGRAD_SHARE_CHIP) leaves room for the chain's kernels on every CU
 template <int CFG, int WS>
-__global__ __launch_bounds__(512, 2) void wgrad3_kernel(Wg3P p) {
+__global__ __launch_bounds__(CFG == 2 ? 256 : 512, 2) void wgrad3_kernel(Wg3P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wg3_smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef WG3_NO_STAGGER                  // A/B: both halves stage at the head of the row
+    constexpr int MID = 0;
+#else
+    constexpr int MID = WS / 32;       // half a row of 16-pixel steps
+#endif
     if (CFG == 0) {
-        wg3_body<2, 4, WS, 0, 9>(p, wg3_smem, wave & 1, wave >> 1, (wave & 1) == 0);
-    } else {
+        if (wave < 4) wg3_body<2, 4, WS, 0, 9, 0>(p, wg3_smem, wave & 1, wave >> 1, (wave & 1) == 0);
+        else wg3_body<2, 4, WS, 0, 9, MID>(p, wg3_smem, wave & 1, wave >> 1, (wave & 1) == 0);
+    } else if (CFG == 1) {
         const int kc = wave & 1, nt = (wave >> 1) & 1;
-        if ((wave >> 2) == 0) wg3_body<2, 2, WS, 0, 5>(p, wg3_smem, kc, nt, kc == 0);
-        else wg3_body<2, 2, WS, 5, 4>(p, wg3_smem, kc, nt, false);
+        if ((wave >> 2) == 0) wg3_body<2, 2, WS, 0, 5, 0>(p, wg3_smem, kc, nt, kc == 0);
+        else wg3_body<2, 2, WS, 5, 4, MID>(p, wg3_smem, kc, nt, false);
+    } else {
+        wg3_body<1, 4, WS, 0, 9, 0>(p, wg3_smem, 0, wave, true);
     }
 }
+
+static int enabled = -1, min_steps = 0, small_wg = 1;
 
 Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g) {
     Wg3Plan pl;
     memset(&pl, 0, sizeof(pl));
-    static int enabled = -1, min_steps = 0;
     static long target = 0;
     if (enabled < 0) {
+        const char* c = getenv("DSNT_WG3_SMALL");          // four-wave workgroups for shared launches (A/B: 0 = never)
+        small_wg = (c && c[0] == '0') ? 0 : 1;
         const char* e = getenv("DSNT_WGRAD3");
         enabled = (e && e[0] == '0') ? 0 : 1;
         const char* m = getenv("DSNT_WG3_MINSTEPS");
@@ -309,7 +327,7 @@ Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g) {
     pl.WS = WS;
     pl.strips = g->W / WS;
     pl.kchunks = g->Cin / 64;
-    pl.nchunks = g->Cout / (pl.cfg == 0 ? 128 : 64);
+    pl.nchunks = g->Cout / (pl.cfg == 1 ? 64 : 128);
     // rows per slab: halve (while it stays a divisor of H) until the launch has `target` workgroups, but keep at least
     // `min_steps` 16-pixel steps per workgroup: every workgroup pays a three-row prologue and writes a whole slab
     int rps = g->H;
@@ -326,17 +344,22 @@ Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g) {
 
 template <int CFG, int WS>
 static void wg3_launch_cfg(const Wg3Plan& pl, const Wg3P& p, hipStream_t st) {
+    // CFG 2 (a launch that shares the chip): more than half of the LDS keeps it to ONE four-wave workgroup per CU —
+    // half of every CU's registers stay free for the dependency chain's kernels on the other streams
+    const int share_lds = 84 * 1024;
+    const int lds = CFG == 2 ? share_lds : pl.lds;
+    const int blocks = CFG == 2 ? 2 * pl.blocks : pl.blocks;       // 32 instead of 64 input channels per workgroup
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)wgrad3_kernel<CFG, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds);
+        hipFuncSetAttribute((const void*)wgrad3_kernel<CFG, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    DSNT_LAUNCH((wgrad3_kernel<CFG, WS>), dim3(pl.blocks), dim3(512), pl.lds, st, p);
+    DSNT_LAUNCH((wgrad3_kernel<CFG, WS>), dim3(blocks), dim3(CFG == 2 ? 256 : 512), lds, st, p);
 }
 
 void dsnt_wg3_launch(const Wg3Plan& pl, const float* x, const float* in_scale, const float* in_shift, int in_relu,
                      const float* dy, float* ws, const float* a_bound, const float* g_bound, const dsnt_conv_geom* g,
-                     hipStream_t st) {
+                     hipStream_t st, bool share) {
     Wg3P p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.dy = dy; p.ws = ws;
@@ -344,13 +367,16 @@ void dsnt_wg3_launch(const Wg3Plan& pl, const float* x, const float* in_scale, c
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Cout = g->Cout; p.K = 9 * g->Cin;
     p.strips = pl.strips; p.rps = pl.rps; p.hsplits = pl.hsplits; p.kchunks = pl.kchunks; p.nchunks = pl.nchunks;
     p.nslabs = pl.nslabs;
-    if (pl.cfg == 0) {
-        if (pl.WS == 64) wg3_launch_cfg<0, 64>(pl, p, st);
-        else if (pl.WS == 32) wg3_launch_cfg<0, 32>(pl, p, st);
-        else wg3_launch_cfg<0, 16>(pl, p, st);
-    } else {
-        if (pl.WS == 64) wg3_launch_cfg<1, 64>(pl, p, st);
-        else if (pl.WS == 32) wg3_launch_cfg<1, 32>(pl, p, st);
-        else wg3_launch_cfg<1, 16>(pl, p, st);
-    }
+    const bool small = share && small_wg && pl.cfg == 0;
+    if (small) p.kchunks = 2 * pl.kchunks;
+#define WG3_PICK(CFG)                                                   \
+    do {                                                                \
+        if (pl.WS == 64) wg3_launch_cfg<CFG, 64>(pl, p, st);            \
+        else if (pl.WS == 32) wg3_launch_cfg<CFG, 32>(pl, p, st);       \
+        else wg3_launch_cfg<CFG, 16>(pl, p, st);                        \
+    } while (0)
+    if (small) WG3_PICK(2);
+    else if (pl.cfg == 0) WG3_PICK(0);
+    else WG3_PICK(1);
+#undef WG3_PICK
 }

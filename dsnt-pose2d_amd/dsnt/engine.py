@@ -813,7 +813,6 @@ class Tape:
             share = 2 if (wl != cur and self.wgrad_share) else 0      # DSNT_WGRAD_SHARE_CHIP: one workgroup per CU beside the chain
             w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
             if self.defer_reduce:
-                ws = self.empty(nws)         # lives until the bucket's reduction
                 # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
                 # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
                 grouped = (w6 and normed and res1 is None and res2 is None and wl == cur and
@@ -821,6 +820,12 @@ class Tape:
                 # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
                 w16 = w6 and self.use_f16x3 and (normed or x_amax is not None) and y.grad_amax is not None
                 ab = (self.f16_bn_bound_bwd(src) if normed else x_amax) if w16 else None
+                splits = self.lib.dsnt_conv_wgrad_splits(C.byref(g))
+                if w16 and not grouped:
+                    # dsnt_conv_wgrad_f16x3 cuts the pixels of a 3x3 convolution into its own slabs (halo kernel)
+                    nws = self.lib.dsnt_conv_wgrad_f16x3_ws_floats(C.byref(g))
+                    splits = self.lib.dsnt_conv_wgrad_f16x3_splits(C.byref(g))
+                ws = self.empty(nws)         # lives until the bucket's reduction
                 if grouped:
                     desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
                     if w16:
@@ -846,8 +851,7 @@ class Tape:
                 if p.post_reduce is not None:
                     self._post_reduce.append(p.post_reduce)
                 self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
-                                             self.lib.dsnt_conv_wgrad_splits(C.byref(g)), p.Cout * g.R * g.S * g.Cin,
-                                             p.Cout, 0])
+                                             splits, p.Cout * g.R * g.S * g.Cin, p.Cout, 0])
             else:
                 ws = self.scratch('wgrad', nws)
                 self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,

@@ -34,13 +34,26 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.guard = guard          # dsnt.guard.NanGuard: the update is skipped while its device flag is up
         self.runner = _find_arena(model)
         arena = self.runner.arena
-        arena_params = {id(p) for _, p, _, _ in arena.slots}
-        self.extra = [p for p in model.parameters() if id(p) not in arena_params]
-        super().__init__([p for _, p, _, _ in arena.slots] + self.extra, defaults)
+        arena_names = {id(p): name for name, p, _, _ in arena.slots}
+        self.extra = [p for p in model.parameters() if id(p) not in arena_names]
+        # Parameter indices of param_groups / state_dict follow model.parameters() — the order a stock
+        # torch.optim.RMSprop(model.parameters()) (bin/train.py:314-326) numbers them in — NOT the arena's slot order
+        # (bucket by bucket: stem, stack 0, stack 1, ...), so that a checkpointed optimiser state lands on the same
+        # parameters on either side.  _where[i] = ('arena', slot name) or ('extra', index into self.extra).
+        extra_idx = {id(p): j for j, p in enumerate(self.extra)}
+        ordered = list(model.parameters())
+        self._where = [('arena', arena_names[id(p)]) if id(p) in arena_names else ('extra', extra_idx[id(p)])
+                       for p in ordered]
+        assert len({id(p) for p in ordered}) == len(arena.slots) + len(self.extra), 'arena holds a parameter the model does not'
+        super().__init__(ordered, defaults)
         self.grad_scale = 1.0
         self._steps = 0
         self.flat_state = torch.zeros_like(arena.params)
         self.extra_state = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.extra]
+
+    def _state_tensor(self, i):
+        kind, key = self._where[i]
+        return self.runner.arena.logical(self.flat_state, key) if kind == 'arena' else self.extra_state[key]
 
     def _gather_grads(self):
         arena = self.runner.arena
@@ -55,15 +68,11 @@ class _FlatOptimizer(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------ torch-format state
     def state_dict(self):
-        arena = self.runner.arena
-        n_arena = len(arena.slots)
         step = torch.tensor(float(self._steps))
         state = {}
         if self._has_state():
-            for i, (name, p, o, n) in enumerate(arena.slots):
-                state[i] = self._entry(arena.logical(self.flat_state, name).clone(), step)
-            for j, s in enumerate(self.extra_state):
-                state[n_arena + j] = self._entry(s.clone(), step)
+            for i in range(len(self._where)):
+                state[i] = self._entry(self._state_tensor(i).clone(), step)
         groups = []
         for g in self.param_groups:
             pg = {k: v for k, v in g.items() if k != 'params'}
@@ -72,31 +81,26 @@ class _FlatOptimizer(torch.optim.Optimizer):
         return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, state_dict):
-        arena = self.runner.arena
-        n_arena = len(arena.slots)
         groups = state_dict['param_groups']
-        if len(groups) != 1 or len(groups[0]['params']) != n_arena + len(self.extra):
+        if len(groups) != 1 or len(groups[0]['params']) != len(self._where):
             raise ValueError('dsnt.optim: loaded state dict has a different number of parameters')
         for k, v in groups[0].items():
             if k != 'params':
                 self.param_groups[0][k] = v
         st = state_dict['state']
         steps = 0
-        for i, (name, p, o, n) in enumerate(arena.slots):
+        for i in range(len(self._where)):
             e = st.get(i, st.get(str(i)))
-            dst = arena.logical(self.flat_state, name)
+            dst = self._state_tensor(i)
             if e is None or e.get(self.STATE_KEY) is None:
                 dst.zero_()
                 continue
-            dst.copy_(e[self.STATE_KEY].to(dst.device, dst.dtype))
+            src = e[self.STATE_KEY]
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError('dsnt.optim: state of parameter %d has shape %s, the parameter %s' %
+                                 (i, tuple(src.shape), tuple(dst.shape)))
+            dst.copy_(src.to(dst.device, dst.dtype))
             steps = max(steps, int(float(e.get('step', 1))))
-        for j, s in enumerate(self.extra_state):
-            e = st.get(n_arena + j, st.get(str(n_arena + j)))
-            if e is None or e.get(self.STATE_KEY) is None:
-                s.zero_()
-            else:
-                s.copy_(e[self.STATE_KEY].to(s.device, s.dtype))
-                steps = max(steps, int(float(e.get('step', 1))))
         self._steps = steps
 
 

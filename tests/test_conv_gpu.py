@@ -571,6 +571,11 @@ def test_wgrad_halo_f16x3(case, pro, relu):
     dw2, db2 = torch.zeros_like(dw16), torch.zeros_like(db16)
     call('dsnt_conv_wgrad_f16x3', *args, ptr(ws2), None, None, 0, ptr(ab), ptr(gb), C.byref(g))
     assert torch.equal(ws, ws2)
+    # DSNT_WGRAD_SHARE_CHIP (bit 1): four-wave workgroups of 32 input channels that leave half of every CU to the
+    # other streams — the same slabs, bit for bit
+    ws3 = torch.full((nws,), float('nan'), device=dev)
+    call('dsnt_conv_wgrad_f16x3', *args, ptr(ws3), None, None, 2, ptr(ab), ptr(gb), C.byref(g))
+    assert torch.equal(ws, ws3)
     table = torch.tensor([[ws2.data_ptr(), dw2.data_ptr(), db2.data_ptr(), splits, Cout * 9 * Cin, Cout, 0]],
                          dtype=torch.int64).to(dev)
     call('dsnt_wgrad_reduce_all', ptr(table), 1, (Cout * 9 * Cin // 4 + (Cout + 3) // 4 + 63) // 64)

@@ -311,6 +311,69 @@ def test_ten_optimiser_steps_vs_oracle(mfma_path, kind):
     assert torch.equal(m.hg.arena.params, after)
 
 
+def test_optimiser_state_interoperates_with_torch_optim_on_hg2():
+    """The flat optimiser's state_dict numbers parameters as torch.optim.RMSprop(model.parameters()) would (train.py:314-326,
+    364, 492).  hg2's arena is ordered bucket by bucket (stem, stack 0, stack 1) while model.parameters() runs
+    hg.*, res.*, fc.*, score.*, ...: after three steps the state loads into a stock RMSprop over the same parameters
+    with every square_avg on its own parameter, one more step of either optimiser gives the same weights, and the
+    stock optimiser's state loads back."""
+    from dsnt.model import build_mpii_pose_model
+    from dsnt import optim
+    m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(m, seed=8)
+    m.cuda().train()
+    x, target, mask = synthetic.batch(2, size=64, seed=4, mask_p=0.9)
+    xd, td, kd = x.to(DEV), target.to(DEV), mask.to(DEV)
+    m.hg._runner().ensure(torch.device(DEV))
+    arena = m.hg.arena
+    params = list(m.parameters())
+    arena_order = [id(p) for _, p, _, _ in arena.slots]
+    assert arena_order != [id(p) for p in params], 'hg2: arena order and model.parameters() order should differ'
+    opt = optim.RMSprop(m, lr=2.5e-4)
+    assert [id(p) for p in opt.param_groups[0]['params']] == [id(p) for p in params]
+
+    def backward():
+        out = m(xd)
+        loss = m.forward_loss(out, td, kd)
+        opt.zero_grad()
+        loss.backward()
+    for _ in range(3):
+        backward()
+        opt.step()
+    sd = opt.state_dict()
+    assert len(sd['state']) == len(params)
+    # every entry has its parameter's shape and equals the arena's state of THAT parameter
+    by_id = {id(p): name for name, p, _, _ in arena.slots}
+    for i, p in enumerate(params):
+        sq = sd['state'][i]['square_avg']
+        assert tuple(sq.shape) == tuple(p.shape), (i, sq.shape, p.shape)
+        assert torch.equal(sq, arena.logical(opt.flat_state, by_id[id(p)]))
+    stock = torch.optim.RMSprop(params, lr=2.5e-4)
+    stock.load_state_dict(sd)
+    for i, p in enumerate(params):
+        assert torch.equal(stock.state[p]['square_avg'], sd['state'][i]['square_avg'])
+    # one more step with the same gradients: stock optimiser vs the flat one
+    backward()
+    before = arena.params.clone()
+    grads = arena.grads.clone()
+    opt.step()
+    flat_after = arena.params.clone()
+    arena.params.copy_(before)
+    arena.grads.copy_(grads)
+    stock.step()
+    assert (arena.params - flat_after).abs().max().item() <= 1e-6 * flat_after.abs().max().item()
+    # and back: the stock optimiser's checkpoint resumes in the flat one
+    sd2 = stock.state_dict()
+    opt2 = optim.RMSprop(m, lr=1.0)
+    opt2.load_state_dict(sd2)
+    for i, p in enumerate(params):
+        assert torch.equal(arena.logical(opt2.flat_state, by_id[id(p)]), sd2['state'][i]['square_avg'])
+    assert opt2.param_groups[0]['lr'] == 2.5e-4
+    bad = {'state': {0: {'step': torch.tensor(1.0), 'square_avg': torch.zeros(3)}}, 'param_groups': sd['param_groups']}
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(bad)
+
+
 def test_data_parallel_world1_nccl():
     """`parallel.DataParallel` on the GPU (world size 1, RCCL): the bucket markers of the traced backward list fire in
     backward-completion order for hourglass AND ResNet models, attaching changes no gradient bit, and the 1/world
