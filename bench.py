@@ -13,9 +13,13 @@ For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... be
 fixed (32; hg8: 16) as N grows.  `--global-batch G` fixes the TOTAL batch instead (per-GPU batch G / N,
 "scaling": "strong") — north_star quotes efficiency at global batch 256: `--global-batch 256` at N = 1 and 8.
 Besides the whole-job throughput the line carries
-  roofline     — the dominant kernel (3x3 128->128 implicit-GEMM conv at 64x64, the shape that
-                 holds ~half of the backbone FLOPs) timed live with HIP events on its stream:
-                 algorithmic FLOPs / launch time vs the 157.3 TFLOP/s fp32-MFMA peak;
+  roofline     — the dominant kernel (3x3 128->128 halo convolution at 64x64, the shape that holds ~half of the
+                 backbone FLOPs) timed live with HIP events on its stream: algorithmic FLOPs / launch time vs the
+                 split-precision MFMA peak; `roofline.by_time`: the step's largest kernel families (weight gradients,
+                 1x1 GEMM, 3x3 halo, BatchNorm-backward apply), each timed the same way with its algorithmic FLOPs AND
+                 bytes against whichever bound applies;
+  step_bounds  — the whole step against its two floors: GFLOP/step / the split-precision MFMA peak and the
+                 launch lists' algorithmic bytes / the 6.29 TB/s copy peak;
   cpu_baseline — the CPU oracle (plain PyTorch ops, proven equal to the reference) timed on this
                  node's host cores on a bounded sample of the same workload (rank 0, N = 1): thread-count
                  sweep, then 2 warm-up + 5 timed steps at the best count;
@@ -132,6 +136,99 @@ def dominant_kernel_roofline(batch, iters=20):
     return out
 
 
+HBM_PEAK, HBM_COPY_PEAK = 8000.0, 6290.0      # GB/s: spec and measured float4 copy (MI355X_MICROARCH.md)
+
+
+def family_rooflines(batch, iters=20):
+    """The step's largest kernel families at their 64x64 shapes, each timed alone with HIP events on its stream:
+    algorithmic FLOPs and bytes per launch, and the fraction of the bound that applies (MFMA: 2500 TFLOP/s / 3 fp16
+    MFMAs per product; HBM: 8.0 TB/s spec, the 6.29 TB/s copy peak beside it).  `share_of_step` comes from the
+    serialised kernel profile committed under profiles/ (what each family costs when it has the chip to itself)."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, ConvGeom
+    dev = torch.device('cuda', torch.cuda.current_device())
+    st = torch.cuda.current_stream().cuda_stream
+    H, M = 64, batch * 64 * 64
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3          # us
+
+    def entry(kernel, us, flops, nbytes, bound, note=None):
+        tf, gbs = flops / us / 1e6, nbytes / us / 1e3
+        e = {'kernel': kernel, 'us_per_launch': round(us, 1), 'flops_per_launch': flops, 'bytes_per_launch': nbytes,
+             'tflops': round(tf, 1), 'gbs': round(gbs, 1), 'bound': bound}
+        if bound == 'mfma':
+            e.update(peak=round(PEAK_BF16_MFMA / 3.0, 1), unit='TFLOP/s', frac=round(tf / (PEAK_BF16_MFMA / 3.0), 4))
+        else:
+            e.update(peak=HBM_PEAK, unit='GB/s', frac=round(gbs / HBM_PEAK, 4), frac_of_copy_peak=round(gbs / HBM_COPY_PEAK, 4))
+        if note:
+            e['note'] = note
+        return e
+
+    def bounds(*ts):
+        out = []
+        for t in ts:
+            b = torch.zeros(64, device=dev)
+            assert _lib.fn('dsnt_amax')(ptr(t), t.numel(), ptr(b), st) == 0
+            out.append(b)
+        return out
+
+    res = []
+    sc128, sh128 = torch.rand(128, device=dev) + 0.5, torch.randn(128, device=dev) * 0.1
+    x128 = torch.randn(batch, H, H, 128, device=dev)
+    g128 = torch.randn(batch, H, H, 128, device=dev) * 1e-3
+    g256 = torch.randn(batch, H, H, 256, device=dev) * 1e-3
+    ab = torch.full((64,), float(torch.relu(x128 * sc128 + sh128).max()) * 4.0, device=dev)
+    gb128, gb256 = bounds(g128, g256)
+    # -- weight gradients (hourglass.py:22-25 backward): 3x3 128->128 (halo kernel) and 1x1 128->256
+    wg = _lib.fn('dsnt_conv_wgrad_f16x3')
+    for k, cout, gy, gb in ((3, 128, g128, gb128), (1, 256, g256, gb256)):
+        g = ConvGeom(batch, H, H, 128, H, H, cout, k, k, 1, k // 2, 1)
+        ws = torch.empty(_lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g)), device=dev)
+        us = timed(lambda: wg(ptr(x128), ptr(sc128), ptr(sh128), 1, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb),
+                              C.byref(g), st))
+        flops = 2.0 * M * k * k * 128 * cout
+        nbytes = 4.0 * (M * 128 + M * cout + k * k * 128 * cout)
+        res.append(entry('weight gradient %dx%d 128->%d @64x64 B=%d (fp16x3%s), slabs only' %
+                         (k, k, cout, batch, ', halo kernel' if k == 3 else ''), us, flops, nbytes,
+                         'mfma' if k == 3 else 'hbm',
+                         'plus %.1f MB of split-M slabs written per launch (workspace, reduced once per parameter bucket)'
+                         % (ws.numel() * 4 / 1e6)))
+        del ws
+    # -- 1x1 GEMM: the expanding conv3 of a Bottleneck, BN+ReLU prologue, residual add, statistics epilogue
+    g = ConvGeom(batch, H, H, 128, H, H, 256, 1, 1, 1, 0, 1)
+    w = torch.randn(256, 1, 1, 128, device=dev) * 0.05
+    planes16 = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+    wb, = bounds(w)
+    assert _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(planes16), w.numel(), w.numel(), ptr(wb), st) == 0
+    y = torch.empty(batch, H, H, 256, device=dev)
+    bias = torch.zeros(256, device=dev)
+    stats = torch.empty((M + 127) // 128, 2, 256, device=dev)
+    fwd = _lib.fn('dsnt_conv_fwd_f16x3_ex')
+    us = timed(lambda: fwd(ptr(x128), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(bias), ptr(y), ptr(sc128), ptr(sh128),
+                           1, ptr(g256), None, ptr(stats), C.byref(g), None, None, st))
+    res.append(entry('1x1 GEMM 128->256 @64x64 B=%d (fp16x3, BN+ReLU prologue, residual add, statistics)' % batch, us,
+                     2.0 * M * 128 * 256, 4.0 * (M * 128 + 2 * M * 256), 'hbm'))
+    # -- BatchNorm-backward apply (hourglass.py:36-43 backward): dx = f(dz, x), 12 B per element
+    dz, dx = g128, torch.empty_like(g128)
+    mean, invstd, coef = torch.zeros(128, device=dev), torch.ones(128, device=dev), torch.zeros(256, device=dev)
+    amax = torch.zeros(64, device=dev)
+    ap = _lib.fn('dsnt_bn_act_bwd_apply_amax')
+    us = timed(lambda: ap(ptr(dz), ptr(x128), ptr(sc128), ptr(sh128), ptr(mean), ptr(invstd), ptr(coef), 0, ptr(dx), 0,
+                          M, 128, ptr(amax), st))
+    res.append(entry('bn_act_bwd_apply 128 channels @64x64 B=%d (with the fp16x3 bound of its output)' % batch, us,
+                     8.0 * M * 128, 12.0 * M * 128, 'hbm'))
+    return res
+
+
 def _host_cpus():
     """(usable logical CPUs, physical cores among them, model string) of this process's CPU share."""
     usable = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
@@ -166,8 +263,8 @@ def _host_cpus():
 
 def cpu_baseline(base, reg, batch=8, timed=5, warm=2):
     """The CPU oracle on the same workload at a bounded batch (images/sec on the host cores).  BASELINE.md §3:
-    physical-core count and CPU model stated, 2 warm-up + >= 5 timed steps, median; the thread count is swept first
-    (1 warm-up + 1 timed step each) because an oversubscribed intra-op pool is several times slower."""
+    physical-core count and CPU model stated, 2 warm-up + >= 5 timed steps, median; on more than 16 logical CPUs the
+    thread count is swept first (an oversubscribed intra-op pool is several times slower)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     from dsnt_oracle import model as omodel
     from dsnt import synthetic
@@ -188,25 +285,35 @@ def cpu_baseline(base, reg, batch=8, timed=5, warm=2):
         return time.perf_counter() - t0
 
     saved = torch.get_num_threads()
-    cands = sorted({n for n in (8, 16, 32, 64, physical, logical) if 1 <= n <= logical})
-    sweep = {}
-    for n in cands:
-        torch.set_num_threads(n)
-        step()
-        sweep[n] = step()
-    best_n = min(sweep, key=sweep.get)
+    # A GPU box hands this process <= 16 logical CPUs: every one of them is used and there is nothing to sweep (the
+    # round-2 sweep compared 8 with 16 threads on first-touch steps, i.e. it measured warm-up).  On a larger share the
+    # thread count is swept with TWO warm-up steps per candidate before its timed one.
+    sweep, cands = {}, [logical]
+    if logical > 16:
+        cands = sorted({n for n in (16, 32, 64, physical, logical) if 1 <= n <= logical})
+        for n in cands:
+            torch.set_num_threads(n)
+            step()
+            step()
+            sweep[n] = step()
+    best_n = min(sweep, key=sweep.get) if sweep else logical
     torch.set_num_threads(best_n)
     for _ in range(warm):
         step()
     times = sorted(step() for _ in range(timed))
     torch.set_num_threads(saved)
     med = times[len(times) // 2]
-    return {'value': round(batch / med, 3), 'unit': 'images/sec', 'cores': best_n, 'kind': 'port',
-            'physical_cores': physical, 'logical_cpus': logical, 'cpu_model': cpu_model,
-            'thread_sweep_images_per_sec': {str(n): round(batch / v, 3) for n, v in sweep.items()},
-            'sample': '%s+dsnt reg=%s, batch %d, 256x256, RMSprop train step; thread sweep %s (1 warm-up + 1 timed '
-                      'each), then %d warm-up + %d timed steps at %d threads (median); torch %s CPU ops'
-                      % (base, reg, batch, cands, warm, timed, best_n, torch.__version__)}
+    out = {'value': round(batch / med, 3), 'unit': 'images/sec', 'cores': best_n, 'kind': 'port',
+           'physical_cores': physical, 'logical_cpus': logical, 'cpu_model': cpu_model,
+           'spread_images_per_sec': [round(batch / times[-1], 3), round(batch / times[0], 3)],
+           'sample': '%s+dsnt reg=%s, batch %d, 256x256, RMSprop train step; %s; %d warm-up + %d timed steps at %d '
+                     'threads (median); torch %s CPU ops'
+                     % (base, reg, batch, ('thread sweep %s (2 warm-up + 1 timed each)' % cands) if sweep else
+                        'all %d logical CPUs of this process (no sweep at <= 16)' % logical, warm, timed, best_n,
+                        torch.__version__)}
+    if sweep:
+        out['thread_sweep_images_per_sec'] = {str(n): round(batch / v, 3) for n, v in sweep.items()}
+    return out
 
 
 def parity_vs_oracle(model, base, reg, batch=4):
@@ -446,8 +553,24 @@ def main():
             'final_loss': final_loss,
             'step_mfma_frac': round(ips / world * gflop * 1e9 / (PEAK_F32_MFMA * 1e12), 4),
         }
+        # the step against its two floors (per GPU): arithmetic at the split-precision MFMA peak the convolutions run
+        # on (2500 TFLOP/s dense fp16 / 3 MFMAs per fp32 product), and the launch lists' algorithmic bytes (every
+        # tensor a launch names is read or written once; weight-gradient slabs excluded; + 16 B/parameter for the
+        # optimiser) at the measured 6.29 TB/s copy peak
+        tape = prog.tape
+        nparam = sum(p.numel() for p in model.parameters())
+        step_bytes = tape.bytes_fwd + tape.bytes_bwd + 16 * nparam
+        mfma_ms = batch * gflop * 1e9 / (PEAK_BF16_MFMA / 3.0 * 1e12) * 1e3
+        hbm_ms = step_bytes / (HBM_COPY_PEAK * 1e9) * 1e3
+        ms_step = 1e3 * elapsed / args.steps
+        out['step_bounds'] = {'gflop_per_step': round(batch * gflop, 1), 'mfma_peak_tflops': round(PEAK_BF16_MFMA / 3.0, 1),
+                              'mfma_ms': round(mfma_ms, 3), 'algorithmic_gbytes_per_step': round(step_bytes / 1e9, 2),
+                              'hbm_peak_gbs': HBM_COPY_PEAK, 'hbm_ms': round(hbm_ms, 3),
+                              'frac_of_max_bound': round(max(mfma_ms, hbm_ms) / ms_step, 4),
+                              'frac_of_sum_of_bounds': round((mfma_ms + hbm_ms) / ms_step, 4)}
         if not args.no_extras:
             out['roofline'] = dominant_kernel_roofline(batch)
+            out['roofline']['by_time'] = family_rooflines(batch)
             out['head_roofline'] = head_roofline()
             if hasattr(model, 'hg'):
                 out['parity'] = parity_vs_oracle(model, base, reg)

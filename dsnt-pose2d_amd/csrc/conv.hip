@@ -20,6 +20,7 @@
 #include "bn_tail.h"
 #include "conv_split.h"
 #include "wgrad3.h"
+#include "gemm1.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -27,24 +28,6 @@
 #define BK 32
 #define PITCH 36
 
-struct ConvP {
-    const float* x; const float* w; const float* bias; float* y;
-    const float* in_scale; const float* in_shift;
-    const float* res1; const float* res2; float* stats;
-    const unsigned short* wq;      // bf16x6 path: plane 0 of the weights; planes are `wq_stride` elements apart
-    long wq_stride;
-    // optional batch-norm-backward epilogue (data-gradient launches): y = dz = acc * [bn(x) > 0],
-    // stats = per-tile (sum dz, sum dz*xhat); the BN input x is passed through res1
-    const float* bnb_scale; const float* bnb_shift; const float* bnb_mean; const float* bnb_invstd;
-    int bnb_relu;
-    int in_relu;
-    // fp16x3 path: device scalars >= max|A operand| and max|weights| (null on the other paths)
-    const float* a_bound; const float* w_bound;
-    int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil;
-    int M, K, mtiles, ntiles;
-    // optional: the launch's last workgroup finishes the BatchNorm bookkeeping over `stats` (bn_tail.h)
-    BnTailP tail;
-};
 
 // Debug timeline (normally null): when set through dsnt_debug_set_timeline, lane 0 of every wave
 // of workgroup `g_dbg_block` stamps s_memtime at chosen points: dbg[wave*128 + slot].
@@ -1452,6 +1435,11 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     DSNT_REQUIRE(!((p.tail.amax || p.tail.amax_bn) && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
     p.a_bound = a_bound; p.w_bound = w_bound;
     if (a_bound) {                   // fp16x3: two fp16 weight planes, operand bounds in device memory
+        const int ntw = dsnt_gemm1_cfg(p);      // large 1x1 convolutions: the streaming kernel (gemm1.hip)
+        if (ntw > 0) {
+            dsnt_gemm1_launch(p, ntw, in_scale != nullptr, st);
+            DSNT_CHECK_LAUNCH("dsnt_conv_fwd_f16x3");
+        }
         if (conv3x3_halo_ok(g) && !g_force_gemm6) {
             if (BN == 128) launch_conv3x3_6<2, true>(p, in_scale != nullptr, st);
             else launch_conv3x3_6<1, true>(p, in_scale != nullptr, st);

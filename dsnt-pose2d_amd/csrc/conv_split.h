@@ -2,6 +2,7 @@
 // fp16x3 operand scale / 64-slot bounds and the exact two-plane fp16 split.  Device code only (gfx950).
 #pragma once
 #include "common.h"
+#include "bn_tail.h"
 #include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -51,3 +52,23 @@ __device__ __forceinline__ void split4h(const float4 v, uint2& p1, uint2& p2) {
     p2.x = pk_f16(v.x - (float)a0.x, v.y - (float)a0.y);
     p2.y = pk_f16(v.z - (float)a1.x, v.w - (float)a1.y);
 }
+
+// Kernel arguments of the forward / data-gradient convolution kernels (conv.hip, gemm1.hip)
+struct ConvP {
+    const float* x; const float* w; const float* bias; float* y;
+    const float* in_scale; const float* in_shift;
+    const float* res1; const float* res2; float* stats;
+    const unsigned short* wq;      // bf16x6 path: plane 0 of the weights; planes are `wq_stride` elements apart
+    long wq_stride;
+    // optional batch-norm-backward epilogue (data-gradient launches): y = dz = acc * [bn(x) > 0],
+    // stats = per-tile (sum dz, sum dz*xhat); the BN input x is passed through res1
+    const float* bnb_scale; const float* bnb_shift; const float* bnb_mean; const float* bnb_invstd;
+    int bnb_relu;
+    int in_relu;
+    // fp16x3 path: device scalars >= max|A operand| and max|weights| (null on the other paths)
+    const float* a_bound; const float* w_bound;
+    int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil;
+    int M, K, mtiles, ntiles;
+    // optional: the launch's last workgroup finishes the BatchNorm bookkeeping over `stats` (bn_tail.h)
+    BnTailP tail;
+};

@@ -381,6 +381,47 @@ __global__ __launch_bounds__(HB) void reg_bwd_kernel(const float* __restrict__ h
     });
 }
 
+// d(reg row)/d(mu_t): the reference builds its target as make_gauss(mu_t, ...) inside autograd (nn.py:219-271), so
+// kl / js / mse are differentiable in the target means.  With D_i = d div / d q_i (the divergence's derivative in the
+// TARGET pixel) this is make_gauss's backward with G = D, composed in registers: one read of the heat-map, nothing
+// materialised.   d/d mu_x = (sum_i D_i q_i dx_i - (sum_j q_j dx_j)(sum_i D_i q_i)) / sigma^2
+template <int VEC, bool CACHED>
+__global__ __launch_bounds__(HB) void reg_bwd_mu_kernel(const float* __restrict__ hm, const float* __restrict__ target,
+                                                         const float* __restrict__ g_row, float* __restrict__ gmu,
+                                                         int h, int w, float k, int kind) {
+    __shared__ float red[32];
+    const int hw = h * w;
+    Row<VEC, CACHED> row;
+    row.load(hm + (size_t)blockIdx.x * hw, hw);
+    const Grid2 g(h, w);
+    const float tx = target[2 * (size_t)blockIdx.x], ty = target[2 * (size_t)blockIdx.x + 1];
+    const RegCtx c = reg_context(row, g, tx, ty, k, kind, red);
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // sum D q, sum D q dx, sum D q dy, sum q dx, sum q dy
+    row.each([&](int i, float p) {
+        float x, y; g.xy(i, x, y);
+        const float dx = x - tx, dy = y - ty;
+        const float q = expf((dx * dx + dy * dy) * k) / c.z;
+        float D;
+        if (kind == 0) {
+            const float m = 0.5f * (p + q);
+            D = 0.5f * (logf(q + REG_EPS) - logf(m + REG_EPS) + q / (q + REG_EPS) - m / (m + REG_EPS));
+        } else if (kind == 1) {
+            D = -p / (q + REG_EPS);
+        } else {
+            D = -2.f * (p - q);
+        }
+        const float dq = D * q;
+        s[0] += dq; s[1] = fmaf(dq, dx, s[1]); s[2] = fmaf(dq, dy, s[2]);
+        s[3] = fmaf(q, dx, s[3]); s[4] = fmaf(q, dy, s[4]);
+    });
+    block_sum<5>(s, red);
+    if (threadIdx.x == 0) {
+        const float f = g_row[blockIdx.x] * (-2.f * k);          // upstream gradient / sigma^2
+        gmu[2 * (size_t)blockIdx.x] = (s[1] - s[3] * s[0]) * f;
+        gmu[2 * (size_t)blockIdx.x + 1] = (s[2] - s[4] * s[0]) * f;
+    }
+}
+
 // ------------------------------------------------------------------ euclid / masked average
 __global__ void euclid_fwd_kernel(const float* __restrict__ a, const float* __restrict__ t, float* __restrict__ dist,
                                   long n, int d) {
@@ -814,6 +855,16 @@ extern "C" int dsnt_reg_bwd(const float* hm, const float* target, const float* g
     ROW_DISPATCH(reg_bwd_kernel, (int)rows, h * w, dsnt_aligned16(hm), hm, target, g_row, ghm, h, w, sigma,
                  gauss_k(sigma), kind);
     DSNT_CHECK_LAUNCH("dsnt_reg_bwd");
+}
+
+extern "C" int dsnt_reg_bwd_mu(const float* hm, const float* target, const float* g_row, float* gmu, int64_t rows,
+                               int h, int w, float sigma, int kind, void* stream) {
+    DSNT_REQUIRE(hm && g_row && gmu && target, DSNT_ERR_ARG, "dsnt_reg_bwd_mu: null tensor");
+    DSNT_REQUIRE(kind >= 0 && kind <= 2, DSNT_ERR_ARG, "dsnt_reg_bwd_mu: kind %d has no target Gaussian", kind);
+    if (int e = check_rows("dsnt_reg_bwd_mu", rows, h, w)) return e;
+    ROW_DISPATCH(reg_bwd_mu_kernel, (int)rows, h * w, dsnt_aligned16(hm), hm, target, g_row, gmu, h, w,
+                 gauss_k(sigma), kind);
+    DSNT_CHECK_LAUNCH("dsnt_reg_bwd_mu");
 }
 
 extern "C" int dsnt_euclid_fwd(const float* actual, const float* target, float* dist, int64_t n, int d,

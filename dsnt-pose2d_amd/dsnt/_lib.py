@@ -63,6 +63,7 @@ SIGNATURES = {
     'dsnt_fc2_bwd': [P, P, P, P, P, P, L, I, P],
     'dsnt_reg_fwd': [P, P, P, L, I, I, F, I, P],
     'dsnt_reg_bwd': [P, P, P, P, L, I, I, F, I, P],
+    'dsnt_reg_bwd_mu': [P, P, P, P, L, I, I, F, I, P],
     'dsnt_euclid_fwd': [P, P, P, L, I, P],
     'dsnt_euclid_bwd': [P, P, P, P, P, L, I, P],
     'dsnt_masked_avg_fwd': [P, P, P, L, P],

@@ -90,6 +90,7 @@ class Tape:
         self._keep = []         # keeps ctypes structs / tensors alive
         self.lib = _lib.load()
         self.nbytes = 0
+        self.bytes_fwd, self.bytes_bwd, self.bytes_by_name, self._ws_ptrs = 0, 0, {}, set()
         # fp32-accurate split-bf16 matrix-core path for the large convolutions (DSNT_MFMA=f32 disables)
         self.use_bf16x6 = os.environ.get('DSNT_MFMA', 'bf16x6') != 'f32'
         self.bf16x6_min_rows = int(os.environ.get('DSNT_BF16X6_MIN_ROWS', '16384'))
@@ -369,6 +370,15 @@ class Tape:
         conv = []
         for a in args:
             if isinstance(a, torch.Tensor):
+                # algorithmic HBM bytes of the step (bench.py `step_bounds`): every tensor a launch names is read or
+                # written once by it; weight-gradient slabs (workspace, not algorithm) are left out
+                if a.data_ptr() not in self._ws_ptrs:
+                    nb = a.numel() * a.element_size()
+                    self.bytes_by_name[name] = self.bytes_by_name.get(name, 0) + nb
+                    if lst is self.fwd:
+                        self.bytes_fwd += nb
+                    else:
+                        self.bytes_bwd += nb
                 conv.append(_lib.ptr(a))
             elif isinstance(a, (ConvGeom, BnBwdEpilogue, BnTail)):
                 self._keep.append(a)
@@ -629,6 +639,7 @@ class Tape:
             acc = 0
         elif a.grad.data_ptr() in self._wgrad_lane_reads:
             self._wgrad_lane_reads.discard(a.grad.data_ptr())
+            self.release_wgrads()                            # a held-back launch that reads it must be on the list first
             self.sync_bwd(self.wgrad_lane, self.lane)        # a weight gradient on its own lane still reads this buffer
         if self.use_f16x3 and amax and (self.amax_all or (amax == 'apply' and acc == 0)):
             if a.grad_amax is None:
@@ -826,6 +837,7 @@ class Tape:
                     nws = self.lib.dsnt_conv_wgrad_f16x3_ws_floats(C.byref(g))
                     splits = self.lib.dsnt_conv_wgrad_f16x3_splits(C.byref(g))
                 ws = self.empty(nws)         # lives until the bucket's reduction
+                self._ws_ptrs.add(ws.data_ptr())
                 if grouped:
                     desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
                     if w16:
@@ -856,6 +868,8 @@ class Tape:
                 ws = self.scratch('wgrad', nws)
                 self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
                        p.gw, p.gb, 0, g)
+                if p.post_reduce is not None:      # the stem's space-to-depth gradient -> the parameter's 7x7 layout
+                    self.b(p.post_reduce[0], *p.post_reduce[1])
             self.lane = cur
             if hold:
                 self.bwd = listed

@@ -5,10 +5,14 @@ on NaN dumps weights, optimiser state and inputs to `model_dump.pth` and raises
 (`/root/reference/src/dsnt/bin/train.py:360-371`).  Here the check is a device-side flag:
 
 * `check(loss)` enqueues a one-launch test of the loss scalar (any tensor works) that raises bit DSNT_FLAG_LOSS;
-* an optimiser built with `guard=` (dsnt.optim) skips the whole update while the flag is up — the weights stay the
-  last finite ones, which is what the reference's dump captures by raising before `optimizer.step()` — and raises
-  DSNT_FLAG_GRAD itself for gradient elements that are not finite (e.g. an fp16x3 operand bound that was too
-  small would surface as inf here);
+* an optimiser built with `guard=` (dsnt.optim) skips the WHOLE update (arena and out-of-arena parameters) while the
+  loss flag is up: after a non-finite loss the weights and optimiser state are those before the step — what the
+  reference's dump captures by raising before `optimizer.step()`;
+* a non-finite GRADIENT behind a finite loss (e.g. an fp16x3 operand bound that was too small would surface as inf in
+  one weight gradient) is handled element-wise: the update kernels skip exactly the non-finite elements and raise
+  DSNT_FLAG_GRAD; every finite element IS updated from that backward pass.  (The reference has no such check at all:
+  torch.optim would write the NaN into the weights.)  So after this error the weights are finite but they are NOT the
+  pre-step weights; from the next step on the raised flag blocks every update until `reset()`;
 * `poll()` reads the flag asynchronously: a non-blocking copy into pinned host memory whose event is examined on
   the NEXT poll, so a bad step is reported one step late and a good step never waits.  `sync()` is the blocking
   form (end of an epoch, tests).
@@ -46,8 +50,11 @@ class NanGuard:
             what.append('non-finite loss')
         if (v[0] | v[1]) & FLAG_GRAD:
             what.append('non-finite gradient')
-        raise NonFiniteError('dsnt: %s detected on the device; the optimiser skipped the update, the weights are the '
-                             'last finite ones (train.py:360-371 dumps them here)' % ' and '.join(what))
+        how = ('the optimiser skipped that whole update: weights and optimiser state are the pre-step ones '
+               '(train.py:360-371 dumps them here)' if v[0] & FLAG_LOSS else
+               'the optimiser skipped exactly the non-finite elements (every other element was updated) and updates '
+               'nothing further until reset()')
+        raise NonFiniteError('dsnt: %s detected on the device; %s' % (' and '.join(what), how))
 
     def poll(self):
         """Non-blocking: raise if an EARLIER poll's copy of the flag has landed and is non-zero."""

@@ -287,19 +287,27 @@ class _RegRows(Function):
         call('dsnt_reg_fwd', ptr(hm), ptr(mu), ptr(out), rows, h, w, float(sigma_t), kind)
         ctx.save_for_backward(hm, mu)
         ctx.sigma, ctx.kind = float(sigma_t), kind
+        ctx.mu_shape = tuple(mu_t.shape) if torch.is_tensor(mu_t) else None
         return out
 
     @staticmethod
     def backward(ctx, g):
         hm, mu = ctx.saved_tensors
+        g = f32(g).contiguous()
+        rows, h, w = _rows(hm, 2), hm.shape[-2], hm.shape[-1]
+        ghm = gmu = None
+        if ctx.needs_input_grad[0]:
+            ghm = torch.empty_like(hm)
+            call('dsnt_reg_bwd', ptr(hm), ptr(mu), ptr(g), ptr(ghm), rows, h, w, ctx.sigma, ctx.kind)
         if ctx.needs_input_grad[1]:
-            raise NotImplementedError(
-                'dsnt.nn: the fused regularisers treat the target means as constants (train.py never asks for their '
-                'gradient); for d/d mu_t compose dsnt.nn.make_gauss (differentiable) with _js_2d / _kl_2d')
-        ghm = torch.empty_like(hm)
-        call('dsnt_reg_bwd', ptr(hm), ptr(mu), ptr(g.contiguous()), ptr(ghm), _rows(hm, 2),
-             hm.shape[-2], hm.shape[-1], ctx.sigma, ctx.kind)
-        return ghm, None, None, None
+            # the reference's target is make_gauss(mu_t) inside autograd (nn.py:219-271): differentiable in mu_t
+            if ctx.kind == 3:                       # the variance regulariser never reads mu_t
+                gmu = torch.zeros(ctx.mu_shape, device=hm.device, dtype=hm.dtype)
+            else:
+                gmu = torch.empty_like(mu)
+                call('dsnt_reg_bwd_mu', ptr(hm), ptr(mu), ptr(g), ptr(gmu), rows, h, w, ctx.sigma, ctx.kind)
+                gmu = gmu.sum_to_size(ctx.mu_shape)  # mu_t may have been broadcast over leading dimensions
+        return ghm, gmu, None, None
 
 
 def kl_reg_loss(heatmaps, mu_t, sigma_t, mask=None):

@@ -51,6 +51,13 @@ class _FlatOptimizer(torch.optim.Optimizer):
         self.flat_state = torch.zeros_like(arena.params)
         self.extra_state = [torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.extra]
 
+    def _extra_keep(self, gr):
+        """Element mask of an out-of-arena update under the guard (device-side, no host read): all False while the loss
+        flag is up, False where the gradient is not finite — those also raise FLAG_GRAD, as the arena kernels do."""
+        finite = torch.isfinite(gr)
+        self.guard.flag[1:2].bitwise_or_((~finite).any().to(torch.int32) * 2)
+        return finite & (self.guard.flag[0] == 0)
+
     def _state_tensor(self, i):
         kind, key = self._where[i]
         return self.runner.arena.logical(self.flat_state, key) if kind == 'arena' else self.extra_state[key]
@@ -139,6 +146,11 @@ class RMSprop(_FlatOptimizer):
             gr = p.grad * self.grad_scale
             if g['weight_decay'] != 0:
                 gr = gr.add(p, alpha=g['weight_decay'])
+            if self.guard is not None:                       # as the guarded arena kernel: nothing while the loss flag is
+                keep = self._extra_keep(gr)                  # up, non-finite gradient elements skipped (and flagged)
+                sq.copy_(torch.where(keep, g['alpha'] * sq + (1 - g['alpha']) * gr * gr, sq))
+                p.sub_(torch.where(keep, g['lr'] * gr / (sq.sqrt() + g['eps']), torch.zeros_like(gr)))
+                continue
             sq.mul_(g['alpha']).addcmul_(gr, gr, value=1 - g['alpha'])
             p.addcdiv_(gr, sq.sqrt().add_(g['eps']), value=-g['lr'])
         self._steps += 1
@@ -185,11 +197,10 @@ class SGD(_FlatOptimizer):
             gr = p.grad * self.grad_scale
             if g['weight_decay'] != 0:
                 gr = gr.add(p, alpha=g['weight_decay'])
+            keep = self._extra_keep(gr) if self.guard is not None else None
             if g['momentum'] != 0:
-                if first:
-                    buf.copy_(gr)
-                else:
-                    buf.mul_(g['momentum']).add_(gr)
+                nb = gr if first else g['momentum'] * buf + gr
+                buf.copy_(nb if keep is None else torch.where(keep, nb, buf))
                 gr = buf
-            p.add_(gr, alpha=-g['lr'])
+            p.sub_(g['lr'] * gr if keep is None else torch.where(keep, g['lr'] * gr, torch.zeros_like(gr)))
         self._steps += 1

@@ -109,6 +109,11 @@ int dsnt_reg_fwd(const float* hm, const float* target, float* per_row, int64_t r
 /* ghm[row] = g_row[row] * d(per_row)/d(hm). */
 int dsnt_reg_bwd(const float* hm, const float* target, const float* g_row, float* ghm,
                  int64_t rows, int h, int w, float sigma, int kind, void* stream);
+/* gmu[row][2] = g_row[row] * d(per_row)/d(target[row]) for kind 0..2: the reference's target Gaussian is
+ * make_gauss(mu_t, ...) inside autograd (/root/reference/src/dsnt/nn.py:219-271), so its regularisers are differentiable
+ * in the target means; the derivative through the target pixel is composed with make_gauss's backward in registers. */
+int dsnt_reg_bwd_mu(const float* hm, const float* target, const float* g_row, float* gmu,
+                    int64_t rows, int h, int w, float sigma, int kind, void* stream);
 
 /* nn.py:97-116 `euclidean_loss` (per-point part): dist[i] = ||a_i - t_i||_2, d dims. */
 int dsnt_euclid_fwd(const float* actual, const float* target, float* dist, int64_t n, int d,

@@ -262,6 +262,13 @@ BF16X6_CASES = [c for c in CASES if c[3] % 16 == 0 and c[4] % 4 == 0] + [
     (1, 24, 48, 32, 160, 3, 1, 1, 1),    # ragged Cout (second N tile masked), two chunks
     (3, 16, 16, 96, 128, 3, 1, 1, 1),    # six chunks
     (1, 8, 16, 32, 128, 3, 1, 1, 1),     # a single tile: every halo edge is padding
+    # 1x1 convolutions of >= 65536 rows run on the streaming kernel (csrc/gemm1.hip) when both fp16x3 bounds exist
+    (16, 64, 64, 128, 256, 1, 1, 0, 1),  # expanding conv3 of a Bottleneck: 256 columns per workgroup
+    (16, 64, 64, 256, 128, 1, 1, 0, 1),  # reducing conv1: K = 256
+    (16, 64, 64, 128, 128, 1, 1, 0, 1),  # 128 columns, two row tiles per wave
+    (16, 64, 64, 256, 256, 1, 1, 0, 1),  # lin / fc_: two column chunks
+    (4, 128, 128, 64, 64, 1, 1, 0, 1),   # stem Bottleneck: K = 64, four row tiles per wave
+    (4, 128, 128, 64, 128, 1, 1, 0, 1),
 ]
 
 
@@ -639,6 +646,8 @@ BNB_CASES = [
     (4, 64, 64, 128, 256, 1),     # expanding 1x1: data gradient 256 -> 128
     (2, 8, 8, 128, 128, 3),       # 128 rows: the K-split kernel on the fp32 path
     (2, 16, 16, 128, 128, 3),     # 512 rows: 32x128 tiles / K-split
+    (16, 64, 64, 256, 128, 1),    # 65536 rows: the streaming 1x1 kernel (fp16x3 path), data gradient 128 -> 256
+    (16, 64, 64, 128, 256, 1),    # ... 256 -> 128
 ]
 
 
@@ -850,8 +859,9 @@ def test_bn_tail_forward_matches_the_finalize_launch(kind):
 
 
 @pytest.mark.parametrize('path', ['f32', 'bf16x6', 'f16x3'])
-@pytest.mark.parametrize('k,with_res', [(1, True), (3, False)])
-def test_epilogue_leaves_the_bound_of_its_output(path, k, with_res):
+@pytest.mark.parametrize('k,with_res,N', [(1, True, 2), (3, False, 2), (1, True, 64)],
+                         ids=['k1_res', 'k3', 'k1_res_65536rows'])
+def test_epilogue_leaves_the_bound_of_its_output(path, k, with_res, N):
     """dsnt_bn_tail.amax: the launch raises a 64-slot bound to max|y| of what it wrote (bias and residual included) —
     the fp16x3 operand bound of a consumer that reads y raw (skip projections / `lin` convolutions,
     hourglass.py:45-48,120-135).  Exactly the maximum (a max is order-independent), never lowered, and a second
@@ -860,7 +870,7 @@ def test_epilogue_leaves_the_bound_of_its_output(path, k, with_res):
     from dsnt._lib import ptr, call, ConvGeom, BnTail
     dev = torch.device('cuda:0')
     torch.manual_seed(1234)
-    N, H, Cin, Cout = 2, 32, 64, 128
+    H, Cin, Cout = 32, 64, 128           # N = 64: 65536 rows, the streaming 1x1 kernel on the fp16x3 path
     g = ConvGeom(N, H, H, Cin, H, H, Cout, k, k, 1, k // 2, 1)
     x = torch.randn(N, H, H, Cin, device=dev)
     w = torch.randn(Cout, k, k, Cin, device=dev) * 0.1

@@ -123,9 +123,45 @@ def test_make_gauss_grad_vs_oracle(dev, h, w, sigma):
     gd, go = md2.grad.cpu().double().flatten(), mo2.grad.flatten()
     assert torch.isfinite(gd).all()
     assert float(gd @ go / (gd.norm() * go.norm())) > 1 - 1e-6
-    with pytest.raises(NotImplementedError, match='constants'):
-        md3 = mu.to(dev).requires_grad_()
-        dn.js_reg_loss(p.to(dev), md3, sigma).backward()
+
+
+@pytest.mark.parametrize('reg', ['js', 'kl', 'mse', 'var'])
+@pytest.mark.parametrize('h,w,sigma', [(64, 64, 2 / 64), (5, 5, 0.4), (12, 20, 0.15)])
+def test_reg_losses_are_differentiable_in_the_target_means(dev, reg, h, w, sigma):
+    """The reference builds the target Gaussian with make_gauss(mu_t) inside autograd (nn.py:219-271): kl / js / mse are
+    differentiable in mu_t (and in the heat-maps at the same time); `var` never reads mu_t.  HIP (fused: the
+    divergence's derivative in the target pixel composed with make_gauss's backward, `dsnt_reg_bwd_mu`) vs the oracle's
+    fp64 autograd, with a mask, with mu_t broadcast over the batch, bar 2e-5 of the gradient scale (KL: its 1/q
+    amplifies the fp32 rounding of the Gaussian's far tail — direction and scale are held instead)."""
+    import dsnt.nn as dn
+    from dsnt_oracle import nn as onn
+    fn = {'js': 'js_reg_loss', 'kl': 'kl_reg_loss', 'mse': 'mse_reg_loss', 'var': 'variance_reg_loss'}[reg]
+    p = torch.softmax(synthetic.tensor('rm.p', (3, 16, h * w), seed=11) * 2.0, -1).view(3, 16, h, w)
+    mu = synthetic.tensor('rm.mu', (3, 16, 2), seed=11, kind='uniform') * 0.8
+    mask = (synthetic.tensor('rm.m', (3, 16), seed=11, kind='uniform') > 0.3).float()
+    for mu0, use_mask in ((mu, True), (mu[:1], False)):            # second: one set of means for the whole batch
+        pd, md = p.to(dev).requires_grad_(), mu0.to(dev).requires_grad_()
+        loss = getattr(dn, fn)(pd, md, sigma, mask.to(dev) if use_mask else None)
+        po, mo = p.double().requires_grad_(), mu0.double().requires_grad_()
+        loss_o = getattr(onn, fn)(po, mo, sigma, mask.double() if use_mask else None)
+        assert abs(loss.item() - loss_o.item()) <= 2e-5 * max(1.0, abs(loss_o.item()))
+        if reg == 'var':
+            loss.backward()
+            loss_o.backward()
+            assert md.grad is not None and float(md.grad.abs().max()) == 0.0 and tuple(md.grad.shape) == tuple(mu0.shape)
+            assert mo.grad is None or float(mo.grad.abs().max()) == 0.0
+            continue
+        loss.backward()
+        loss_o.backward()
+        assert tuple(md.grad.shape) == tuple(mu0.shape)
+        gd, go = md.grad.cpu().double().flatten(), mo.grad.flatten()
+        assert torch.isfinite(gd).all()
+        if reg == 'kl':
+            assert float(gd @ go / (gd.norm() * go.norm())) > 1 - 1e-6 and abs(float(gd.norm() / go.norm()) - 1) < 1e-3
+        else:
+            assert (gd - go).abs().max() <= 2e-5 * float(go.abs().max()), (reg, (gd - go).abs().max(), go.abs().max())
+        ph, pho = pd.grad.cpu().double(), po.grad
+        assert (ph - pho).abs().max() <= 2e-5 * float(pho.abs().max())
 
 
 def test_ops_vs_oracle_and_golden(dev):

@@ -50,7 +50,8 @@ def test_blocks(kind):
         assert abs(p.grad.double().norm().item() - want) <= 1e-4 * max(1.0, want), n
 
 
-@pytest.mark.parametrize('base,size,reg,tag', [('hg1', 128, 'none', 'hg1_128'), ('hg2', 128, 'js', 'hg2_128')])
+@pytest.mark.parametrize('base,size,reg,tag', [('hg1', 128, 'none', 'hg1_128'), ('hg2', 128, 'js', 'hg2_128'),
+                                               ('hg8', 128, 'js', 'hg8_128')])
 def test_end_to_end(base, size, reg, tag):
     g = gu.load(tag)
     m = omodel.build_mpii_pose_model(base=base, output_strat='dsnt', reg=reg)
