@@ -192,7 +192,7 @@ def family_rooflines(batch, iters=20):
     wg = _lib.fn('dsnt_conv_wgrad_f16x3')
     for k, cout, gy, gb in ((3, 128, g128, gb128), (1, 256, g256, gb256)):
         g = ConvGeom(batch, H, H, 128, H, H, cout, k, k, 1, k // 2, 1)
-        ws = torch.empty(_lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g)), device=dev)
+        ws = torch.empty(_lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 0), device=dev)
         us = timed(lambda: wg(ptr(x128), ptr(sc128), ptr(sh128), 1, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb),
                               C.byref(g), st))
         flops = 2.0 * M * k * k * 128 * cout

@@ -2481,8 +2481,10 @@ static void wgrad_plan(const dsnt_conv_geom* g, int& ktiles, int& ntiles, int& s
     ktiles = (K + 127) / 128;
     ntiles = (g->Cout + 127) / 128;
     static long target = -1;                  // DSNT_WGRAD_WGS: workgroups aimed at per launch (tuning switch)
-    if (target < 0) { const char* e = getenv("DSNT_WGRAD_WGS"); target = e ? atol(e) : 512; }
-    long want = target / (ktiles * ntiles);   // ~2 workgroups per CU; more only inflates the slabs
+    // one workgroup per CU: these launches run at one workgroup per CU beside the dependency chain anyway
+    // (DSNT_WGRAD_SHARE_CHIP), and half as many splits are half the slab traffic (512: +0.2 ms per hg2 step)
+    if (target < 0) { const char* e = getenv("DSNT_WGRAD_WGS"); target = e ? atol(e) : 256; }
+    long want = target / (ktiles * ntiles);
     if (want < 1) want = 1;
     long max_splits = (M + 255) / 256;         // at least 8 steps of 32 rows per split
     if (max_splits < 1) max_splits = 1;
@@ -2598,7 +2600,7 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
                  "dsnt_conv_wgrad_f16x3: geometry not supported (need Wo %% 4 == 0, tensors < 2 GiB)");
     DSNT_REQUIRE(a_bound && g_bound, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: both operand bounds are required");
     // 3x3 / stride 1 convolutions: the halo kernel (wgrad3.hip) — every operand element staged once for all nine taps
-    const Wg3Plan pl = dsnt_wg3_plan(g);
+    const Wg3Plan pl = dsnt_wg3_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
     if (pl.ok) {
         if (int e = check_geom(g, "dsnt_conv_wgrad_f16x3")) return e;
         DSNT_REQUIRE(x && dy && ws, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: null tensor");
@@ -2622,19 +2624,20 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
 }
 
 // Plan of dsnt_conv_wgrad_f16x3 (the halo kernel cuts the pixels into its own slabs): number of slabs to reduce and
-// workspace floats; equal to dsnt_conv_wgrad_splits / _ws_floats where the implicit-GEMM kernel runs.
-extern "C" int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g) {
+// workspace floats for a launch with these `accumulate` flags (DSNT_WGRAD_SHARE_CHIP changes the halo kernel's plan);
+// equal to dsnt_conv_wgrad_splits / _ws_floats where the implicit-GEMM kernel runs.
+extern "C" int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g, int accumulate) {
     if (!g) return 0;
-    const Wg3Plan pl = dsnt_wg3_plan(g);
+    const Wg3Plan pl = dsnt_wg3_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
     return pl.ok ? pl.nslabs : dsnt_conv_wgrad_splits(g);
 }
-extern "C" int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g) {
+extern "C" int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate) {
     if (!g) return 0;
-    const Wg3Plan pl = dsnt_wg3_plan(g);
+    const Wg3Plan pl = dsnt_wg3_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
     if (!pl.ok) return dsnt_conv_wgrad_ws_floats(g);
     return (int64_t)pl.nslabs * g->Cout * (9 * g->Cin) + (int64_t)pl.nslabs * g->Cout;
 }
-extern "C" int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g) { return g ? dsnt_wg3_plan(g).ok : 0; }
+extern "C" int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g) { return g ? dsnt_wg3_plan(g, false).ok : 0; }
 
 static int conv_wgrad_impl(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                            const float* dy, float* ws, float* dw, float* dbias, int accumulate,

@@ -18,7 +18,8 @@ struct Wg3Plan {
     int blocks;         // workgroups
     int lds;            // dynamic LDS bytes
 };
-Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g);
+// share = DSNT_WGRAD_SHARE_CHIP: the plan of a launch that runs beside a dependency chain (fewer, longer slabs)
+Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, bool share);
 // enqueue (or record) the launch; tensors as dsnt_conv_wgrad_f16x3 (in_scale / in_shift may be null); share =
 // DSNT_WGRAD_SHARE_CHIP: the launch runs beside a dependency chain on another stream
 void dsnt_wg3_launch(const Wg3Plan& pl, const float* x, const float* in_scale, const float* in_shift, int in_relu,

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(CFG == 2 ? 256 : 512, 2) void wgrad3_kernel(Wg3P p)
 
 static int enabled = -1, min_steps = 0, small_wg = 1;
 
-Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g) {
+Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, bool share) {
     Wg3Plan pl;
     memset(&pl, 0, sizeof(pl));
     static long target = 0;
@@ -332,7 +332,10 @@ Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g) {
     // `min_steps` 16-pixel steps per workgroup: every workgroup pays a three-row prologue and writes a whole slab
     int rps = g->H;
     const long per = (long)pl.kchunks * pl.nchunks * pl.strips * g->N;
-    while (per * (g->H / rps) < target && rps % 2 == 0 && (rps / 2) * (WS / 16) >= min_steps) rps /= 2;
+    // (a launch that shares the chip runs as four-wave workgroups of 32 channels, ONE per CU: twice the workgroups per
+    // slab, so half as many slabs fill the chip — and half the slab bytes are written and reduced)
+    const long want = (share && small_wg && pl.cfg == 0) ? target / 2 : target;
+    while (per * (g->H / rps) < want && rps % 2 == 0 && (rps / 2) * (WS / 16) >= min_steps) rps /= 2;
     pl.rps = rps;
     pl.hsplits = g->H / rps;
     pl.nslabs = g->N * pl.hsplits * pl.strips;

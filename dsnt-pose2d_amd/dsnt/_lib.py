@@ -156,8 +156,8 @@ PLAIN = {
     'dsnt_conv_wgrad_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_splits': (I, [GP]),
     'dsnt_conv_wgrad_halo_ok': (I, [GP]),
-    'dsnt_conv_wgrad_f16x3_splits': (I, [GP]),
-    'dsnt_conv_wgrad_f16x3_ws_floats': (L, [GP]),
+    'dsnt_conv_wgrad_f16x3_splits': (I, [GP, I]),
+    'dsnt_conv_wgrad_f16x3_ws_floats': (L, [GP, I]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
     'dsnt_conv_wgrad_desc_bytes': (I, []),
     'dsnt_conv_wgrad_desc': (I, [P, P, P, I, P, P, GP, P]),

@@ -239,8 +239,8 @@ class Tape:
 
     def amax_slot(self):
         if self._amax_buf is None:
-            self._amax_buf = self.empty(64 * 2048)
-        assert self._amax_used + 64 <= self._amax_buf.numel()
+            self._amax_buf = self.empty(64 * 4096)
+        assert self._amax_used + 64 <= self._amax_buf.numel(), 'backward bound slots exhausted'
         self._amax_used += 64
         return self._amax_buf[self._amax_used - 64:self._amax_used]
 
@@ -261,8 +261,8 @@ class Tape:
 
     def _famax_slot(self):
         if self._famax_buf is None:
-            self._famax_buf = self.empty(64 * 256)
-        assert self._famax_used + 64 <= self._famax_buf.numel()
+            self._famax_buf = self.empty(64 * 2048)      # hg8 with every level on fp16x3 claims ~800 slots
+        assert self._famax_used + 64 <= self._famax_buf.numel(), 'forward bound slots exhausted'
         self._famax_used += 64
         return self._famax_buf[self._famax_used - 64:self._famax_used]
 
@@ -821,7 +821,9 @@ class Tape:
                 # for the weight-gradient lane first (grad_target)
                 self._wgrad_lane_reads.add(gy.data_ptr())
             nws = self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g))
-            share = 2 if (wl != cur and self.wgrad_share) else 0      # DSNT_WGRAD_SHARE_CHIP: one workgroup per CU beside the chain
+            # DSNT_WGRAD_SHARE_CHIP: one workgroup per CU beside the chain — except for the first convolution of the
+            # network (no data gradient: it is the LAST launch of backward and has the chip to itself)
+            share = 2 if (wl != cur and self.wgrad_share and need_input_grad) else 0
             w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
             if self.defer_reduce:
                 # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
@@ -834,8 +836,8 @@ class Tape:
                 splits = self.lib.dsnt_conv_wgrad_splits(C.byref(g))
                 if w16 and not grouped:
                     # dsnt_conv_wgrad_f16x3 cuts the pixels of a 3x3 convolution into its own slabs (halo kernel)
-                    nws = self.lib.dsnt_conv_wgrad_f16x3_ws_floats(C.byref(g))
-                    splits = self.lib.dsnt_conv_wgrad_f16x3_splits(C.byref(g))
+                    nws = self.lib.dsnt_conv_wgrad_f16x3_ws_floats(C.byref(g), share)
+                    splits = self.lib.dsnt_conv_wgrad_f16x3_splits(C.byref(g), share)
                 ws = self.empty(nws)         # lives until the bucket's reduction
                 self._ws_ptrs.add(ws.data_ptr())
                 if grouped:

@@ -315,10 +315,12 @@ int dsnt_conv_wgrad_desc_f16x3(const float* x, const float* in_scale, const floa
  * dsnt_conv_wgrad_f16x3 as a HALO kernel: a workgroup owns 64 input channels x all nine taps x 128 output channels of a
  * strip of pixel rows, so each operand element is BatchNorm-transformed and split once instead of nine times.  It cuts
  * the pixels into its own slabs: size `ws` with dsnt_conv_wgrad_f16x3_ws_floats and reduce
- * dsnt_conv_wgrad_f16x3_splits slabs (both fall back to the plain plan for every other geometry). */
+ * dsnt_conv_wgrad_f16x3_splits slabs, both asked with the `accumulate` flags of the launch (a DSNT_WGRAD_SHARE_CHIP
+ * launch runs as four-wave workgroups, one per CU, over half as many slabs; both fall back to the plain plan for every
+ * other geometry). */
 int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g);
-int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g);
-int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g);
+int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g, int accumulate);
+int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate);
 
 /* ----------------------------------------------------- heat-map matching ("gauss" output strategy)
  * Rows = (image, joint) maps of h x w floats, target = normalised coordinates [rows][2].

@@ -556,8 +556,8 @@ def test_wgrad_halo_f16x3(case, pro, relu):
     ab, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
     ab.fill_(act.abs().max().item() * 16.0)
     call('dsnt_amax', ptr(gyd), gyd.numel(), ptr(gb))
-    nws = _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g))
-    splits = _lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g))
+    nws = _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 0)
+    splits = _lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g), 0)
     assert nws == splits * Cout * (9 * Cin + 1)
     ws = torch.full((nws,), float('nan'), device=dev)
     dw16, dw32 = torch.empty(Cout, 3, 3, Cin, device=dev), torch.empty(Cout, 3, 3, Cin, device=dev)
@@ -579,10 +579,19 @@ def test_wgrad_halo_f16x3(case, pro, relu):
     call('dsnt_conv_wgrad_f16x3', *args, ptr(ws2), None, None, 0, ptr(ab), ptr(gb), C.byref(g))
     assert torch.equal(ws, ws2)
     # DSNT_WGRAD_SHARE_CHIP (bit 1): four-wave workgroups of 32 input channels that leave half of every CU to the
-    # other streams — the same slabs, bit for bit
-    ws3 = torch.full((nws,), float('nan'), device=dev)
-    call('dsnt_conv_wgrad_f16x3', *args, ptr(ws3), None, None, 2, ptr(ab), ptr(gb), C.byref(g))
-    assert torch.equal(ws, ws3)
+    # other streams, over its own plan of (at most as many) slabs: every slab element written, the same gradient
+    nws_s = _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 2)
+    splits_s = _lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g), 2)
+    assert nws_s == splits_s * Cout * (9 * Cin + 1) and splits_s <= splits
+    ws3 = torch.full((nws_s,), float('nan'), device=dev)
+    dw3, db3 = torch.empty_like(dw16), torch.empty_like(db16)
+    call('dsnt_conv_wgrad_f16x3', *args, ptr(ws3), ptr(dw3), ptr(db3), 2, ptr(ab), ptr(gb), C.byref(g))
+    assert bool(torch.isfinite(ws3).all())
+    e3 = (dw3.cpu().double() - ref).abs().max().item()
+    assert e3 <= 3e-5 * scale and e3 <= max(4 * e32, 2e-6 * scale), (e3, e32)
+    assert (db3.cpu().double() - b.grad).abs().max().item() <= 3e-5 * b.grad.abs().max().item()
+    if splits_s == splits:
+        assert torch.equal(ws, ws3)      # same slabs: the two workgroup shapes add in the same order, bit for bit
     table = torch.tensor([[ws2.data_ptr(), dw2.data_ptr(), db2.data_ptr(), splits, Cout * 9 * Cin, Cout, 0]],
                          dtype=torch.int64).to(dev)
     call('dsnt_wgrad_reduce_all', ptr(table), 1, (Cout * 9 * Cin // 4 + (Cout + 3) // 4 + 63) // 64)

@@ -14,7 +14,7 @@ x = torch.randn(B, H, H, Cin, device=dev)
 sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
 gy = torch.randn(B, H, H, Cout, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-nws = _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g))
+nws = _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 0)
 ws = torch.empty(nws, device=dev)
 ab, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
 _lib.fn('dsnt_amax')(ptr(gy), gy.numel(), ptr(gb), st)
@@ -37,4 +37,4 @@ us = e0.elapsed_time(e1) * 1000 / n
 fl = 2.0 * B * H * H * k * k * Cin * Cout
 print('wgrad %dx%d %d->%d k%d B%d halo=%d slabs=%d ws=%.1f MB: %.1f us  %.1f TFLOP/s (algorithmic)' % (
     H, H, Cin, Cout, k, B, _lib.fn('dsnt_conv_wgrad_halo_ok')(C.byref(g)),
-    _lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g)), nws * 4 / 1e6, us, fl / us / 1e6))
+    _lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g), 0), nws * 4 / 1e6, us, fl / us / 1e6))

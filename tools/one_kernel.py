@@ -16,7 +16,7 @@ y = torch.empty(B, H, H, Cout, device=dev); gy = torch.randn(B, H, H, Cout, devi
 M = B * H * H
 stats = torch.empty((M + 127) // 128, 2, Cout, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-ws = torch.empty(max(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g))), device=dev); dw = torch.empty_like(w); db = torch.empty(Cout, device=dev)
+ws = torch.empty(max(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 0)), device=dev); dw = torch.empty_like(w); db = torch.empty(Cout, device=dev)
 planes = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=dev)
 _lib.fn('dsnt_split_bf16x3')(ptr(w), ptr(planes), w.numel(), st)
 planes16 = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
