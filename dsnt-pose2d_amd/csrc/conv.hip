@@ -1043,10 +1043,10 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
     }
 }
 
-// rows up to which the K-split kernel replaces the 32 x 128 tiling (DSNT_KSPLIT_ROWS; 0 disables)
+// rows up to which the K-split kernel replaces the 32 x 128 tiling (measured crossover: 2048)
 static long ksplit_rows() {
     static long v = -1;
-    if (v < 0) { const char* e = getenv("DSNT_KSPLIT_ROWS"); v = e ? atol(e) : 2048; }
+    if (v < 0) v = 2048;
     return v;
 }
 
@@ -1344,9 +1344,6 @@ static void launch_conv3x3_6(const ConvP& p, bool pro, hipStream_t st) {
     size_t lds = (size_t)((F16 ? 2 : 1) * NPL * 192 + 2 * NPL * BN) * PITCH6 * 2;
     const size_t epi = (size_t)128 * (BN + 4) * 4;
     if (epi > lds) lds = epi;
-    static int one = -1;            // DSNT_HALO_ONE=1 (experiment): pad the LDS request so that only ONE workgroup fits a CU
-    if (one < 0) { const char* e = getenv("DSNT_HALO_ONE"); one = (e && e[0] == '1') ? 1 : 0; }
-    if (one) lds = 100 * 1024;
     static bool attr_done = false;
     if (!attr_done && lds > 65536) {
         hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1371,23 +1368,14 @@ static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
     if (epi > lds) lds = epi;
     static size_t attr_lds = 0;
     if (lds > 65536 && lds > attr_lds) {
-        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    // A-operand register stages: 2 (default) or 4 (DSNT_GEMM_DEPTH=4).  Measured on MI355X: four stages are 2-5 %
-    // SLOWER on every 1x1 shape of the hourglass (the kernel is not waiting for HBM latency: see DESIGN.md, issue bound)
-    static int depth = -1;
-    if (depth < 0) { const char* e = getenv("DSNT_GEMM_DEPTH"); depth = (e && e[0] == '4') ? 4 : 2; }
+    // two A-operand register stages (DA): four measured 2-5 % slower on every 1x1 shape of the hourglass (round 2)
     dim3 gr(p.mtiles * p.ntiles), bl(512);
-    // (the three-plane kernel with the BN prologue needs 139 registers with four stages: one workgroup per CU; it keeps two)
-    if (depth == 2 || (pro && !F16)) {
-        if (pro) DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 2>), gr, bl, lds, st, p);
-        else DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>), gr, bl, lds, st, p);
-    } else if (pro) DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 4>), gr, bl, lds, st, p);
-    else DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 4>), gr, bl, lds, st, p);
+    if (pro) DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 2>), gr, bl, lds, st, p);
+    else DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>), gr, bl, lds, st, p);
 }
 
 static bool g_force_gemm6 = false;      // debug/bench: route 3x3 convolutions through the implicit-GEMM kernel
@@ -2173,232 +2161,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_group_kernel(const W
     else wgrad6_body<true, false>(p, blockIdx.x, smem);
 }
 
-// ------------------------------------------------------------------------------------------
-// bf16x6 weight gradient without the loader / MFMA role split ("unified" waves): every wave owns a 64 x 64
-// quadrant of the 128 x 128 tile AND stages a quarter of the next step's operands (waves 0,1: A rows;
-// waves 2,3: dY rows) between its MFMAs.  256 threads, 2 workgroups per CU (same 72 KB double buffer).
-// Kept as an A/B variant (DSNT_WGRAD_KERNEL=unified): it measures the same as the role-split kernel
-// (3x3 128->128 @64^2, B=32: 259 vs 261 us).  What the experiments around it showed (round 1, MI355X):
-//   * in-kernel timeline: a step takes ~3500 cycles per wave = 2270 of fragment reads + staging + 24 MFMAs
-//     (768 cycles of matrix pipe), ~400-800 to issue four buffer loads, ~450-900 at the barrier: every
-//     instruction of the two co-resident waves of a SIMD queues at one vector-issue port;
-//   * the same kernel with ALL split arithmetic removed (raw bits permuted into LDS, wrong results) was
-//     only 10 % faster (261 -> 233 us): pre-splitting the operands in HBM would not pay;
-//   * a "ping-pong" variant (512 threads, two groups alternating matrix and staging phases, one barrier
-//     per phase, so that a SIMD always pairs an MFMA wave with a staging wave) was 14 % SLOWER (298 us):
-//     a phase took ~2000 cycles, i.e. the partner's VALU stream and the MFMAs did not overlap;
-//   * packed fp32 ops (v_pk_add_f32 / v_pk_fma_f32) in the split cost more issue time than the plain
-//     instructions they replace (MI355X_MICROARCH.md): 260 -> 230 us after un-packing them.
-template <bool PRO, bool IS_A>
-__device__ __forceinline__ void wgrad6u_wave(const WgradP& p, __bf16* At, __bf16* Gt, const int ltid,
-                                             const int wave, const int lane, const int ktile, const int ntile,
-                                             const int split, float* smem) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    __bf16* T = IS_A ? At : Gt;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int m_begin = split * p.rows_per_split;
-    const int m_end = min(p.M, m_begin + p.rows_per_split);
-    const int nsteps = (m_end - m_begin + 15) / 16;
-    // ---- staging role (see wgrad6_loader)
-    const int mb = ltid & 3, q = (ltid >> 2) & 31;
-    const unsigned OOB = 0xF0000000u;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(IS_A ? p.x : p.dy), 0,
-        IS_A ? (int)((size_t)p.N * p.H * p.W * p.Cin * 4u) : (int)((size_t)p.M * p.Cout * 4u), 0x00020000);
-    const int k0 = ktile * 128 + q * 4;
-    const bool vk = k0 < p.K;
-    const int tap = k0 / p.Cin, c = k0 - tap * p.Cin;
-    const int r = tap / p.S, s_ = tap - r * p.S;
-    const int dh = r * p.dil - p.pad, dw = s_ * p.dil - p.pad;
-    f32x2 sc0 = {1.f, 1.f}, sc1 = {1.f, 1.f}, sh0 = {0.f, 0.f}, sh1 = {0.f, 0.f};
-    if (PRO && IS_A && vk) {
-        const float4 a = *reinterpret_cast<const float4*>(p.in_scale + c);
-        const float4 b = *reinterpret_cast<const float4*>(p.in_shift + c);
-        sc0 = (f32x2){a.x, a.y}; sc1 = (f32x2){a.z, a.w};
-        sh0 = (f32x2){b.x, b.y}; sh1 = (f32x2){b.z, b.w};
-    }
-    const float lo_valid = (PRO && IS_A && p.in_relu) ? 0.f : -__builtin_inff();
-    const int n0 = ntile * 128 + q * 4;
-    const bool vn = n0 < p.Cout;
-    const int HoWo = p.Ho * p.Wo;
-    int rm = m_begin + mb * 4;
-    const int mm0 = rm < p.M ? rm : 0;
-    int rn = mm0 / HoWo;
-    int roh = (mm0 - rn * HoWo) / p.Wo;
-    int row_ = mm0 - rn * HoWo - roh * p.Wo;
-    const int adv_h = 16 / p.Wo, adv_w = 16 - adv_h * p.Wo;
-    struct Stage { u32x4 v[4]; unsigned ok; };
-    Stage S0, S1;
-    f32x2 bs0 = {0.f, 0.f}, bs1 = {0.f, 0.f};
-    auto gload = [&](Stage& st) {
-        st.ok = 0;
-        if (IS_A) {
-            const int ih = roh * p.stride + dh;
-            const bool vrow = vk && ih >= 0 && ih < p.H;
-            const int base = ((rn * p.H + ih) * p.W) * p.Cin + c;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int iw = (row_ + j) * p.stride + dw;
-                const bool ok = (rm + j) < m_end && vrow && iw >= 0 && iw < p.W;
-                const unsigned off = (unsigned)(base + iw * p.Cin) * 4u;
-                st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
-                st.ok |= (ok ? 1u : 0u) << j;
-            }
-            row_ += adv_w; roh += adv_h;
-            if (row_ >= p.Wo) { row_ -= p.Wo; roh += 1; }
-            // 16 rows cross at most one image boundary when an image has >= 16 pixels (branch-free); tiny maps loop
-            if (HoWo >= 16) { const bool wrap = roh >= p.Ho; roh = wrap ? roh - p.Ho : roh; rn = wrap ? rn + 1 : rn; }
-            else while (roh >= p.Ho) { roh -= p.Ho; rn += 1; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = (rm + j) < m_end && vn;
-                const unsigned off = (unsigned)((rm + j) * p.Cout + n0) * 4u;
-                st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);
-            }
-        }
-        rm += 16;
-    };
-    auto lstore = [&](const Stage& st, int buf) {
-        f32x2 v0[4], v1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v0[j] = (f32x2){__uint_as_float(st.v[j].x), __uint_as_float(st.v[j].y)};
-            v1[j] = (f32x2){__uint_as_float(st.v[j].z), __uint_as_float(st.v[j].w)};
-            if (PRO && IS_A) {
-                v0[j].x = fmaf(v0[j].x, sc0.x, sh0.x); v0[j].y = fmaf(v0[j].y, sc0.y, sh0.y);
-                v1[j].x = fmaf(v1[j].x, sc1.x, sh1.x); v1[j].y = fmaf(v1[j].y, sc1.y, sh1.y);
-                const bool ok = (st.ok >> j) & 1u;
-                const float lo = ok ? lo_valid : 0.f, hi = ok ? __builtin_inff() : 0.f;
-                v0[j].x = __builtin_amdgcn_fmed3f(v0[j].x, lo, hi); v0[j].y = __builtin_amdgcn_fmed3f(v0[j].y, lo, hi);
-                v1[j].x = __builtin_amdgcn_fmed3f(v1[j].x, lo, hi); v1[j].y = __builtin_amdgcn_fmed3f(v1[j].y, lo, hi);
-            }
-            if (!IS_A) { bs0.x += v0[j].x; bs0.y += v0[j].y; bs1.x += v1[j].x; bs1.y += v1[j].y; }
-        }
-        __bf16* base = T + ((size_t)(buf * 3) * 128 + q * 4) * PITCH6 + mb * 4;
-#define SPLIT_COL(E, V, COMP)                                                                        \
-        {                                                                                            \
-            uint2 q1, q2, q3;                                                                        \
-            split4(make_float4(V[0].COMP, V[1].COMP, V[2].COMP, V[3].COMP), q1, q2, q3);            \
-            __bf16* d = base + (E) * PITCH6;                                                         \
-            *reinterpret_cast<uint2*>(d) = q1;                                                       \
-            *reinterpret_cast<uint2*>(d + 128 * PITCH6) = q2;                                        \
-            *reinterpret_cast<uint2*>(d + 2 * 128 * PITCH6) = q3;                                    \
-        }
-        SPLIT_COL(0, v0, x) SPLIT_COL(1, v0, y) SPLIT_COL(2, v1, x) SPLIT_COL(3, v1, y)
-#undef SPLIT_COL
-    };
-    // ---- MFMA role
-    const int wk = wave >> 1, wn = wave & 1;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    struct Frag { bf16x8 a[2][3], b[2][3]; };
-    Frag F;
-    auto rd = [&](int buf) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                F.a[t][pl] = *reinterpret_cast<const bf16x8*>(
-                    At + ((size_t)(buf * 3 + pl) * 128 + wk * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
-                F.b[t][pl] = *reinterpret_cast<const bf16x8*>(
-                    Gt + ((size_t)(buf * 3 + pl) * 128 + wn * 64 + t * 32 + lr) * PITCH6 + 8 * lh);
-            }
-    };
-    auto mm = [&]() {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][2], F.b[b][0], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][2], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][1], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][1], F.b[b][0], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][1], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[a][0], F.b[b][0], acc[a][b], 0, 0, 0);
-            }
-    };
-    // one half-step: fragments of the current buffer, then the MFMAs with the staging of the next step
-    // (split + LDS stores into the other buffer) scheduled between them, then the prefetch two steps ahead
-#define WG6U_HALF(SCUR, BUFC, STEP)                                                                  \
-    DBG_STAMP(1 + 3 * (STEP));                                                                       \
-    rd(BUFC);                                                                                        \
-    lstore(SCUR, 1 - (BUFC));                                                                        \
-    mm();                                                                                            \
-    DBG_STAMP(2 + 3 * (STEP));                                                                       \
-    gload(SCUR);                                                                                     \
-    DBG_STAMP(3 + 3 * (STEP));                                                                       \
-    __syncthreads();
-    DBG_INIT();
-    DBG_STAMP(0);
-    gload(S0);
-    gload(S1);
-    lstore(S0, 0);
-    gload(S0);
-    __syncthreads();
-    int s = 0;
-    for (; s + 1 < nsteps; s += 2) {
-        WG6U_HALF(S1, 0, s)
-        WG6U_HALF(S0, 1, s + 1)
-    }
-    if (s < nsteps) { rd(0); mm(); }
-    DBG_STAMP(125);
-#undef WG6U_HALF
-    // slab store: ws[split][n][k], D row = k (regs, 4 consecutive), D col = n (lane)
-    float* slab = p.ws + (size_t)split * p.Cout * p.K;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = ntile * 128 + wn * 64 + b * 32 + lr;
-        if (n >= p.Cout) continue;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int k = ktile * 128 + wk * 64 + a * 32 + 8 * qq + 4 * lh;
-                if (k < p.K)
-                    *reinterpret_cast<float4*>(slab + (size_t)n * p.K + k) =
-                        make_float4(acc[a][b][4 * qq + 0], acc[a][b][4 * qq + 1], acc[a][b][4 * qq + 2],
-                                    acc[a][b][4 * qq + 3]);
-            }
-    }
-    // bias partial: column sums of this split's dY rows (the dY-staging waves of the ktile-0 blocks)
-    if (ktile == 0) {
-        float* red = smem;   // [4][128] floats
-        __syncthreads();
-        if (!IS_A)
-            *reinterpret_cast<float4*>(red + mb * 128 + q * 4) = make_float4(bs0.x, bs0.y, bs1.x, bs1.y);
-        __syncthreads();
-        const int tid = threadIdx.x;
-        if (tid < 128) {
-            const int n = ntile * 128 + tid;
-            if (n < p.Cout)
-                p.ws[(size_t)p.splits * p.Cout * p.K + (size_t)split * p.Cout + n] =
-                    red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
-        }
-    }
-}
-
-template <bool PRO>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x6u_kernel(WgradP p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* At = reinterpret_cast<__bf16*>(smem);            // [2][3][128][PITCH6]
-    __bf16* Gt = At + 2 * 3 * 128 * PITCH6;                  // [2][3][128][PITCH6]
-    int bid;
-    xcd_remap(blockIdx.x, gridDim.x, bid);
-    const int ktile = bid % p.ktiles; bid /= p.ktiles;
-    const int ntile = bid % p.ntiles;
-    const int split = bid / p.ntiles;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (wave < 2) wgrad6u_wave<PRO, true>(p, At, Gt, tid, wave, lane, ktile, ntile, split, smem);
-    else wgrad6u_wave<PRO, false>(p, At, Gt, tid - 128, wave, lane, ktile, ntile, split, smem);
-}
-
 // Slab reduction: 64 float4 columns x 4 split-lanes per block, 8 loads in flight per thread.
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, float* __restrict__ dw,
                                                   float* __restrict__ dbias, int splits, int CK, int Cout,
@@ -2480,10 +2242,9 @@ static void wgrad_plan(const dsnt_conv_geom* g, int& ktiles, int& ntiles, int& s
     const int K = g->R * g->S * g->Cin;
     ktiles = (K + 127) / 128;
     ntiles = (g->Cout + 127) / 128;
-    static long target = -1;                  // DSNT_WGRAD_WGS: workgroups aimed at per launch (tuning switch)
-    // one workgroup per CU: these launches run at one workgroup per CU beside the dependency chain anyway
-    // (DSNT_WGRAD_SHARE_CHIP), and half as many splits are half the slab traffic (512: +0.2 ms per hg2 step)
-    if (target < 0) { const char* e = getenv("DSNT_WGRAD_WGS"); target = e ? atol(e) : 256; }
+    // 256 workgroups = one per CU: these launches run at one workgroup per CU beside the dependency chain anyway
+    // (DSNT_WGRAD_SHARE_CHIP), and half as many splits are half the slab traffic (512 measured +0.2 ms per hg2 step)
+    const long target = 256;
     long want = target / (ktiles * ntiles);
     if (want < 1) want = 1;
     long max_splits = (M + 255) / 256;         // at least 8 steps of 32 rows per split
@@ -2670,13 +2431,8 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
         if (!attr_done) {
             hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
             hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_full);
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6u_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_full);
             attr_done = true;
         }
-        // DSNT_WGRAD_KERNEL=unified: the variant without the loader / MFMA role split (A/B switch; same speed)
-        static int unified = -1;
-        if (unified < 0) { const char* e = getenv("DSNT_WGRAD_KERNEL"); unified = (e && e[0] == 'u') ? 1 : 0; }
         if (a_bound) {              // fp16x3 (role-split kernel; its two fp16 planes need 2/3 of the LDS)
             static bool attr16 = false;
             if (!attr16) {
@@ -2687,9 +2443,6 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
             const int lds16 = share ? share_lds : 2 * 2 * 2 * 128 * PITCH6 * 2;
             if (in_scale) DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<true, true>), dim3(grid), dim3(512), lds16, st, p);
             else DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<false, true>), dim3(grid), dim3(512), lds16, st, p);
-        } else if (unified) {
-            if (in_scale) DSNT_LAUNCH(conv_wgrad_bf16x6u_kernel<true>, dim3(grid), dim3(256), lds_full, st, p);
-            else DSNT_LAUNCH(conv_wgrad_bf16x6u_kernel<false>, dim3(grid), dim3(256), lds_full, st, p);
         } else if (in_scale) DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<true, false>), dim3(grid), dim3(512), lds, st, p);
         else DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<false, false>), dim3(grid), dim3(512), lds, st, p);
     } else if (in_scale)

@@ -264,14 +264,12 @@ __global__ __launch_bounds__(512, 2) void gemm1_kernel(ConvP p, int niter) {
 }
 
 static int g1_enabled = -1;
-static long g1_min_rows = 65536;
+static const long g1_min_rows = 65536;     // below: too few row blocks to fill 256 persistent workgroups
 
 int dsnt_gemm1_cfg(const ConvP& p) {
     if (g1_enabled < 0) {
         const char* e = getenv("DSNT_GEMM1");
         g1_enabled = (e && e[0] == '0') ? 0 : 1;
-        const char* r = getenv("DSNT_GEMM1_MIN_ROWS");
-        if (r) g1_min_rows = atol(r);
     }
     if (!g1_enabled || !p.a_bound || !p.w_bound || !p.wq) return -1;
     if (!(p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.Ho == p.H && p.Wo == p.W)) return -1;
@@ -282,7 +280,7 @@ int dsnt_gemm1_cfg(const ConvP& p) {
     if ((size_t)p.M * p.K * 4u >= (1ull << 31) || (size_t)p.M * p.Cout * 4u >= (1ull << 31)) return -1;
     // (K, columns per workgroup): the weight chunk has to fit LDS beside the statistics scratch
     int ntw;
-    if (p.K == 128) ntw = p.Cout % 256 == 0 ? 8 : (p.Cout % 128 == 0 ? 4 : 0);
+    if (p.K == 128) ntw = p.Cout % 256 == 0 ? 8 : (p.Cout % 128 == 0 ? 4 : (p.Cout % 64 == 0 ? 2 : 0));
     else if (p.K == 256) ntw = p.Cout % 128 == 0 ? 4 : 0;
     else if (p.K == 64) ntw = p.Cout % 128 == 0 ? 4 : (p.Cout % 64 == 0 ? 2 : 0);
     else return -1;
@@ -331,7 +329,8 @@ static void g1_launch(const ConvP& p, bool pro, hipStream_t st) {
 void dsnt_gemm1_launch(const ConvP& p, int ntw, bool pro, hipStream_t st) {
     if (p.K == 128) {
         if (ntw == 8) g1_launch<8, 8>(p, pro, st);
-        else g1_launch<8, 4>(p, pro, st);
+        else if (ntw == 4) g1_launch<8, 4>(p, pro, st);
+        else g1_launch<8, 2>(p, pro, st);
     } else if (p.K == 256) {
         g1_launch<16, 4>(p, pro, st);
     } else {

@@ -304,16 +304,15 @@ static int enabled = -1, min_steps = 0, small_wg = 1;
 Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, bool share) {
     Wg3Plan pl;
     memset(&pl, 0, sizeof(pl));
-    static long target = 0;
+    // tuning constants (measured on MI355X, hg2 batch 32): 256 workgroups = one per CU; at least 32 16-pixel steps per
+    // workgroup (every workgroup pays a three-row prologue and writes a whole slab); four-wave workgroups for launches
+    // that share the chip
+    const long target = 256;
     if (enabled < 0) {
-        const char* c = getenv("DSNT_WG3_SMALL");          // four-wave workgroups for shared launches (A/B: 0 = never)
-        small_wg = (c && c[0] == '0') ? 0 : 1;
         const char* e = getenv("DSNT_WGRAD3");
         enabled = (e && e[0] == '0') ? 0 : 1;
-        const char* m = getenv("DSNT_WG3_MINSTEPS");
-        min_steps = m ? atoi(m) : 32;
-        const char* t = getenv("DSNT_WG3_WGS");
-        target = t ? atol(t) : 256;
+        min_steps = 32;
+        small_wg = 1;
     }
     if (!enabled || !g) return pl;
     if (!(g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1 && g->dil == 1 && g->Ho == g->H && g->Wo == g->W))

@@ -185,8 +185,6 @@ def load():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = res
-        if os.environ.get('DSNT_FORCE_GEMM6'):       # A/B switch: 3x3 convolutions on the implicit-GEMM kernel
-            lib.dsnt_debug_force_gemm6(1)
         _lib = lib
     return _lib
 

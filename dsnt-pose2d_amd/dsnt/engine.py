@@ -98,12 +98,12 @@ class Tape:
         # skip branch of every hourglass level runs beside the low-resolution recursion)
         self.lane = 0
         self.use_lanes = os.environ.get('DSNT_LANES', '1') != '0'
-        self.fuse_join = os.environ.get('DSNT_FUSE_JOIN', '1') != '0'      # hourglass.Hourglass._level
+        self.fuse_join = True      # hourglass.Hourglass._level: branch gradients joined inside the pool's backward (-0.15 ms)
         self.side_stream = None
         self.wgrad_stream = None
         # lanes 3.. : more side lanes (the skip branches of the hourglass levels alternate over them: an inner level's
         # branch, which the main lane needs back first, does not queue behind the outer level's large kernels)
-        self.side_lanes = (1,) + tuple(range(3, 3 + max(0, int(os.environ.get('DSNT_SIDE_LANES', '2')) - 1)))
+        self.side_lanes = (1, 3)   # two side lanes (one: +0.13 ms, four: +0.35 ms: DESIGN.md "round 2")
         self.n_lanes = 3 + len(self.side_lanes) - 1
         self.chain_lanes = (0,) + self.side_lanes
         self.more_streams = ()
@@ -113,17 +113,17 @@ class Tape:
         # DSNT_WGRAD_LANE_RES=1 also moves convolutions with residual inputs, whose dY buffer is donated onwards and
         # written again — the writer then has to wait for the lane (measured: +0.45 ms, off).
         self.wgrad_lane = 2 if (self.use_lanes and os.environ.get('DSNT_WGRAD_LANE', '1') != '0') else None
-        self.wgrad_lane_rows = int(os.environ.get('DSNT_WGRAD_LANE_ROWS', '16000'))
-        self.wgrad_lane_res = os.environ.get('DSNT_WGRAD_LANE_RES', '0') != '0'
-        self.wgrad_lane_from = self.chain_lanes if os.environ.get('DSNT_WGRAD_LANE_SIDE', '1') != '0' else (0,)
-        self.wgrad_share = os.environ.get('DSNT_WGRAD_SHARE', '1') != '0'
+        self.wgrad_lane_rows = 16000
+        self.wgrad_lane_res = False
+        self.wgrad_lane_from = self.chain_lanes
+        self.wgrad_share = True    # DSNT_WGRAD_SHARE_CHIP on every launch of that lane (-0.2 ms)
         self._wgrad_lane_reads = set()
         # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
         # phase: a `release point` is the backward of an up-sampling whose low-resolution operand has at most
         # DSNT_WGRAD_RELEASE_ROWS rows.  Issued as they come, the weight gradients share the chip with the large
         # data-gradient kernels and are gone by the time the small levels start; held back, they run beside them.
         # Only while a release point is still ahead in the backward order (a ResNet has none: nothing is held back).
-        self.release_rows = int(os.environ.get('DSNT_WGRAD_RELEASE_ROWS', '8192'))
+        self.release_rows = 8192
         self._release_total, self._release_left = 0, 0
         self._held = []
         self.acts = []          # every activation in creation order (debugging / introspection)
@@ -139,11 +139,11 @@ class Tape:
         # weight gradients of the low-resolution levels (few workgroups each, nothing downstream in backward
         # needs them) wait for the end of their parameter bucket and run side by side in one grouped launch;
         # DSNT_WGRAD_GROUP_ROWS = largest N*Ho*Wo that is deferred (0 disables)
-        self.group_rows = int(os.environ.get('DSNT_WGRAD_GROUP_ROWS', '8192')) if self.defer_reduce else 0
+        self.group_rows = 8192 if self.defer_reduce else 0
         self._pending_group = []    # (descriptor bytes, workgroups) since the last flush
         # max-pool / upsample+add write the BatchNorm statistics of their output themselves (DSNT_FUSE_OP_STATS=0:
         # a separate dsnt_bn_stats pass when a BatchNorm asks for them)
-        self.fuse_op_stats = os.environ.get('DSNT_FUSE_OP_STATS', '1') != '0'
+        self.fuse_op_stats = True
         # fp16x3 (default; DSNT_SPLIT=bf16x6 turns it off): two fp16 planes + three MFMAs instead of three bf16 planes + six, where an operand
         # bound is available without a host round-trip: train-mode BN+ReLU operands (bound from the BN parameters) and
         # weights (amax in the per-step prep launch)
@@ -152,16 +152,16 @@ class Tape:
         self._f16_bn_rows = []
         self._eval_bn_rows = []     # eval mode: every BatchNorm's vectors come from ONE table-driven launch per forward
         self._amax_buf, self._amax_used = None, 0      # zeroed at the start of every backward
-        self.raw_f16 = os.environ.get('DSNT_RAW_F16', '1') != '0'      # A/B switch: bounds of raw operands from the producers' epilogues
+        self.raw_f16 = True        # bounds of raw operands from the producers' epilogues (-0.24 ms)
         self._planar_src, self._prep_exempt, self._post_reduce = {}, set(), []
-        self.stem_s2d_on = os.environ.get('DSNT_STEM_S2D', '1') != '0'
+        self.stem_s2d_on = True    # the stem as a space-to-depth convolution (-0.08 ms)
         self._famax_buf, self._famax_used, self._famax_of, self._famax_bn_of = None, 0, {}, {}   # forward activations: zeroed at the start of every forward
         # DSNT_AMAX_ALL=0: only single-writer BN-backward outputs get a bound (A/B switch); default: bounds follow the
         # gradient through every writer that can report one (apply, axpy, pool / upsample backward) and through donations
-        self.amax_all = os.environ.get('DSNT_AMAX_ALL', '1') != '0'
+        self.amax_all = True
         self._f16_dw_rows = []      # fp16x3 planes of the re-packed data-gradient weights
         self._dgrad_pack = None     # arguments of the one re-packing launch (set by finish, emitted by emit_f16_prep)
-        self.prep_on_side_lane = os.environ.get('DSNT_PREP_LANE', '1') != '0'
+        self.prep_on_side_lane = self.use_lanes      # per-step preparation beside the stem (-0.15 ms)
         self.dgrad_planes16, self.dgrad_bounds = None, None
         # every fp16x3 launch with the tensors behind its operands and bounds: (list entry, {...}) — lets a test walk a
         # step launch by launch and hold each bound against the operand it must dominate (tests/test_bounds_gpu.py)
@@ -169,7 +169,7 @@ class Tape:
         self._pending_group_uses = []
         # BatchNorm finalisation folded into the producers' last workgroup (csrc/bn_tail.h); DSNT_BN_TAIL=0: separate
         # dsnt_bn_finalize / dsnt_bn_bwd_finalize launches as before (A/B switch)
-        self.use_tail = os.environ.get('DSNT_BN_TAIL', '1') != '0'
+        self.use_tail = True
         # ... for producers of up to DSNT_BN_TAIL_ROWS rows.  Default 0 = off: measured on MI355X (hg2, batch 32) the
         # 193 finalise launches are NOT on the critical path of an untraced step — 16.53 ms without tails, 16.69 ms with
         # tails on every launch of <= 32768 rows (507 launches/step instead of 651), 16.80 ms with tails everywhere (460)
@@ -181,7 +181,7 @@ class Tape:
         self._tail_used = 0
         # replay from C (dsnt_list_*): a launch list is recorded once into the library and then issued by ONE call per
         # segment instead of one ctypes call per launch (DSNT_C_REPLAY=0: the Python loop below)
-        self.c_replay = os.environ.get('DSNT_C_REPLAY', '1') != '0'
+        self.c_replay = True
         self._clists = {}
 
     # ------------------------------------------------------------------ buffers
@@ -193,7 +193,7 @@ class Tape:
 
     def scratch(self, key, numel):
         """Shared scratch (valid only within one op's launches on the single stream)."""
-        if os.environ.get('DSNT_NO_SCRATCH'):
+        if False:      # (debugging aid: private buffers instead of the shared scratch)
             return self.empty(max(numel, 1))
         key = (key, self.lane)
         t = self._scratch.get(key)
@@ -652,7 +652,7 @@ class Tape:
         """a.grad (+)= g.  With `donate`, g's buffer is handed over when a has no gradient yet
         (the caller guarantees g is dead after its own launches).  Returns True if donated.
         g_amax: the bound slot of g, if it has one (it moves with a donated buffer)."""
-        if a.grad is None and donate and not os.environ.get('DSNT_NO_DONATE'):
+        if a.grad is None and donate:
             a.grad = g
             a.grad_amax = g_amax if self.amax_all else None
             return True

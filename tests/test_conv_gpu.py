@@ -269,6 +269,7 @@ BF16X6_CASES = [c for c in CASES if c[3] % 16 == 0 and c[4] % 4 == 0] + [
     (16, 64, 64, 256, 256, 1, 1, 0, 1),  # lin / fc_: two column chunks
     (4, 128, 128, 64, 64, 1, 1, 0, 1),   # stem Bottleneck: K = 64, four row tiles per wave
     (4, 128, 128, 64, 128, 1, 1, 0, 1),
+    (4, 128, 128, 128, 64, 1, 1, 0, 1),  # K = 128 with 64 columns (data gradient of the stem's 64 -> 128 expansion)
 ]
 
 

@@ -246,6 +246,31 @@ def test_hg2_every_gradient_vs_oracle(smooth):
         assert _rel_l2(p.grad, 2 * g1[n], 1e-3 * g1[n].norm().item() + 1e-12) <= 1e-5, n
 
 
+def test_gradients_with_the_slab_reduction_inside_every_launch(monkeypatch):
+    """DSNT_DEFER_REDUCE=0 (each weight gradient reduces its own slabs instead of one launch per parameter bucket) gives
+    the same gradients as the default schedule — including the stem's 7x7 filter, whose gradient is produced in the
+    space-to-depth layout and gathered back by a launch that has to follow the reduction on either path."""
+    from dsnt.model import build_mpii_pose_model
+
+    def grads(env):
+        if env is not None:
+            monkeypatch.setenv('DSNT_DEFER_REDUCE', env)
+        else:
+            monkeypatch.delenv('DSNT_DEFER_REDUCE', raising=False)
+        m = build_mpii_pose_model(base='hg1', output_strat='dsnt', reg='js')
+        synthetic.fill_state_dict(m, seed=4)
+        m.cuda().train()
+        x, target, mask = synthetic.batch(2, size=128, seed=6, mask_p=0.9)
+        loss = m.forward_loss(m(x.to(DEV)), target.to(DEV), mask.to(DEV))
+        loss.backward()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    a, b = grads(None), grads('0')
+    assert float(b['hg.conv1.weight'].abs().max()) > 0
+    for n in a:
+        scale = max(float(a[n].abs().max()), 1e-12)
+        assert float((a[n] - b[n]).abs().max()) <= 2e-5 * scale + 1e-9, n
+
+
 def test_hg8_every_gradient_vs_oracle_on_the_smooth_network():
     """hg8 + DSNT + JS (BASELINE config 5's model; batch 2, 128 px) against the CPU oracle: coordinates of all eight
     stacks within 1e-4, the loss, and — with the ReLUs taken out on both sides, so that no mask bit can flip — every

@@ -57,7 +57,10 @@ def test_backward_list_lanes_and_fusions(tape):
     assert set(by_lane) == {0, 1, 2, 3}
     wg = [(n, lane, a) for n, lane, a in bwd if n in ('dsnt_conv_wgrad_f16x3', 'dsnt_conv_wgrad_bf16x6')]
     on_lane2 = [x for x in wg if x[1] == 2]
-    assert len(on_lane2) >= 25 and all(x[2][8] == 2 for x in on_lane2)          # DSNT_WGRAD_SHARE_CHIP in `accumulate`
+    # DSNT_WGRAD_SHARE_CHIP in `accumulate` — except on the network's first convolution: no data gradient follows it, its
+    # weight gradient is the LAST launch of backward and has the chip to itself
+    assert len(on_lane2) >= 25 and all(x[2][8] == 2 for x in on_lane2[:-1]) and on_lane2[-1][2][8] == 0
+    assert wg[-1] is on_lane2[-1]
     assert all(x[2][8] == 0 for x in wg if x[1] != 2)
     # slab reductions, grouped small weight gradients and the gradient-bucket markers live on the weight-gradient lane
     assert all(lane == 2 for n, lane, _ in bwd if n in ('dsnt_wgrad_reduce_all', 'dsnt_conv_wgrad_group'))
@@ -74,3 +77,46 @@ def test_backward_list_lanes_and_fusions(tape):
 def test_launch_counts_stay_bounded(tape):
     nf, nb = len(_launches(tape.fwd)), len(_launches(tape.bwd))
     assert nf <= 235 and nb <= 400, (nf, nb)
+
+
+def _trace(monkeypatch_module, base, training, shape, **kw):
+    from dsnt import _lib
+    import dsnt.engine as E
+    monkeypatch_module.setattr(_lib, 'ptr', lambda t: C.c_void_p(t.data_ptr()) if t is not None else None)
+    monkeypatch_module.setattr(E._lib, 'ptr', _lib.ptr)
+    from dsnt.model import build_mpii_pose_model
+    from dsnt.hourglass import Arena, Program
+    m = build_mpii_pose_model(base=base, output_strat='dsnt', **kw)
+    m.train(training)
+    root = m.hg if hasattr(m, 'hg') else m._runner().root
+    return Program(root, Arena(root, torch.device('cpu')), shape, training, False).tape
+
+
+def test_eval_mode_schedule_of_hg2(monkeypatch_module):
+    """Inference (inference.py:33-48): no backward list, every BatchNorm's vectors from ONE table-driven launch, no
+    finalise launches, no statistics passes, the side lane still carries the skip branches; the large convolutions run
+    fp16x3 with bounds their producers leave (dsnt_bn_tail.amax_bn), so the forward list starts by zeroing them."""
+    tape = _trace(monkeypatch_module, 'hg2', False, (32, 3, 256, 256), reg='none')
+    fwd = _launches(tape.fwd)
+    names = [n for n, _, _ in fwd]
+    assert not tape.bwd
+    assert names.count('dsnt_bn_eval_prep') == 1 and 'dsnt_bn_finalize' not in names and 'dsnt_bn_stats' not in names
+    assert names[0] == 'dsnt_fill_zero'
+    assert names.count('dsnt_conv_fwd_f16x3_ex') >= 40
+    assert {lane for _, lane, _ in fwd} == {0, 1}            # the forward-only trace forks every skip branch onto lane 1
+    assert len(fwd) <= 135, len(fwd)
+
+
+def test_resnet34_train_schedule(monkeypatch_module):
+    """BASELINE config 1's model (ResNet-34 + DSNT, batch 8, 8x8 heat-maps): one lane chain (no skip branches to fork),
+    post-activation blocks as conv -> [BN+ReLU in the next conv's load] -> conv -> one bn_add_act launch, strided
+    convolutions' data gradients through zero-stuffing, weight gradients reduced once per bucket."""
+    tape = _trace(monkeypatch_module, 'resnet34', True, (8, 3, 256, 256))
+    fwd, bwd = _launches(tape.fwd), _launches(tape.bwd)
+    fn, bn = [n for n, _, _ in fwd], [n for n, _, _ in bwd]
+    assert fn.count('dsnt_bn_add_act_fwd') == 16                     # 3 + 4 + 6 + 3 BasicBlocks
+    assert fn.count('dsnt_maxpool3s2_fwd') == 1 and bn.count('dsnt_maxpool3s2_bwd') == 1
+    assert bn.count('dsnt_zero_insert') == 6                         # three stage transitions x (conv1 + downsample)
+    assert bn.count('dsnt_wgrad_reduce_all') >= 1 and bn.count('dsnt_wgrad_reduce_all') <= 6
+    assert not any(n.startswith('dsnt_axpy') for n in fn)
+    assert len(fwd) <= 180 and len(bwd) <= 330, (len(fwd), len(bwd))
