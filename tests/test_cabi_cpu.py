@@ -95,3 +95,20 @@ def test_launch_list_records_instead_of_launching():
     assert lib.dsnt_list_end() == 0
     assert lib.dsnt_list_replay(h, 5, None, 3) != 0            # bad arguments are refused before anything is enqueued
     lib.dsnt_list_destroy(h)
+
+
+def test_no_packed_fp32_instruction_with_crossed_halves_on_its_own_destination():
+    """The one instruction form that loses results on gfx950 (profiles/r03_slp_packed_add_hazard.txt: a v_pk_*_f32 whose
+    destination pair is also a source pair read with crossed halves — what hipcc's SLP vectoriser makes of adjacent scalar
+    sums) must not appear in the shipped library: every translation unit is built with -fno-slp-vectorize (build.py),
+    and this disassembles the built code objects to hold it to that."""
+    import importlib.util
+    import shutil
+    if not shutil.which('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        pytest.skip('llvm-objdump not available')
+    spec = importlib.util.spec_from_file_location('check_isa', os.path.join(ROOT, 'tools', 'check_isa_packed_f32.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from dsnt import _lib
+    total, bad = mod.scan(_lib.LIB_PATH)
+    assert not bad, bad[:5]
