@@ -2381,6 +2381,26 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
         }
         DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_f16x3");
     }
+    // 1x1 convolutions of >= 16384 rows: the transposition-free four-wave kernel (wgrad1.hip)
+    const Wg1Plan p1 = dsnt_wg1_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
+    if (p1.ok) {
+        if (int e = check_geom(g, "dsnt_conv_wgrad_f16x3")) return e;
+        DSNT_REQUIRE(x && dy && ws, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: null tensor");
+        DSNT_REQUIRE(dw || !dbias, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: dbias without dw");
+        DSNT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DSNT_ERR_ARG,
+                     "dsnt_conv_wgrad_f16x3: in_scale/in_shift must be given together");
+        DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(dy) && dsnt_aligned16(ws) && (!dw || dsnt_aligned16(dw)),
+                     DSNT_ERR_ALIGN, "dsnt_conv_wgrad_f16x3: tensors must be 16-byte aligned");
+        hipStream_t st = (hipStream_t)stream;
+        dsnt_wg1_launch(p1, x, in_scale, in_shift, in_relu, dy, ws, a_bound, g_bound, g, st);
+        if (dw) {
+            const int CK = g->Cout * g->Cin;
+            const int total = CK / 4 + (g->Cout + 3) / 4;
+            DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias, p1.nsplits, CK,
+                        g->Cout, accumulate & 1);
+        }
+        DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_f16x3");
+    }
     return conv_wgrad_impl(x, in_scale, in_shift, in_relu, dy, ws, dw, dbias, accumulate, g, stream, true, a_bound, g_bound);
 }
 
@@ -2390,13 +2410,17 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
 extern "C" int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g, int accumulate) {
     if (!g) return 0;
     const Wg3Plan pl = dsnt_wg3_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
-    return pl.ok ? pl.nslabs : dsnt_conv_wgrad_splits(g);
+    if (pl.ok) return pl.nslabs;
+    const Wg1Plan p1 = dsnt_wg1_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
+    return p1.ok ? p1.nsplits : dsnt_conv_wgrad_splits(g);
 }
 extern "C" int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate) {
     if (!g) return 0;
     const Wg3Plan pl = dsnt_wg3_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
-    if (!pl.ok) return dsnt_conv_wgrad_ws_floats(g);
-    return (int64_t)pl.nslabs * g->Cout * (9 * g->Cin) + (int64_t)pl.nslabs * g->Cout;
+    if (pl.ok) return (int64_t)pl.nslabs * g->Cout * (9 * g->Cin) + (int64_t)pl.nslabs * g->Cout;
+    const Wg1Plan p1 = dsnt_wg1_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
+    if (p1.ok) return (int64_t)p1.nsplits * g->Cout * g->Cin + (int64_t)p1.nsplits * g->Cout;
+    return dsnt_conv_wgrad_ws_floats(g);
 }
 extern "C" int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g) { return g ? dsnt_wg3_plan(g, false).ok : 0; }
 

@@ -25,3 +25,17 @@ Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, bool share);
 void dsnt_wg3_launch(const Wg3Plan& pl, const float* x, const float* in_scale, const float* in_shift, int in_relu,
                      const float* dy, float* ws, const float* a_bound, const float* g_bound, const dsnt_conv_geom* g,
                      hipStream_t st, bool share);
+
+// ---- 1x1 weight gradients (wgrad1.hip): a four-wave workgroup owns ck x cn channels of the weight matrix for its pixels
+struct Wg1Plan {
+    int ok;
+    int ck, cn;             // input / output channels per workgroup (64, 128 or 256)
+    int kchunks, nchunks;   // Cin / ck, Cout / cn
+    int nsplits;            // slabs ws[nsplits][Cout][Cin] (+ [nsplits][Cout] bias partials)
+    int rows_per_split;     // multiple of 16
+    int blocks, lds;
+};
+Wg1Plan dsnt_wg1_plan(const dsnt_conv_geom* g, bool share);
+void dsnt_wg1_launch(const Wg1Plan& pl, const float* x, const float* in_scale, const float* in_shift, int in_relu,
+                     const float* dy, float* ws, const float* a_bound, const float* g_bound, const dsnt_conv_geom* g,
+                     hipStream_t st);

@@ -601,6 +601,82 @@ def test_wgrad_halo_f16x3(case, pro, relu):
     assert (dw16.cpu().double() - 2 * ref).abs().max().item() <= 6e-5 * scale
 
 
+W1_CASES = [
+    # N, H, W, Cin, Cout: 1x1 / stride 1 shapes of >= 16384 rows: the transposition-free weight gradient (csrc/wgrad1.hip)
+    (4, 64, 64, 128, 256),     # expanding conv3: the whole 128 x 256 matrix per workgroup
+    (4, 64, 64, 256, 128),     # reducing conv1: 256 x 128
+    (4, 64, 64, 256, 256),     # lin: two input-channel chunks
+    (4, 64, 64, 128, 128),
+    (2, 128, 128, 64, 64),     # stem Bottleneck
+    (2, 128, 128, 64, 128),
+    (2, 128, 128, 128, 64),
+    (5, 64, 64, 128, 256),     # 20480 rows: the last slab is shorter
+]
+
+
+@pytest.mark.parametrize('case', W1_CASES)
+@pytest.mark.parametrize('pro,relu', [(True, 1), (False, 0)])
+def test_wgrad_1x1_f16x3(case, pro, relu):
+    """The four-wave 1x1 weight gradient (conv1 / conv3 of every Bottleneck, hourglass.py:20-25) vs fp64 autograd, the
+    bars of test_wgrad_f16x3, every slab element written, slabs-only + table-driven reduction bit-identical to the
+    reduction inside the call, and the DSNT_WGRAD_SHARE_CHIP launch (same kernel) bit-identical too."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    N, H, W, Cin, Cout = case
+    dev = torch.device('cuda:0')
+    tag = 'w1' + '_'.join(map(str, case))
+    g = _geom(N, H, W, Cin, Cout, 1, 1, 1, 0, 1)
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=1)
+    sc = synthetic.tensor(tag + 's', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'h', (Cin,), seed=1, scale=0.3)
+    act = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) if pro else x
+    act = (F.relu(act) if relu else act).double()
+    gy = synthetic.tensor(tag + 'g', (N, Cout, H, W), seed=2) * 1e-4
+    a2 = act.permute(0, 2, 3, 1).reshape(-1, Cin)
+    g2 = gy.double().permute(0, 2, 3, 1).reshape(-1, Cout)
+    ref = (g2.t() @ a2).view(Cout, 1, 1, Cin)
+    bref = g2.sum(0)
+    xd, gyd, scd, shd = _nhwc(x).to(dev), _nhwc(gy).to(dev), sc.to(dev), sh.to(dev)
+    ab, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ab.fill_(act.abs().max().item() * 16.0)
+    call('dsnt_amax', ptr(gyd), gyd.numel(), ptr(gb))
+    nws = _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 0)
+    splits = _lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g), 0)
+    assert nws == splits * Cout * (Cin + 1)
+    ws = torch.full((nws,), float('nan'), device=dev)
+    dw16, dw32 = torch.empty(Cout, 1, 1, Cin, device=dev), torch.empty(Cout, 1, 1, Cin, device=dev)
+    db16, db32 = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+    args = (ptr(xd), ptr(scd) if pro else None, ptr(shd) if pro else None, relu, ptr(gyd))
+    call('dsnt_conv_wgrad_f16x3', *args, ptr(ws), ptr(dw16), ptr(db16), 0, ptr(ab), ptr(gb), C.byref(g))
+    assert bool(torch.isfinite(ws).all()), 'a slab element was never written'
+    ws32 = torch.empty(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), device=dev)
+    call('dsnt_conv_wgrad', *args, ptr(ws32), ptr(dw32), ptr(db32), 0, C.byref(g))
+    scale = ref.abs().max().item()
+    e16 = (dw16.cpu().double() - ref).abs().max().item()
+    e32 = (dw32.cpu().double() - ref).abs().max().item()
+    assert e16 <= 3e-5 * scale and e16 <= max(4 * e32, 2e-6 * scale), (e16, e32)
+    assert (db16.cpu().double() - bref).abs().max().item() <= 3e-5 * bref.abs().max().item()
+    ws2 = torch.empty(nws, device=dev)
+    dw2, db2 = torch.zeros_like(dw16), torch.zeros_like(db16)
+    call('dsnt_conv_wgrad_f16x3', *args, ptr(ws2), None, None, 0, ptr(ab), ptr(gb), C.byref(g))      # slabs only
+    assert torch.equal(ws, ws2)
+    table = torch.tensor([[ws2.data_ptr(), dw2.data_ptr(), db2.data_ptr(), splits, Cout * Cin, Cout, 0]],
+                         dtype=torch.int64).to(dev)
+    call('dsnt_wgrad_reduce_all', ptr(table), 1, (Cout * Cin // 4 + (Cout + 3) // 4 + 63) // 64)
+    assert torch.equal(dw2, dw16) and torch.equal(db2, db16)
+    # DSNT_WGRAD_SHARE_CHIP: half as many (longer) slabs on half the CUs — its own plan, the same gradient
+    nws_s = _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 2)
+    splits_s = _lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g), 2)
+    assert nws_s == splits_s * Cout * (Cin + 1) and splits_s <= splits
+    ws3 = torch.full((nws_s,), float('nan'), device=dev)
+    dw3, db3 = torch.empty_like(dw16), torch.empty_like(db16)
+    call('dsnt_conv_wgrad_f16x3', *args, ptr(ws3), ptr(dw3), ptr(db3), 2, ptr(ab), ptr(gb), C.byref(g))
+    assert bool(torch.isfinite(ws3).all())
+    e3 = (dw3.cpu().double() - ref).abs().max().item()
+    assert e3 <= 3e-5 * scale and e3 <= max(4 * e32, 2e-6 * scale), (e3, e32)
+    assert (db3.cpu().double() - bref).abs().max().item() <= 3e-5 * bref.abs().max().item()
+
+
 def test_f16x3_preparation_launches():
     """The per-step table-driven launches of the fp16x3 path: weight planes + bounds of several tensors at once equal
     the single-tensor entry points; the BatchNorm bound is max_c(|gamma_c| sqrt(M) + |beta_c|) in all 64 slots; the
