@@ -223,6 +223,10 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
     const int wm = cw / WN, wn = cw % WN;
     DBG_INIT();
     DBG_STAMP(0);
+    if (PRO && p.pro.partial) {          // the A operand's BatchNorm is finalised here (bn_tail.h: bn_pro_forward)
+        bn_pro_forward<512>(p.pro, reinterpret_cast<double*>(smem), blockIdx.x == 0);
+        __syncthreads();                 // this workgroup's stores to in_scale / in_shift are visible to its loads
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -930,6 +934,10 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const unsigned OOB = 0xF0000000u;
+    if (PRO && p.pro.partial) {          // the A operand's BatchNorm is finalised here (bn_tail.h: bn_pro_forward)
+        bn_pro_forward<512>(p.pro, reinterpret_cast<double*>(&part[0][0][0]), blockIdx.x == 0);
+        __syncthreads();                 // this workgroup's stores to in_scale / in_shift are visible to its loads
+    }
     // A row of this lane
     const int m = mtile * 32 + i;
     const bool vm = m < p.M;
@@ -1050,11 +1058,17 @@ static long ksplit_rows() {
     return v;
 }
 
+// fp32 path only, <= 256 input channels, <= 128 KB of partial sums: what every workgroup re-reads in its prologue
+static bool conv_fwd_pro_ok(const dsnt_conv_geom* g, int tiles, int C) {
+    return g && C == g->Cin && C <= 256 && C % 4 == 0 && tiles > 0 && (long)tiles * C <= 16384;
+}
+extern "C" int dsnt_conv_fwd_pro_ok(const dsnt_conv_geom* g, int tiles, int C) { return conv_fwd_pro_ok(g, tiles, C) ? 1 : 0; }
+
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, float* y,
                          const float* in_scale, const float* in_shift, int in_relu,
                          const float* res1, const float* res2, float* stats_partial,
                          const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, const dsnt_bn_tail* g_tail,
-                         void* stream) {
+                         void* stream, const dsnt_bn_prologue* g_pro = nullptr) {
     if (int e = check_geom(g, "dsnt_conv_fwd")) return e;
     DSNT_REQUIRE(!g_bnb || (g_bnb->x && g_bnb->scale && g_bnb->shift && g_bnb->mean && g_bnb->invstd &&
                             stats_partial && !res1 && !res2 && !bias), DSNT_ERR_ARG,
@@ -1078,6 +1092,21 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
     if (int e = bn_tail_fill(p.tail, g_tail, "dsnt_conv_fwd_ex")) return e;
     DSNT_REQUIRE(!p.tail.counters || (stats_partial && p.tail.mode == (g_bnb ? 1 : 0)), DSNT_ERR_ARG,
                  "dsnt_conv_fwd_ex: a dsnt_bn_tail needs stats_partial; mode 1 goes with the batch-norm-backward epilogue");
+    memset(&p.pro, 0, sizeof(p.pro));
+    if (g_pro) {
+        DSNT_REQUIRE(g_pro->partial && g_pro->mean && g_pro->invstd && g_pro->scale && g_pro->shift && g_pro->M > 0 &&
+                     conv_fwd_pro_ok(g, g_pro->tiles, g_pro->C), DSNT_ERR_ARG,
+                     "dsnt_conv_fwd_pro: incomplete dsnt_bn_prologue, or more than 256 channels / 128 KB of partial sums");
+        DSNT_REQUIRE((g_pro->running_mean == nullptr) == (g_pro->running_var == nullptr), DSNT_ERR_ARG,
+                     "dsnt_conv_fwd_pro: running_mean/var must be given together");
+        DSNT_REQUIRE(dsnt_aligned16(g_pro->scale) && dsnt_aligned16(g_pro->shift), DSNT_ERR_ALIGN, "dsnt_conv_fwd_pro: alignment");
+        p.pro.partial = g_pro->partial; p.pro.tiles = g_pro->tiles; p.pro.C = g_pro->C;
+        p.pro.invM = 1.0 / (double)g_pro->M;
+        p.pro.unbias = g_pro->M > 1 ? (double)g_pro->M / (double)(g_pro->M - 1) : 1.0;
+        p.pro.gamma = g_pro->gamma; p.pro.beta = g_pro->beta; p.pro.rmean = g_pro->running_mean; p.pro.rvar = g_pro->running_var;
+        p.pro.momentum = g_pro->momentum; p.pro.eps = g_pro->eps;
+        p.pro.mean = g_pro->mean; p.pro.invstd = g_pro->invstd; p.pro.scale = g_pro->scale; p.pro.shift = g_pro->shift;
+    }
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
@@ -1112,6 +1141,13 @@ extern "C" int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bia
                                 const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail,
                                 void* stream) {
     return conv_fwd_impl(x, w, bias, y, in_scale, in_shift, in_relu, res1, res2, stats_partial, g, bnb, tail, stream);
+}
+
+extern "C" int dsnt_conv_fwd_pro(const float* x, const float* w, const float* bias, float* y, const dsnt_bn_prologue* pro,
+                                 int in_relu, const float* res1, const float* res2, float* stats_partial,
+                                 const dsnt_conv_geom* g, const dsnt_bn_tail* tail, void* stream) {
+    DSNT_REQUIRE(pro, DSNT_ERR_ARG, "dsnt_conv_fwd_pro: null dsnt_bn_prologue");
+    return conv_fwd_impl(x, w, bias, y, pro->scale, pro->shift, in_relu, res1, res2, stats_partial, g, nullptr, tail, stream, pro);
 }
 
 
@@ -1402,6 +1438,7 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     DSNT_REQUIRE(plane_stride >= (int64_t)g->Cout * g->R * g->S * g->Cin && plane_stride % 8 == 0 &&
                  (2 * plane_stride + (int64_t)g->Cout * g->R * g->S * g->Cin) * 2 < (1LL << 31), DSNT_ERR_SHAPE,
                  "dsnt_conv_fwd_bf16x6: bad plane stride %lld", (long long)plane_stride);
+    memset(&p.pro, 0, sizeof(p.pro));
     p.x = x; p.w = nullptr; p.wq = (const unsigned short*)w_planes; p.wq_stride = plane_stride; p.bias = bias; p.y = y;
     p.in_scale = in_scale; p.in_shift = in_shift; p.res1 = res1; p.res2 = res2; p.stats = stats_partial;
     p.in_relu = in_relu;

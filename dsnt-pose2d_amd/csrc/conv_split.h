@@ -71,4 +71,7 @@ struct ConvP {
     int M, K, mtiles, ntiles;
     // optional: the launch's last workgroup finishes the BatchNorm bookkeeping over `stats` (bn_tail.h)
     BnTailP tail;
+    // optional (pro.partial != null): the BatchNorm of the A operand is finalised in this launch's prologue — every
+    // workgroup writes in_scale / in_shift (= pro.scale / pro.shift) itself before it reads them (bn_tail.h)
+    BnProP pro;
 };

@@ -5,6 +5,7 @@
 // reduction is produced (partials are combined in fp64 by the finalise kernels: deterministic,
 // no atomics).
 #include "common.h"
+#include <string.h>
 #include "bn_tail.h"
 
 #define TILE_ROWS 128
@@ -466,8 +467,13 @@ template <bool FIXED>
 __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const float4* __restrict__ x,
                                         const float4* __restrict__ scale, const float4* __restrict__ shift,
                                         const float4* __restrict__ mean, const float4* __restrict__ invstd,
-                                        const float4* __restrict__ coef, int relu, float4* dx,
-                                        int accumulate, long n4, int C4, unsigned* __restrict__ amax) {
+                                        const float4* coef, int relu, float4* dx,
+                                        int accumulate, long n4, int C4, unsigned* __restrict__ amax, BnBwdProP pro) {
+    if (pro.partial) {                   // dsnt_bn_act_bwd_apply_pro: coef / dgamma / dbeta from the tile sums, here
+        __shared__ double pro_sh[256];
+        bn_pro_backward<256>(pro, pro_sh, blockIdx.x == 0);
+        __syncthreads();                 // this workgroup's stores to coef are visible to its loads below
+    }
     float am = 0.f;
     const long stride = (long)gridDim.x * blockDim.x;
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -510,7 +516,8 @@ __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const flo
 
 static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, const float* coef, int relu, float* dx,
-                                 int accumulate, int64_t M, int C, float* amax, void* stream);
+                                 int accumulate, int64_t M, int C, float* amax, void* stream,
+                                 const BnBwdProP* pro = nullptr);
 
 extern "C" int dsnt_bn_act_bwd_apply_amax(const float* da, const float* x, const float* scale,
                                           const float* shift, const float* mean, const float* invstd,
@@ -538,26 +545,47 @@ extern "C" int dsnt_bn_act_bwd_apply(const float* da, const float* x, const floa
 
 static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, const float* coef, int relu, float* dx,
-                                 int accumulate, int64_t M, int C, float* amax, void* stream) {
+                                 int accumulate, int64_t M, int C, float* amax, void* stream, const BnBwdProP* pro) {
     DSNT_REQUIRE(da && x && scale && shift && mean && invstd && coef && dx && M > 0 && C > 0,
                  DSNT_ERR_ARG, "dsnt_bn_act_bwd_apply: bad argument");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(da) && dsnt_aligned16(x) && dsnt_aligned16(dx) &&
                  dsnt_aligned16(coef), DSNT_ERR_ALIGN, "dsnt_bn_act_bwd_apply: alignment");
     const long n4 = (long)M * C / 4;
-    const int grid = flat_grid(n4, 256);
+    int grid = flat_grid(n4, 256);
+    BnBwdProP q;
+    memset(&q, 0, sizeof(q));
+    if (pro) {
+        q = *pro;
+        // every workgroup re-reads the tile sums in its prologue: few, fat workgroups (these launches are latency-bound)
+        if (grid > 128) grid = 128;
+    }
     if (((long)grid * 256) % (C / 4) == 0)
         DSNT_LAUNCH(bn_act_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0,
                     (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
                     (const float4*)shift, (const float4*)mean, (const float4*)invstd,
-                    (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax);
+                    (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax, q);
     else
         DSNT_LAUNCH(bn_act_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0,
                     (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
                     (const float4*)shift, (const float4*)mean, (const float4*)invstd,
-                    (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax);
+                    (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax, q);
     DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_apply");
 }
 
+// The same with dsnt_bn_bwd_finalize folded into its prologue (tile sums of <= 64 KB: the 8x8 / 4x4 hourglass levels,
+// where a finalise launch between two 10-us kernels costs the chain ~8 us): every workgroup sums partial[tiles][2][C]
+// itself (fp64, fixed order) into coef, workgroup 0 also writes dgamma / dbeta (+= with accumulate_params).
+extern "C" int dsnt_bn_act_bwd_apply_pro(const float* da, const float* x, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, const float* partial, int ntiles,
+                                         float* dgamma, float* dbeta, int accumulate_params, float* coef, int relu,
+                                         float* dx, int accumulate, int64_t M, int C, float* amax, void* stream) {
+    DSNT_REQUIRE(partial && ntiles > 0 && coef && C <= 256 && (long)ntiles * C <= 16384, DSNT_ERR_ARG,
+                 "dsnt_bn_act_bwd_apply_pro: needs partial sums of at most 256 channels / 128 KB and a coef buffer");
+    BnBwdProP q;
+    q.partial = partial; q.tiles = ntiles; q.C = C; q.invM = 1.0 / (double)M;
+    q.dgamma = dgamma; q.dbeta = dbeta; q.accumulate = accumulate_params; q.coef = coef;
+    return bn_act_bwd_apply_impl(da, x, scale, shift, mean, invstd, coef, relu, dx, accumulate, M, C, amax, stream, &q);
+}
 // ---------------------------------------------------------------- pooling / upsampling
 __global__ void maxpool2_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y,
                                     uchar4* __restrict__ idx, int N, int H, int W, int C4) {

@@ -35,6 +35,17 @@ class BnBwdEpilogue(C.Structure):
 BP = C.POINTER(BnBwdEpilogue)
 
 
+class BnPrologue(C.Structure):
+    """dsnt_bn_prologue: a BatchNorm finalised in the prologue of the launch that consumes it."""
+    _fields_ = [('partial', C.c_void_p), ('tiles', C.c_int), ('C', C.c_int), ('M', C.c_int64),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
+                ('momentum', C.c_float), ('eps', C.c_float),
+                ('mean', C.c_void_p), ('invstd', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p)]
+
+
+PP = C.POINTER(BnPrologue)
+
+
 class BnTail(C.Structure):
     """dsnt_bn_tail: the BatchNorm bookkeeping a statistics-producing launch finishes in its last workgroup."""
     _fields_ = [('mode', C.c_int), ('accumulate', C.c_int), ('counters', C.c_void_p), ('level2', C.c_void_p),
@@ -100,6 +111,8 @@ SIGNATURES = {
     'dsnt_bn_eval_prep': [P, I, P],
     'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
     'dsnt_bn_act_bwd_apply_amax': [P, P, P, P, P, P, P, I, P, I, L, I, P, P],
+    'dsnt_bn_act_bwd_apply_pro': [P, P, P, P, P, P, P, I, P, P, I, P, I, P, I, L, I, P, P],
+    'dsnt_conv_fwd_pro': [P, P, P, P, PP, I, P, P, P, GP, TP, P],
     'dsnt_fill_zero': [P, L, P],
     'dsnt_axpy_amax': [P, P, F, I, L, P, P],
     'dsnt_maxpool2_bwd_amax': [P, P, P, I, I, I, I, I, P, P],
@@ -156,6 +169,7 @@ PLAIN = {
     'dsnt_conv_wgrad_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_splits': (I, [GP]),
     'dsnt_conv_wgrad_halo_ok': (I, [GP]),
+    'dsnt_conv_fwd_pro_ok': (I, [GP, I, I]),
     'dsnt_conv_wgrad_f16x3_splits': (I, [GP, I]),
     'dsnt_conv_wgrad_f16x3_ws_floats': (L, [GP, I]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvGeom, BnBwdEpilogue, BnTail
+from ._lib import ConvGeom, BnBwdEpilogue, BnTail, BnPrologue
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -76,7 +76,7 @@ class BnParams:
 
 class Normed:
     """x seen through a BatchNorm(+ReLU): what a fused conv prologue needs."""
-    __slots__ = ('x', 'bn', 'mean', 'invstd', 'scale', 'shift', 'relu', 'abound')
+    __slots__ = ('x', 'bn', 'mean', 'invstd', 'scale', 'shift', 'relu', 'abound', 'pending')
 
 
 class Tape:
@@ -144,6 +144,12 @@ class Tape:
         # max-pool / upsample+add write the BatchNorm statistics of their output themselves (DSNT_FUSE_OP_STATS=0:
         # a separate dsnt_bn_stats pass when a BatchNorm asks for them)
         self.fuse_op_stats = True
+        # BatchNorm finalisation of few-tile statistics inside the consumer's prologue (DSNT_FUSE_FINALIZE=0: separate launches)
+        self.fuse_finalize = os.environ.get('DSNT_FUSE_FINALIZE', '1') != '0'
+        # ... up to this many (tiles x channels) of partial sums.  Measured (tools/bench_bn_prologue.py, MI355X): a finalise
+        # launch costs the chain 4-5 us; the prologue costs every workgroup of the consumer 2.8 us at 16 KB of partials,
+        # 3.2 us at 32 KB, 4.5 us at 64 KB (no gain), 9 us at 128 KB (a loss): fused up to 32 KB
+        self.fuse_finalize_max = 4096
         # fp16x3 (default; DSNT_SPLIT=bf16x6 turns it off): two fp16 planes + three MFMAs instead of three bf16 planes + six, where an operand
         # bound is available without a host round-trip: train-mode BN+ReLU operands (bound from the BN parameters) and
         # weights (amax in the per-step prep launch)
@@ -380,7 +386,7 @@ class Tape:
                     else:
                         self.bytes_bwd += nb
                 conv.append(_lib.ptr(a))
-            elif isinstance(a, (ConvGeom, BnBwdEpilogue, BnTail)):
+            elif isinstance(a, (ConvGeom, BnBwdEpilogue, BnTail, BnPrologue)):
                 self._keep.append(a)
                 conv.append(C.byref(a))
             else:
@@ -686,6 +692,7 @@ class Tape:
         n.x, n.bn, n.relu = x, bn, relu
         n.abound = None
         n.mean, n.invstd, n.scale, n.shift = (self.empty(bn.C) for _ in range(4))
+        n.pending = None
         if self.training:
             part, tiles = self.ensure_stats(x)
             tl = x.stats_tail
@@ -695,6 +702,10 @@ class Tape:
                 tl.running_mean, tl.running_var = _lib.ptr(bn.rmean), _lib.ptr(bn.rvar)
                 tl.momentum, tl.eps = bn.momentum, bn.eps
                 tl.out0, tl.out1, tl.out2, tl.out3 = (_lib.ptr(v) for v in (n.mean, n.invstd, n.scale, n.shift))
+            elif self.fuse_finalize and bn.C <= 256 and tiles * bn.C <= self.fuse_finalize_max:
+                # few tiles (the 8x8 / 4x4 levels): the launch that CONSUMES this BatchNorm finalises it in its prologue
+                # (`conv`); any other first reader materialises it with the usual launch (`materialize`)
+                n.pending = (part, tiles)
             else:
                 self.f('dsnt_bn_finalize', part, tiles, x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
                        bn.momentum, bn.eps, 1, n.mean, n.invstd, n.scale, n.shift)
@@ -705,6 +716,15 @@ class Tape:
                                        n.mean.data_ptr(), n.invstd.data_ptr(), n.scale.data_ptr(), n.shift.data_ptr(),
                                        bn.C, bits])
         return n
+
+    def materialize(self, n):
+        """The separate finalise launch of a BatchNorm whose finalisation was left to its consumer (`norm`)."""
+        if n.pending is not None:
+            part, tiles = n.pending
+            n.pending = None
+            bn = n.bn
+            self.f('dsnt_bn_finalize', part, tiles, n.x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
+                   bn.momentum, bn.eps, 1, n.mean, n.invstd, n.scale, n.shift)
 
     def bwd_tail(self, n, tiles):
         """dsnt_bn_tail (mode 1) for a data-gradient launch with the BatchNorm-backward epilogue of Normed n: its last
@@ -734,12 +754,19 @@ class Tape:
             part = self.scratch('bnpart', tiles * 2 * bn.C).view(-1)
             self.b('dsnt_bn_act_bwd_reduce', da, x.buf, n.scale, n.shift, n.mean, n.invstd, relu, part,
                    x.M, bn.C)
+        fused = (not finalised) and self.fuse_finalize and bn.C <= 256 and tiles * bn.C <= self.fuse_finalize_max
         if not finalised:
             acc_p = 1 if bn.uses > 0 else 0
             bn.uses += 1
-            self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef)
+            if not fused:
+                self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef)
         buf, acc = self.grad_target(x, amax='apply')
-        if x.grad_amax is not None:
+        if fused:
+            # few tiles: the apply launch sums them itself in its prologue (coef) and writes dgamma / dbeta
+            coef = self.empty(2 * bn.C)          # private: the launch writes it (a shared scratch could still be in use)
+            self.b('dsnt_bn_act_bwd_apply_pro', da, x.buf, n.scale, n.shift, n.mean, n.invstd, part, tiles,
+                   bn.ggamma, bn.gbeta, acc_p, coef, relu, buf, acc, x.M, bn.C, x.grad_amax)
+        elif x.grad_amax is not None:
             self.b('dsnt_bn_act_bwd_apply_amax', da, x.buf, n.scale, n.shift, n.mean, n.invstd, coef, relu,
                    buf, acc, x.M, bn.C, x.grad_amax)
         else:
@@ -775,6 +802,8 @@ class Tape:
         if use6 and p.wq16 is not None:
             x_amax = self.operand_amax_bn(src) if normed else self.operand_amax(x)
         use16 = use6 and self.use_f16x3 and p.wq16 is not None and ((self.training and normed) or x_amax is not None)
+        if normed and (use16 or use6):
+            self.materialize(src)
         if use16:
             self.f16_weights(p)
             ab = self.f16_bn_bound(src) if (normed and self.training) else x_amax
@@ -785,7 +814,19 @@ class Tape:
         elif use6:
             self.f('dsnt_conv_fwd_bf16x6_ex', x.buf, p.wq, p.wq_stride, p.b, y.buf, sc, sh, relu, r1, r2, part, g,
                    None, tail)
+        elif normed and src.pending is not None and self.lib.dsnt_conv_fwd_pro_ok(C.byref(g), src.pending[1], src.bn.C):
+            # the BatchNorm of this operand has few statistics tiles: finalised in this launch's prologue
+            spart, stiles = src.pending
+            src.pending = None
+            bn = src.bn
+            pro = BnPrologue(_lib.ptr(spart), stiles, bn.C, x.M, _lib.ptr(bn.gamma), _lib.ptr(bn.beta), _lib.ptr(bn.rmean),
+                             _lib.ptr(bn.rvar), bn.momentum, bn.eps, _lib.ptr(src.mean), _lib.ptr(src.invstd),
+                             _lib.ptr(src.scale), _lib.ptr(src.shift))
+            self._keep.extend((spart, src.mean, src.invstd, src.scale, src.shift))
+            self.f('dsnt_conv_fwd_pro', x.buf, p.w, p.b, y.buf, pro, relu, r1, r2, part, g, tail)
         else:
+            if normed:
+                self.materialize(src)
             self.f('dsnt_conv_fwd_ex', x.buf, p.w, p.b, y.buf, sc, sh, relu, r1, r2, part, g, None, tail)
         if not self.training:
             return y
@@ -956,6 +997,7 @@ class Tape:
     def bn_act(self, x, bn, relu=True, name=''):
         """Materialised y = relu?(bn(x)) (the stem: hourglass.py:157-159)."""
         n = self.norm(x, bn, relu)
+        self.materialize(n)
         y = self.act(x.N, x.H, x.W, x.C, name)
         big = self.use_f16x3 and y.M >= self.bf16x6_min_rows
         if self.training and self.fuse_op_stats:
@@ -1025,6 +1067,7 @@ class Tape:
         y = self.act(x.N, x.H, x.W, x.C, name)
         if os.environ.get('DSNT_DEBUG_NO_RELU'):
             relu = False
+        self.materialize(n)
         self.f('dsnt_bn_add_act_fwd', x.buf, n.scale, n.shift, skip.buf, 1 if relu else 0, y.buf, x.M, x.C)
         if self.training:
             def backward():

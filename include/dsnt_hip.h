@@ -68,6 +68,21 @@ typedef struct {
 /* m-tiles whose partial rows one first-level reduction covers (32) */
 int dsnt_bn_tail_group(void);
 
+/* BatchNorm finalisation folded into the prologue of the launch that CONSUMES the BatchNorm (the low-resolution
+ * hourglass levels, /root/reference/src/dsnt/hourglass.py:33-43 between two 10-us convolutions: a separate
+ * dsnt_bn_finalize launch costs the dependency chain ~8 us there, ~120 of them 1.0 ms of an hg2 step).  Every
+ * workgroup sums partial[tiles][2][C] itself (fp64, fixed order), writes mean / invstd / scale / shift — which the
+ * launch then reads as its in_scale / in_shift and backward reads later — and workgroup 0 moves the running
+ * statistics.  Limits: C <= 256, tiles * C <= 16384 (dsnt_conv_fwd_pro_ok). */
+typedef struct dsnt_bn_prologue {
+    const float* partial; int tiles, C;
+    int64_t M;                                   /* rows the sums run over */
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;     /* may be NULL */
+    float momentum, eps;
+    float* mean; float* invstd; float* scale; float* shift;
+} dsnt_bn_prologue;
+
 int dsnt_version(void);
 const char* dsnt_last_error(void);
 
@@ -200,6 +215,14 @@ int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y
                      const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail, void* stream);
 /* (`tail`, here and in the other _ex variants: the BatchNorm bookkeeping over stats_partial done by the launch's last
  * workgroup — forward statistics of the consumer BatchNorm, or with `bnb` the dgamma / dbeta / coef of the backward.) */
+
+/* dsnt_conv_fwd_ex with the BatchNorm of its A operand finalised in the launch's prologue (fp32-MFMA path: the
+ * small-M kernels); in_scale / in_shift are pro->scale / pro->shift.  dsnt_conv_fwd_pro_ok(g, tiles, C) != 0 if the
+ * limits hold for this geometry. */
+int dsnt_conv_fwd_pro_ok(const dsnt_conv_geom* g, int tiles, int C);
+int dsnt_conv_fwd_pro(const float* x, const float* w, const float* bias, float* y, const dsnt_bn_prologue* pro,
+                      int in_relu, const float* res1, const float* res2, float* stats_partial,
+                      const dsnt_conv_geom* g, const dsnt_bn_tail* tail, void* stream);
 
 /* Rows per stats_partial tile that dsnt_conv_fwd uses for this geometry (128 or 32): the
  * caller sizes stats_partial as [ceil(M/bm)][2][Cout] and hands ceil(M/bm) to dsnt_bn_finalize. */
@@ -389,6 +412,13 @@ int dsnt_bn_act_bwd_apply(const float* da, const float* x, const float* scale,
 int dsnt_bn_act_bwd_apply_amax(const float* da, const float* x, const float* scale, const float* shift,
                                const float* mean, const float* invstd, const float* coef, int relu, float* dx,
                                int accumulate, int64_t M, int C, float* amax, void* stream);
+/* dsnt_bn_act_bwd_apply(_amax) with dsnt_bn_bwd_finalize folded into its prologue (same limits as dsnt_bn_prologue):
+ * partial[ntiles][2][C] = (sum dz, sum dz * xhat) tiles; coef is scratch of 2 * C floats the launch fills and reads;
+ * dgamma / dbeta are written (+= with accumulate_params) by workgroup 0. */
+int dsnt_bn_act_bwd_apply_pro(const float* da, const float* x, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, const float* partial, int ntiles,
+                              float* dgamma, float* dbeta, int accumulate_params, float* coef, int relu,
+                              float* dx, int accumulate, int64_t M, int C, float* amax, void* stream);
 int dsnt_fill_zero(float* p, int64_t n, void* stream);
 /* The other kernels that (re)write a whole gradient tensor, with the same amax side output: a tensor written by several
  * of them in turn is bounded by the maximum over their amaxes (each rewrites all of it), so gradients accumulated along

@@ -857,6 +857,76 @@ def test_bn_backward_epilogue_with_relu_vs_autograd(case, path, use_tail):
     assert (dx.cpu().permute(0, 3, 1, 2).double() - xr.grad).abs().max().item() <= tol * s_dx
 
 
+@pytest.mark.parametrize('shape', [(2, 8, 8, 128, 128, 3), (2, 8, 8, 256, 128, 1), (4, 16, 16, 128, 256, 1), (2, 4, 4, 128, 128, 3)],
+                         ids=['ksplit_3x3', 'ksplit_1x1_256', 'tiled_1x1_1024rows', 'ksplit_4x4'])
+def test_batchnorm_finalised_in_the_consumers_prologue(shape):
+    """dsnt_conv_fwd_pro (the BatchNorm of the A operand finalised in the convolution's own prologue: the 8x8 / 4x4
+    hourglass levels) == dsnt_bn_finalize + dsnt_conv_fwd_ex: the four BatchNorm vectors to fp32 rounding of the same
+    fp64 sums (another summation order), the running statistics moved exactly once, the convolution output to 1e-6 of
+    its scale; and dsnt_bn_act_bwd_apply_pro == dsnt_bn_bwd_finalize + dsnt_bn_act_bwd_apply (dgamma / dbeta, their
+    accumulate form, dx)."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call, BnPrologue
+    dev = torch.device('cuda:0')
+    N, H, W, Cin, Cout, k = shape
+    g = _geom(N, H, W, Cin, Cout, k, k, 1, k // 2, 1)
+    M = N * H * W
+    tag = 'pro' + '_'.join(map(str, shape))
+    x = synthetic.tensor(tag + 'x', (N, H, W, Cin), seed=31).to(dev)
+    w = (synthetic.tensor(tag + 'w', (Cout, k, k, Cin), seed=31) * 0.05).to(dev)
+    b = (synthetic.tensor(tag + 'b', (Cout,), seed=31) * 0.1).to(dev)
+    gamma = (synthetic.tensor(tag + 'g', (Cin,), seed=31, kind='uniform') + 1.5).to(dev)
+    beta = (synthetic.tensor(tag + 'be', (Cin,), seed=31) * 0.2).to(dev)
+    tiles = (M + 31) // 32          # 32-row tiles, as the small-M convolution kernels write them
+    part = torch.empty(tiles, 2, Cin, device=dev)
+    xr = x.view(-1, Cin)
+    for t in range(tiles):          # per-tile sums as a producer's epilogue leaves them
+        blk = xr[t * 32:(t + 1) * 32]
+        part[t, 0], part[t, 1] = blk.sum(0), (blk * blk).sum(0)
+    assert _lib.fn('dsnt_conv_fwd_pro_ok')(C.byref(g), tiles, Cin) == 1
+    bm = _lib.fn('dsnt_conv_fwd_bm')(C.byref(g))
+    otiles = (M + bm - 1) // bm
+
+    def vectors():
+        return [torch.full((Cin,), float('nan'), device=dev) for _ in range(4)]
+    # reference: separate launches
+    v_ref, rm_ref, rv_ref = vectors(), torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev)
+    call('dsnt_bn_finalize', ptr(part), tiles, M, Cin, ptr(gamma), ptr(beta), ptr(rm_ref), ptr(rv_ref), 0.1, 1e-5, 1,
+         *[ptr(v) for v in v_ref])
+    y_ref, st_ref = torch.empty(N, H, W, Cout, device=dev), torch.zeros(otiles, 2, Cout, device=dev)
+    call('dsnt_conv_fwd_ex', ptr(x), ptr(w), ptr(b), ptr(y_ref), ptr(v_ref[2]), ptr(v_ref[3]), 1, None, None, ptr(st_ref),
+         C.byref(g), None, None)
+    # fused
+    v, rm, rv = vectors(), torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev)
+    pro = BnPrologue(ptr(part), tiles, Cin, M, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, *[ptr(t_) for t_ in v])
+    y, st = torch.empty(N, H, W, Cout, device=dev), torch.zeros(otiles, 2, Cout, device=dev)
+    call('dsnt_conv_fwd_pro', ptr(x), ptr(w), ptr(b), ptr(y), C.byref(pro), 1, None, None, ptr(st), C.byref(g), None)
+    for a_, b_ in zip(v, v_ref):
+        assert (a_ - b_).abs().max().item() <= 2e-6 * max(1.0, b_.abs().max().item())
+    assert (rm - rm_ref).abs().max().item() <= 1e-6 and (rv - rv_ref).abs().max().item() <= 1e-6      # moved exactly once
+    assert (y - y_ref).abs().max().item() <= 1e-6 * y_ref.abs().max().item()
+    assert (st - st_ref).abs().max().item() <= 1e-5 * st_ref.abs().max().item()
+    # errors: too many channels / tiles for the prologue
+    assert _lib.fn('dsnt_conv_fwd_pro_ok')(C.byref(g), 16384 // Cin + 1, Cin) == 0
+    # ---- backward: apply with the backward finalise in its prologue
+    da = synthetic.tensor(tag + 'da', (N, H, W, Cin), seed=32).to(dev)
+    bt = (M + 127) // 128
+    bpart = torch.empty(bt, 2, Cin, device=dev)
+    call('dsnt_bn_act_bwd_reduce', ptr(da), ptr(x), ptr(v_ref[2]), ptr(v_ref[3]), ptr(v_ref[0]), ptr(v_ref[1]), 1, ptr(bpart), M, Cin)
+    for accp in (0, 1):
+        dg_ref, db_ref = torch.full((Cin,), 0.25, device=dev), torch.full((Cin,), -0.5, device=dev)
+        dg, db = dg_ref.clone(), db_ref.clone()
+        coef_ref, coef = torch.empty(2, Cin, device=dev), torch.empty(2, Cin, device=dev)
+        dx_ref, dx = torch.ones(N, H, W, Cin, device=dev), torch.ones(N, H, W, Cin, device=dev)
+        call('dsnt_bn_bwd_finalize', ptr(bpart), bt, M, Cin, ptr(dg_ref), ptr(db_ref), accp, ptr(coef_ref))
+        call('dsnt_bn_act_bwd_apply', ptr(da), ptr(x), ptr(v_ref[2]), ptr(v_ref[3]), ptr(v_ref[0]), ptr(v_ref[1]), ptr(coef_ref),
+             1, ptr(dx_ref), accp, M, Cin)
+        call('dsnt_bn_act_bwd_apply_pro', ptr(da), ptr(x), ptr(v_ref[2]), ptr(v_ref[3]), ptr(v_ref[0]), ptr(v_ref[1]), ptr(bpart),
+             bt, ptr(dg), ptr(db), accp, ptr(coef), 1, ptr(dx), accp, M, Cin, None)
+        for a_, b_ in ((dg, dg_ref), (db, db_ref), (coef, coef_ref), (dx, dx_ref)):
+            assert (a_ - b_).abs().max().item() <= 2e-6 * max(1.0, b_.abs().max().item())
+
+
 @pytest.mark.parametrize('kind', ['conv_f32_128', 'conv_f32_32x128', 'conv_ksplit', 'conv_bf16x6', 'conv_halo_f16x3',
                                   'maxpool', 'upsample'])
 def test_bn_tail_forward_matches_the_finalize_launch(kind):
