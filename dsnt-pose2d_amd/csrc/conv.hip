@@ -2294,11 +2294,24 @@ static void wgrad_plan(const dsnt_conv_geom* g, int& ktiles, int& ntiles, int& s
     rps = (int)rows;
 }
 
-extern "C" int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g) {
-    if (!g) return 0;
+static int64_t wgrad_ws_floats_plain(const dsnt_conv_geom* g) {
     int kt, nt, sp, rps;
     wgrad_plan(g, kt, nt, sp, rps);
     return (int64_t)sp * g->Cout * (g->R * g->S * g->Cin) + (int64_t)sp * g->Cout;
+}
+// Enough for ANY of the weight-gradient entry points on this geometry (the fp16x3 kernels of wgrad3.hip / wgrad1.hip cut
+// the pixels into their own, sometimes more, slabs: dsnt_conv_wgrad_f16x3_ws_floats is the exact size of that call)
+extern "C" int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g) {
+    if (!g) return 0;
+    int64_t n = wgrad_ws_floats_plain(g);
+    const int64_t per = (int64_t)g->Cout * (g->R * g->S * g->Cin) + g->Cout;
+    for (int share = 0; share < 2; ++share) {
+        const Wg3Plan p3 = dsnt_wg3_plan(g, share != 0);
+        if (p3.ok && p3.nslabs * per > n) n = p3.nslabs * per;
+        const Wg1Plan p1 = dsnt_wg1_plan(g, share != 0);
+        if (p1.ok && p1.nsplits * per > n) n = p1.nsplits * per;
+    }
+    return n;
 }
 
 extern "C" int dsnt_conv_wgrad_splits(const dsnt_conv_geom* g) {
@@ -2457,7 +2470,7 @@ extern "C" int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int 
     if (pl.ok) return (int64_t)pl.nslabs * g->Cout * (9 * g->Cin) + (int64_t)pl.nslabs * g->Cout;
     const Wg1Plan p1 = dsnt_wg1_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
     if (p1.ok) return (int64_t)p1.nsplits * g->Cout * g->Cin + (int64_t)p1.nsplits * g->Cout;
-    return dsnt_conv_wgrad_ws_floats(g);
+    return wgrad_ws_floats_plain(g);
 }
 extern "C" int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g) { return g ? dsnt_wg3_plan(g, false).ok : 0; }
 

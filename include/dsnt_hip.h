@@ -283,7 +283,8 @@ int dsnt_conv_pack_dgrad_all(const int* table, int nconv, const float* params, f
                              void* planes, int64_t total, void* stream);
 
 /* Weight / bias gradient: dw[Cout][R][S][Cin] = sum_m act(x)[m, (r,s,c)] * dy[m, cout],
- * dbias[cout] = sum_m dy.  `ws` is caller workspace of dsnt_conv_wgrad_ws_floats() floats.
+ * dbias[cout] = sum_m dy.  `ws` is caller workspace of dsnt_conv_wgrad_ws_floats() floats (enough for ANY of the
+ * weight-gradient entry points on that geometry; dsnt_conv_wgrad_f16x3_ws_floats is the exact size of that call).
  * accumulate: bit 0 adds into dw/dbias instead of overwriting; bit 1 (DSNT_WGRAD_SHARE_CHIP, split-precision kernels):
  * the launch shares the chip with a dependency chain on another stream (loss.backward() of bin/train.py:380: weight
  * gradients feed nothing downstream) and keeps to ONE workgroup per CU, so that the chain's small kernels find a slot
