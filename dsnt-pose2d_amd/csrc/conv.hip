@@ -21,6 +21,7 @@
 #include "conv_split.h"
 #include "wgrad3.h"
 #include "gemm1.h"
+#include "conv3s.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -1421,7 +1422,8 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
                           const float* in_scale, const float* in_shift, int in_relu,
                           const float* res1, const float* res2, float* stats_partial,
                           const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, const dsnt_bn_tail* g_tail,
-                          void* stream, const float* a_bound = nullptr, const float* w_bound = nullptr) {
+                          void* stream, const float* a_bound = nullptr, const float* w_bound = nullptr,
+                          bool stream_w = false) {
     if (int e = check_geom(g, "dsnt_conv_fwd_bf16x6")) return e;
     DSNT_REQUIRE(!g_bnb || (g_bnb->x && g_bnb->scale && g_bnb->shift && g_bnb->mean && g_bnb->invstd &&
                             stats_partial && !res1 && !res2 && !bias), DSNT_ERR_ARG,
@@ -1459,6 +1461,12 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     hipStream_t st = (hipStream_t)stream;
     DSNT_REQUIRE(!((p.tail.amax || p.tail.amax_bn) && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
     p.a_bound = a_bound; p.w_bound = w_bound;
+    if (stream_w) {                  // 3x3, weights in the stream layout: the symmetric kernel (conv3s.hip)
+        DSNT_REQUIRE(dsnt_conv3s_ok(p), DSNT_ERR_SHAPE, "dsnt_conv_fwd_f16x3_stream: launch not supported (dsnt_conv_fwd_stream_ok; "
+                     "no second residual, no BatchNorm tail counters)");
+        dsnt_conv3s_launch(p, in_scale != nullptr, st);
+        DSNT_CHECK_LAUNCH("dsnt_conv_fwd_f16x3_stream");
+    }
     if (a_bound) {                   // fp16x3: two fp16 weight planes, operand bounds in device memory
         const int ntw = dsnt_gemm1_cfg(p);      // large 1x1 convolutions: the streaming kernel (gemm1.hip)
         if (ntw > 0) {
@@ -1504,6 +1512,19 @@ extern "C" int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int6
     return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
                           stats_partial, g, bnb, tail, stream, a_bound, w_bound);
 }
+
+// The same call with the weight planes in the STREAM layout of dsnt_f16_prep_weights (3x3 convolutions the symmetric
+// kernel of conv3s.hip runs: dsnt_conv_fwd_stream_ok)
+extern "C" int dsnt_conv_fwd_f16x3_stream(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
+                                          const float* a_bound, const float* bias, float* y, const float* in_scale,
+                                          const float* in_shift, int in_relu, const float* res1, const float* res2,
+                                          float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
+                                          const dsnt_bn_tail* tail, void* stream) {
+    DSNT_REQUIRE(a_bound && w_bound, DSNT_ERR_ARG, "dsnt_conv_fwd_f16x3_stream: the operand bounds (device scalars) are required");
+    return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
+                          stats_partial, g, bnb, tail, stream, a_bound, w_bound, true);
+}
+extern "C" int dsnt_conv_fwd_stream_ok(const dsnt_conv_geom* g) { return dsnt_conv3s_geom_ok(g) ? 1 : 0; }
 
 // max |src[i]| -> out[0] (bit pattern of a non-negative float: integer max is float max)
 __global__ void amax_kernel(const float4* __restrict__ src, unsigned* __restrict__ out, long n4) {
@@ -1555,8 +1576,10 @@ extern "C" int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t 
 }
 
 // Per-step preparation of the fp16x3 operands of MANY tensors in one launch each (table rows of int64):
-//   dsnt_f16_prep_weights: row {src float*, dst fp16 plane 0*, bound float*, count (multiple of 4), plane stride}:
-//     one workgroup per row: bound = max|src|, then dst = two fp16 planes of src * pow2_scale(bound);
+//   dsnt_f16_prep_weights: row {src float*, dst fp16 plane 0*, bound float*, count (multiple of 4), plane stride,
+//     stream Cout, stream Cin}: one workgroup per row: bound = max|src|, then dst = two fp16 planes of src * pow2_scale(bound);
+//     stream Cout > 0: src is an OHWI 3x3 filter [Cout][3][3][Cin] and the planes are written in STREAM order
+//     [Cin / 16][9 taps][Cout][16] — the K-step sequence of conv3s.hip, each step one contiguous block;
 //   dsnt_f16_prep_bn_bounds: row {gamma float*, beta float*, out float*, C, float bits of sqrt(M)}: out =
 //     max_c(|gamma_c| sqrt(M) + |beta_c|) >= every |relu?(bn(x))| of a train-mode BatchNorm over M samples
 //     (|(x - mean) / std| <= sqrt(M - 1) for the biased batch variance).
@@ -1566,11 +1589,13 @@ extern "C" int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t 
 #define PREP_T 1024
 __global__ __launch_bounds__(PREP_T) void f16_prep_weights_kernel(const long long* __restrict__ table) {
     __shared__ float red[PREP_T / 64];
-    const long long* t = table + (size_t)blockIdx.x * 5;
+    const long long* t = table + (size_t)blockIdx.x * 7;
     const float4* src = reinterpret_cast<const float4*>(t[0]);
     uint2* dst = reinterpret_cast<uint2*>(t[1]);
     float* bound = reinterpret_cast<float*>(t[2]);
     const long n4 = (long)t[3] / 4, stride4 = (long)t[4] / 4;
+    const int s_cout = (int)t[5], s_cin = (int)t[6];       // > 0: OHWI [Cout][9][Cin] -> stream order [Cin/16][9][Cout][16]
+    const int s_k4 = 9 * s_cin / 4, s_cin4 = s_cin / 4;
     float m = 0.f;
     long i = threadIdx.x;
     for (; i + 3 * PREP_T < n4; i += 4 * PREP_T) {
@@ -1591,6 +1616,11 @@ __global__ __launch_bounds__(PREP_T) void f16_prep_weights_kernel(const long lon
         v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         uint2 a, b;
         split4h(v, a, b);
+        if (s_cout > 0) {
+            const int n = (int)(j / s_k4), k4 = (int)(j - (long)n * s_k4);
+            const int tap = k4 / s_cin4, c4 = k4 - tap * s_cin4;
+            j = ((long)((c4 >> 2) * 9 + tap) * s_cout + n) * 4 + (c4 & 3);
+        }
         dst[j] = a; dst[stride4 + j] = b;
     };
     i = threadIdx.x;

@@ -1,0 +1,456 @@
+// 3x3 / stride 1 / pad 1 convolutions of the full-resolution levels (hourglass.py:22-23: conv2 of every Bottleneck, forward
+// and as data gradients) on the fp16 matrix cores, fp16x3 split — the SYMMETRIC successor of conv3x3_bf16x6_kernel (conv.hip).
+//
+// What that kernel lost (profiles/r02_timeline_halo.txt, r02_pmc_issue_accounting.txt): its four loader waves share the
+// SIMDs with the four MFMA waves, lose the issue arbitration against them and arrive last at 80 % of the per-K-step
+// barriers (803 of 1993 cycles per step are barrier wait on the MFMA waves); prologue and epilogue (LDS transposition of
+// the 128 x 128 result) are another 18 k cycles per tile with the matrix pipe idle.  Here:
+//   * four waves, ALL alike: every wave copies its share of the weights and of the input halo between its own MFMAs
+//     (an MFMA holds the vector issue port for 8 of its 32 cycles — the staging work of a step fits beside them);
+//   * a tile is a 4 x 32 patch of output pixels x all Cout (64 / 128) columns; the (4+2) x (32+2) input halo of a
+//     16-channel chunk is transformed (BatchNorm + ReLU, operand scale) and split ONCE into LDS, double-buffered;
+//   * the weights come pre-split in STREAM order ([chunk][tap][Cout][16]: dsnt_f16_prep_weights, row flag): a K-step
+//     pair is one contiguous 16 KB block, copied with coalesced 16-byte loads one pair ahead into a two-slot ring;
+//   * ONE barrier per pair of K-steps (24 MFMAs per wave), placed between the two steps: the fragments of the step
+//     after the barrier are read while the MFMAs of the step before it run, so no fragment read is exposed;
+//   * workgroups are persistent: the weight stream wraps around and the next tile's first halo chunk is staged by the
+//     regular schedule of the last chunk pair — a tile has no prologue; the epilogue works from the MFMA result layout
+//     (a register = 2 pixels x 32 consecutive channels = two 128-byte runs; no LDS transposition), residual loads
+//     software-pipelined over the wave's tiles (as gemm1.hip).
+// Same K order (16-channel chunk, tap) and MFMA order as conv3x3_bf16x6_kernel<.., F16>: the convolution sums are
+// bit-identical to that kernel's; the per-tile column statistics are summed in another order.
+// Contract: conv_fwd_bf16x6_kernel<..., F16> minus the second residual and the BatchNorm tail counters (dsnt_conv3s_ok).
+#include "conv3s.h"
+#include <stdlib.h>
+
+typedef unsigned c3_u32x4 __attribute__((ext_vector_type(4)));
+
+#define C3_PH 4
+#define C3_PW 32
+#define C3_HW (C3_PW + 2)
+#define C3_HPX ((C3_PH + 2) * C3_HW)        /* 204 halo pixels */
+#define C3_AP 48                            /* bytes per halo pixel and plane: 16 fp16 + 16 (conflict-free ds_read_b128) */
+#define C3_APL (C3_HPX * C3_AP)
+#define C3_ABUF (2 * C3_APL)
+#define C3_BP 80                            /* bytes per weight row and plane of a slot: 2 x 16 fp16 + 16 */
+#define C3_ITEMS (C3_HPX * 4)
+#ifndef C3_EXP
+#define C3_EXP 0       /* timing experiments (results invalid): 1 no weight reloads, 2 no loop barrier, 3 no weight stores, 4 no halo staging, 5 no MFMA */
+#endif
+
+// MODE: 0 no residual, 1 res1, 3 the BatchNorm-backward epilogue of a data-gradient launch (res1 = the BatchNorm input x)
+template <int CO, bool PRO, int MODE>
+__global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
+    constexpr int WN = CO / 64, WM = 4 / WN, TM = 4 / WM, TN = 2;
+    constexpr int BPL = CO * C3_BP, BSLOT = 2 * BPL;
+    constexpr int NJB = CO / 32;                // 16-byte weight units per thread and K-step pair
+    constexpr int UPP = 4 * CO;                 // units per plane and pair
+    const unsigned OOB = 0xF0000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char c3_smem[];
+    unsigned char* As = c3_smem;                // [2 chunk buffers][2 planes][204 px][48]
+    unsigned char* Bs = c3_smem + 2 * C3_ABUF;  // [2 slots][2 planes][CO][80]
+    float* SS = reinterpret_cast<float*>(Bs + 2 * BSLOT);          // PRO: [2][Cin] BN scale / shift x operand scale
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nchunks = p.Cin >> 4;             // even
+    const int npairs = nchunks * 9 / 2;
+    const int tws = p.W / C3_PW, ths = p.H / C3_PH;
+    const float sa = pow2_scale(bound64(p.a_bound)), sw = pow2_scale(bound64(p.w_bound));
+    const float osc = 1.f / (sa * sw);
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.M * p.Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.wq), 0, (int)(((size_t)p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000);
+    const int ybytes = (int)((size_t)p.M * p.Cout * 4u);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res1 ? p.res1 : p.y), 0, ybytes, 0x00020000);
+    const unsigned rowbytes = (unsigned)p.Cout * 4u;
+
+    // ---- halo staging: item = tid + 256 j (< 816) -> halo pixel item >> 2, 4-channel quad item & 3
+    const int kc = tid & 3;
+    unsigned aoffs[4], aok = 0;
+    auto set_tile = [&](const int vv) {         // global offsets of the tile with virtual index vv; returns its first pixel
+        aok = 0;
+        int img = 0, th = 0, tw = 0;
+        const bool live = vv < ntiles;
+        if (live) {
+            int tile;
+            xcd_remap(vv, ntiles, tile);
+            tw = tile % tws;
+            th = (tile / tws) % ths;
+            img = tile / (tws * ths);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int px = (tid >> 2) + 64 * j;
+            const int hy = px / C3_HW, hx = px - hy * C3_HW;
+            const int ih = th * C3_PH - 1 + hy, iw = tw * C3_PW - 1 + hx;
+            const bool in = live && px < C3_HPX && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            aoffs[j] = in ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + kc * 4) * 4u : OOB;
+            aok |= (in ? 1u : 0u) << j;
+        }
+        return (img * p.H + th * C3_PH) * p.W + tw * C3_PW;
+    };
+    c3_u32x4 ra[4];
+    const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
+    if (PRO) {
+        for (int k = tid; k < p.Cin; k += 256) {
+            SS[k] = p.in_scale[k] * sa;                             // the operand scale rides in the BN vectors
+            SS[p.Cin + k] = p.in_shift[k] * sa;
+        }
+        __syncthreads();
+    }
+    auto gloadA = [&](const int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoffs[j], c * 64, 0);
+    };
+    auto storeA = [&](const int buf, const int c) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRO) {
+            sc = *reinterpret_cast<const float4*>(SS + c * 16 + kc * 4);
+            sh = *reinterpret_cast<const float4*>(SS + p.Cin + c * 16 + kc * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j == 3 && tid >= C3_ITEMS - 768) continue;
+            float4 v = make_float4(__uint_as_float(ra[j].x), __uint_as_float(ra[j].y),
+                                   __uint_as_float(ra[j].z), __uint_as_float(ra[j].w));
+            if (PRO) {
+                // BN FMAs; ReLU + zero padding (applied after BN + ReLU) as one median per element
+                const bool ok = (aok >> j) & 1u;
+                const float lo = ok ? lo_valid : 0.f, hi = ok ? __builtin_inff() : 0.f;
+                v.x = __builtin_amdgcn_fmed3f(fmaf(v.x, sc.x, sh.x), lo, hi);
+                v.y = __builtin_amdgcn_fmed3f(fmaf(v.y, sc.y, sh.y), lo, hi);
+                v.z = __builtin_amdgcn_fmed3f(fmaf(v.z, sc.z, sh.z), lo, hi);
+                v.w = __builtin_amdgcn_fmed3f(fmaf(v.w, sc.w, sh.w), lo, hi);
+            } else {
+                v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
+            }
+            uint2 q1, q2;
+            split4h(v, q1, q2);
+            unsigned char* dst = As + buf * C3_ABUF + ((tid >> 2) + 64 * j) * C3_AP + kc * 8;
+            *reinterpret_cast<uint2*>(dst) = q1;
+            *reinterpret_cast<uint2*>(dst + C3_APL) = q2;
+        }
+    };
+
+    // ---- weight stream: pair gp = K-steps 2 gp, 2 gp + 1 = 2 x [CO][16] fp16 per plane, contiguous
+    unsigned bvoff[NJB], blds[NJB];
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) {
+        const int u = tid + 256 * j, pl = u / UPP, uu = u % UPP;
+        bvoff[j] = (unsigned)((size_t)pl * p.wq_stride * 2u) + (unsigned)uu * 16u;
+        blds[j] = (unsigned)(pl * BPL + ((uu >> 1) % CO) * C3_BP + (uu / (2 * CO)) * 32 + (uu & 1) * 16);
+    }
+    c3_u32x4 rb[NJB];
+    int gp = 0;                                 // the pair the NEXT gloadB fetches
+    auto gloadB = [&]() {
+        const unsigned so = (unsigned)gp * (unsigned)(CO * 64);
+#pragma unroll
+        for (int j = 0; j < NJB; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[j], so, 0);
+        gp = gp + 1 == npairs ? 0 : gp + 1;
+    };
+    auto storeB = [&](const unsigned slot) {
+#pragma unroll
+        for (int j = 0; j < NJB; ++j) *reinterpret_cast<c3_u32x4*>(Bs + slot + blds[j]) = rb[j];
+    };
+
+    // ---- fragments
+    struct Frag { f16x8 a[TM][2], b[TN][2]; };
+    unsigned aoff[TM], boff[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) aoff[a] = (unsigned)(((wm * TM + a) * C3_HW + lr) * C3_AP + 16 * lh);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) boff[b] = (unsigned)(((wn * TN + b) * 32 + lr) * C3_BP + 16 * lh);
+    // local K-step s of a chunk pair (0..17; 18 = step 0 of the next pair): chunk buffer (s / 9) & 1, tap s % 9
+    auto rd = [&](Frag& F, const int s, const unsigned slot) {
+        const int t = s % 9, buf = (s / 9) & 1;
+        const int toff = buf * C3_ABUF + ((t / 3) * C3_HW + (t % 3)) * C3_AP;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+                F.a[a][pl] = *reinterpret_cast<const f16x8*>(As + aoff[a] + toff + pl * C3_APL);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                F.b[b][pl] = *reinterpret_cast<const f16x8*>(Bs + slot + boff[b] + pl * BPL + (s & 1) * 32);
+        }
+    };
+    f32x16 acc[TM][TN];
+    auto mm = [&](const Frag& F) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[a][1], F.b[b][0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[a][0], F.b[b][1], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[a][0], F.b[b][0], acc[a][b], 0, 0, 0);
+            }
+    };
+    auto zero = [&]() {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    };
+
+    const float am2lo = p.tail.amax_relu ? 0.f : -__builtin_inff();
+    float am = 0.f, am2 = 0.f;
+
+    // ---- prologue of the workgroup's FIRST tile
+    int v = blockIdx.x;
+    int m0 = set_tile(v), m0n = 0;
+    gloadA(0);
+    gloadB();
+    storeA(0, 0);
+    storeB(0);
+    gloadB();                                   // pair 1 travels
+    unsigned bcur = 0, bnxt = BSLOT;
+    __syncthreads();
+#ifdef C3_STAGGER
+    // the second workgroup of a CU (dispatched in the second half of the grid) starts half a K-step pair late: partners in
+    // lockstep reach their staging work, their MFMA blocks and their barriers together and the matrix pipe idles
+    if (blockIdx.x >= (gridDim.x >> 1)) {
+#pragma unroll
+        for (int i = 0; i < C3_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+    Frag F0, F1;
+    rd(F0, 0, bcur);
+    zero();
+
+    for (; v < ntiles; v += gridDim.x) {
+        for (int c2 = 0; c2 < nchunks; c2 += 2) {
+#pragma unroll
+            for (int it = 0; it < 9; ++it) {
+                // the pair after this one -> the other slot (its last readers passed the previous barrier); next fetch
+                // first half: the MFMAs of step 2 it carry the fragment reads of step 2 it + 1, the copy of the pair after this
+                // one into the other slot (its last readers passed the previous barrier) and the fetch of the one after that
+                __builtin_amdgcn_sched_barrier(0);
+                rd(F1, 2 * it + 1, bcur);
+                if (C3_EXP != 3) storeB(bnxt);
+                if (C3_EXP != 1) gloadB();
+                if (C3_EXP != 5) mm(F0);
+#ifndef C3_NO_INTERLEAVE
+#pragma unroll
+                for (int i = 0; i < 4 * TM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NJB; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                if (C3_EXP != 2) __syncthreads();                // the other slot / chunk buffer is written; this slot is read
+                // second half: the MFMAs of step 2 it + 1 carry the fragment reads of step 2 it + 2 and the halo staging
+                rd(F0, 2 * it + 2, bnxt);
+                if (C3_EXP != 4) {
+                    if (it == 0) gloadA(c2 + 1);
+                    if (it == 2) storeA(1, c2 + 1);
+                }
+                if (it == 4) {
+                    if (c2 + 2 < nchunks) { if (C3_EXP != 4) gloadA(c2 + 2); }
+                    else { m0n = set_tile(v + (int)gridDim.x); if (C3_EXP != 4) gloadA(0); }      // the next tile's first chunk
+                }
+                if (C3_EXP != 4 && it == 7) storeA(0, c2 + 2 < nchunks ? c2 + 2 : 0);
+                if (C3_EXP != 5) mm(F1);
+                if (C3_EXP == 5) { asm volatile("" :: "v"(F0.a[0][0]), "v"(F0.b[0][0]), "v"(F0.a[TM-1][1]), "v"(F0.b[1][1]), "v"(F1.a[0][0]), "v"(F1.b[0][0]), "v"(F1.a[TM-1][1]), "v"(F1.b[1][1])); }
+#ifndef C3_NO_INTERLEAVE
+#pragma unroll
+                for (int i = 0; i < 4 * TM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if (it == 0 || it == 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+                if (it == 2 || it == 7) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                    }
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned tsw = bcur; bcur = bnxt; bnxt = tsw;
+            }
+        }
+
+        // ---- epilogue from the C layout: register e of a 32 x 32 tile = pixels (e&3) + 8 (e>>2) + 4 lh of patch row
+        // wm TM + a, channel lr of column tile wn TN + b.  `bnxt` (the slot just consumed) is free: statistics scratch.
+        float* red = reinterpret_cast<float*>(Bs + bnxt);          // [WM][CO][2]
+        {
+            constexpr int T = TM * TN, NR = 16;
+            float rbuf[2][NR];
+            auto tile_off = [&](const int i) {       // i = b * TM + a
+                const int a = i % TM, b = i / TM;
+                return (unsigned)((m0 + (wm * TM + a) * p.W + 4 * lh) * p.Cout + (wn * TN + b) * 32 + lr) * 4u;
+            };
+            auto loadres = [&](float (&r)[NR], const int i) {
+                if (MODE == 0) return;
+                const unsigned o0 = tile_off(i);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned so = (unsigned)((e & 3) + 8 * (e >> 2)) * rowbytes;
+                    r[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1r, o0, so, 0));
+                }
+            };
+            struct Col { float cb, sc, sh, mu, is; };
+            auto loadcol = [&](const int b) {
+                const int n = (wn * TN + b) * 32 + lr;
+                Col c = {0.f, 0.f, 0.f, 0.f, 0.f};
+                if (MODE == 3) { c.sc = p.bnb_scale[n]; c.sh = p.bnb_shift[n]; c.mu = p.bnb_mean[n]; c.is = p.bnb_invstd[n]; }
+                else {
+                    if (p.bias) c.cb = p.bias[n];
+                    if (p.tail.amax_bn) { c.sc = p.tail.amax_scale[n]; c.sh = p.tail.amax_shift[n]; }
+                }
+                return c;
+            };
+            Col col = loadcol(0), coln = col;
+            loadres(rbuf[0], 0);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const int a = i % TM, b = i / TM;
+                if (i + 1 < T) {
+                    loadres(rbuf[(i + 1) & 1], i + 1);
+                    if ((i + 1) % TM == 0) coln = loadcol((i + 1) / TM);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float (&r)[NR] = rbuf[i & 1];
+                const unsigned o0 = tile_off(i);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned so = (unsigned)((e & 3) + 8 * (e >> 2)) * rowbytes;
+                    float val = acc[a][b][e] * osc;
+                    if (MODE == 3) {
+                        // val = dL/d relu(bn(x)); r = x: mask by the ReLU, accumulate the BatchNorm-backward sums
+                        const float xv = r[e];
+                        if (p.bnb_relu && fmaf(xv, col.sc, col.sh) <= 0.f) val = 0.f;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), yr, o0, so, 0);
+                        s1 += val;
+                        s2 = fmaf(val, (xv - col.mu) * col.is, s2);
+                    } else {
+                        val += col.cb;
+                        if (MODE >= 1) val += r[e];
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), yr, o0, so, 0);
+                        am = fmaxf(am, fabsf(val));
+                        if (p.tail.amax_bn) am2 = fmaxf(am2, fabsf(fmaxf(fmaf(val, col.sc, col.sh), am2lo)));
+                        s1 += val;
+                        s2 = fmaf(val, val, s2);
+                    }
+                    acc[a][b][e] = 0.f;
+                }
+                if (a == TM - 1) {
+                    if (p.stats) {
+                        s1 += __shfl_xor(s1, 32, 64);
+                        s2 += __shfl_xor(s2, 32, 64);
+                        if (lh == 0) {
+                            red[(wm * CO + (wn * TN + b) * 32 + lr) * 2 + 0] = s1;
+                            red[(wm * CO + (wn * TN + b) * 32 + lr) * 2 + 1] = s2;
+                        }
+                    }
+                    s1 = 0.f; s2 = 0.f;
+                    col = coln;
+                }
+            }
+        }
+        if (p.stats) {
+            int tile;
+            xcd_remap(v, ntiles, tile);
+            __syncthreads();
+            for (int u = tid; u < CO * 2; u += 256) {
+                const int which = u & 1, c = u >> 1;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) s += red[(w * CO + c) * 2 + which];
+                tail_store(p.stats + ((size_t)tile * 2 + which) * p.Cout + c, s);
+            }
+            __syncthreads();                    // the next pair is stored over `red`
+        }
+        m0 = m0n;
+    }
+    if (p.tail.amax) amax_commit(am, p.tail.amax);
+    if (p.tail.amax_bn) amax_commit(am2, p.tail.amax_bn, 1);
+}
+
+static int c3_enabled = -1;
+
+bool dsnt_conv3s_geom_ok(const dsnt_conv_geom* g) {
+    if (c3_enabled < 0) {
+        const char* e = getenv("DSNT_CONV3S");
+        c3_enabled = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (!c3_enabled || !g) return false;
+    if (!(g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1 && g->dil == 1 && g->Ho == g->H && g->Wo == g->W)) return false;
+    if (g->H % C3_PH != 0 || g->W % C3_PW != 0 || g->Cin % 32 != 0 || g->Cin > 128) return false;
+    if (g->Cout != 64 && g->Cout != 128) return false;
+    const size_t M = (size_t)g->N * g->H * g->W;
+    if (M * g->Cin * 4u >= (1ull << 31) || M * g->Cout * 4u >= (1ull << 31)) return false;
+    return true;
+}
+
+bool dsnt_conv3s_ok(const ConvP& p) {
+    dsnt_conv_geom g;
+    memset(&g, 0, sizeof(g));
+    g.N = p.N; g.H = p.H; g.W = p.W; g.Cin = p.Cin; g.Ho = p.Ho; g.Wo = p.Wo; g.Cout = p.Cout;
+    g.R = p.R; g.S = p.S; g.stride = p.stride; g.pad = p.pad; g.dil = p.dil;
+    if (!dsnt_conv3s_geom_ok(&g)) return false;
+    if (!p.a_bound || !p.w_bound || !p.wq) return false;
+    if (p.tail.counters || p.res2) return false;
+    if (p.bnb_scale && p.in_scale) return false;
+    return true;
+}
+
+template <int CO, bool PRO, int MODE>
+static void c3_launch_k(const ConvP& p, hipStream_t st) {
+    const int lds = 2 * C3_ABUF + 2 * 2 * CO * C3_BP + (PRO ? 2 * p.Cin * 4 : 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)conv3s_kernel<CO, PRO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * C3_ABUF + 2 * 2 * CO * C3_BP + 1024);
+        attr_done = true;
+    }
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        hipGetDevice(&dev);
+        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const int ntiles = p.N * (p.H / C3_PH) * (p.W / C3_PW);
+    int grid = 2 * cus;                         // two workgroups per CU (LDS), persistent over the tiles
+    if (grid > ntiles) grid = ntiles;
+    DSNT_LAUNCH((conv3s_kernel<CO, PRO, MODE>), dim3(grid), dim3(256), lds, st, p, ntiles);
+}
+
+template <int CO>
+static void c3_launch(const ConvP& p, bool pro, hipStream_t st) {
+    if (p.bnb_scale) c3_launch_k<CO, false, 3>(p, st);
+    else if (pro) {
+        if (p.res1) c3_launch_k<CO, true, 1>(p, st);
+        else c3_launch_k<CO, true, 0>(p, st);
+    } else if (p.res1) c3_launch_k<CO, false, 1>(p, st);
+    else c3_launch_k<CO, false, 0>(p, st);
+}
+
+void dsnt_conv3s_launch(const ConvP& p, bool pro, hipStream_t st) {
+    if (p.Cout == 128) c3_launch<128>(p, pro, st);
+    else c3_launch<64>(p, pro, st);
+}

@@ -94,6 +94,7 @@ SIGNATURES = {
     'dsnt_conv_fwd_bf16x6': [P, P, L, P, P, P, P, I, P, P, P, GP, P],
     'dsnt_split_bf16x3': [P, P, L, P],
     'dsnt_conv_fwd_f16x3_ex': [P, P, L, P, P, P, P, P, P, I, P, P, P, GP, BP, TP, P],
+    'dsnt_conv_fwd_f16x3_stream': [P, P, L, P, P, P, P, P, P, I, P, P, P, GP, BP, TP, P],
     'dsnt_amax': [P, L, P, P],
     'dsnt_split_f16x2': [P, P, L, L, P, P],
     'dsnt_f16_prep_weights': [P, I, P],
@@ -169,6 +170,7 @@ PLAIN = {
     'dsnt_conv_wgrad_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_splits': (I, [GP]),
     'dsnt_conv_wgrad_halo_ok': (I, [GP]),
+    'dsnt_conv_fwd_stream_ok': (I, [GP]),
     'dsnt_conv_fwd_pro_ok': (I, [GP, I, I]),
     'dsnt_conv_wgrad_f16x3_splits': (I, [GP, I]),
     'dsnt_conv_wgrad_f16x3_ws_floats': (L, [GP, I]),

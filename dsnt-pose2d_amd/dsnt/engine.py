@@ -116,6 +116,8 @@ class Tape:
         self.wgrad_lane_rows = 16000
         self.wgrad_lane_res = False
         self.wgrad_lane_from = self.chain_lanes
+        self.conv3s = True         # 3x3 forward / data gradient: the symmetric persistent kernel (C side: DSNT_CONV3S=0)
+        self._f16_w_stream = {}
         self.wgrad_share = True    # DSNT_WGRAD_SHARE_CHIP on every launch of that lane (-0.2 ms)
         self._wgrad_lane_reads = set()
         # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
@@ -222,8 +224,9 @@ class Tape:
             self._scratch[key] = t
         return t
 
-    def f16_weights(self, p, wq16=None, wsrc=None, wb=None):
-        """Register conv weights (default: the arena's forward layout) for the per-step fp16x3 preparation."""
+    def f16_weights(self, p, wq16=None, wsrc=None, wb=None, stream=False):
+        """Register conv weights (default: the arena's forward layout) for the per-step fp16x3 preparation.
+        stream: the planes of a 3x3 filter in the K-step order of dsnt_conv_fwd_f16x3_stream (csrc/conv3s.hip)."""
         wq16 = p.wq16 if wq16 is None else wq16
         key = wq16.data_ptr()
         if key not in self._f16_w_seen:
@@ -232,7 +235,16 @@ class Tape:
             wb = p.wb if wb is None else wb
             n = wsrc.numel()
             assert n % 4 == 0
-            self._f16_w_rows.append([wsrc.data_ptr(), wq16.data_ptr(), wb.data_ptr(), n, p.wq_stride])
+            self._f16_w_rows.append([wsrc.data_ptr(), wq16.data_ptr(), wb.data_ptr(), n, p.wq_stride] +
+                                    ([p.Cout, p.Cin] if stream else [0, 0]))
+            self._f16_w_stream[key] = stream
+        assert self._f16_w_stream.get(key, False) == stream, 'one weight tensor, two plane layouts'
+
+    def stream_ok(self, p, g, rows, res2):
+        """A 3x3 convolution the symmetric persistent kernel runs (weights in stream order): large enough that no BatchNorm
+        tail is ever attached to it, at most one residual."""
+        return (self.conv3s and p.R == 3 and p.S == 3 and res2 is None and rows > self.tail_rows and
+                bool(self.lib.dsnt_conv_fwd_stream_ok(C.byref(g))))
 
     def f16_bn_bound(self, n):
         """Device scalar >= |relu?(bn(x))| of the train-mode BatchNorm seen through Normed n."""
@@ -805,10 +817,11 @@ class Tape:
         if normed and (use16 or use6):
             self.materialize(src)
         if use16:
-            self.f16_weights(p)
+            st = self.stream_ok(p, g, y.M, res2)
+            self.f16_weights(p, stream=st)
             ab = self.f16_bn_bound(src) if (normed and self.training) else x_amax
-            e = self.f('dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, ab, p.b, y.buf,
-                       sc, sh, relu, r1, r2, part, g, None, tail)
+            e = self.f('dsnt_conv_fwd_f16x3_stream' if st else 'dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, ab,
+                       p.b, y.buf, sc, sh, relu, r1, r2, part, g, None, tail)
             self.f16_uses.append((e, dict(kind='fwd', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
                                           w=p.w, w_bound=p.wb)))
         elif use6:
@@ -950,11 +963,15 @@ class Tape:
                 if d16:
                     wq16 = self.dgrad_planes16[slot:slot + nw]
                     wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
-                    self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total])
+                    # (the data gradient's filter is [Cin][3][3][Cout]: its "Cout" is this convolution's Cin)
+                    d_stream = self.stream_ok(p, gd, x.M, None)
+                    self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total] +
+                                             ([p.Cin, p.Cout] if d_stream else [0, 0]))
 
                 def dgrad(out, res, part=None, bnb=None, tail=None):
                     if d16:
-                        e = self.b('dsnt_conv_fwd_f16x3_ex', gsrc, wq16, self.dgrad_total, wbd, g_amax, None, out, None,
+                        e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
+                                   self.dgrad_total, wbd, g_amax, None, out, None,
                                    None, 0, res, None, part, gd, bnb, tail)
                         self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
                     elif d6:

@@ -260,12 +260,25 @@ int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int64_t plane_s
                            const float* in_shift, int in_relu, const float* res1, const float* res2,
                            float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
                            const dsnt_bn_tail* tail, void* stream);
+/* The same call for a 3x3 / stride 1 / pad 1 convolution whose weight planes are in the STREAM layout of
+ * dsnt_f16_prep_weights (row flag): the symmetric persistent kernel of csrc/conv3s.hip (cuDNN's 3x3 forward / data gradient of
+ * /root/reference/src/dsnt/hourglass.py:22-23).  Needs dsnt_conv_fwd_stream_ok(g) (H % 4 == 0, W % 32 == 0, Cin % 32 == 0 and
+ * <= 128, Cout 64 or 128, tensors < 2 GiB), res2 == NULL and no ticket counters in `tail`; DSNT_ERR_SHAPE otherwise.  The
+ * convolution sums are bit-identical to dsnt_conv_fwd_f16x3_ex's; stats_partial rows are [N * H/4 * W/32 patches][2][Cout]. */
+int dsnt_conv_fwd_f16x3_stream(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
+                               const float* a_bound, const float* bias, float* y, const float* in_scale,
+                               const float* in_shift, int in_relu, const float* res1, const float* res2,
+                               float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
+                               const dsnt_bn_tail* tail, void* stream);
+int dsnt_conv_fwd_stream_ok(const dsnt_conv_geom* g);
 /* out[0..63] = bound slots whose maximum is max |src[i]|; dst = two fp16 planes (plane_stride elements apart) of src * pow2(bound). */
 int dsnt_amax(const float* src, int64_t n, float* out, void* stream);
 int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t plane_stride, const float* bound, void* stream);
 /* The same for many tensors per launch (device tables of int64 rows):
- * dsnt_f16_prep_weights: row {src float*, dst fp16 plane-0*, bound float*, count (% 4 == 0), plane stride (elements)}:
- *   bound = max|src|, dst = the two fp16 planes of src * pow2(bound) — every conv's weights once per step;
+ * dsnt_f16_prep_weights: row {src float*, dst fp16 plane-0*, bound float*, count (% 4 == 0), plane stride (elements),
+ *   stream Cout, stream Cin}: bound = max|src|, dst = the two fp16 planes of src * pow2(bound) — every conv's weights once
+ *   per step; stream Cout > 0: src is an OHWI 3x3 filter [Cout][3][3][Cin] (Cin % 16 == 0) and each plane is written in
+ *   STREAM order [Cin / 16][9 taps][Cout][16] for dsnt_conv_fwd_f16x3_stream (0, 0: element order kept);
  * dsnt_f16_prep_bn_bounds: row {gamma float*, beta float*, out float*, C, bits of float sqrt(M)}:
  *   out = max_c(|gamma_c| sqrt(M) + |beta_c|), an upper bound of |relu?(bn(x))| for a TRAIN-mode BatchNorm over M samples. */
 int dsnt_f16_prep_weights(const int64_t* table, int rows, void* stream);

@@ -691,7 +691,7 @@ def test_f16x3_preparation_launches():
     for w in ws:
         planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
         bound = torch.zeros(64, device=dev)
-        rows.append([w.data_ptr(), planes.data_ptr(), bound.data_ptr(), w.numel(), w.numel()])
+        rows.append([w.data_ptr(), planes.data_ptr(), bound.data_ptr(), w.numel(), w.numel(), 0, 0])
         outs.append(planes); bounds.append(bound)
     table = torch.tensor(rows, dtype=torch.int64).to(dev)
     call('dsnt_f16_prep_weights', ptr(table), len(rows))
@@ -723,6 +723,131 @@ def test_f16x3_preparation_launches():
     low = torch.empty(2, 4, 4, 64, device=dev)
     call('dsnt_upsample2_bwd_amax', ptr(x), ptr(low), 0, 2, 8, 8, 64, ptr(slot))
     assert slot.max().item() == low.abs().max().item()
+
+
+# (N, H, W, Cin, Cout) of 3x3 / stride 1 / pad 1 convolutions the symmetric persistent kernel runs (csrc/conv3s.hip)
+STREAM_CASES = [
+    (2, 16, 32, 64, 64),          # 8 patches, one chunk pair ... two per tile
+    (4, 64, 64, 128, 128),        # the Bottleneck's 3x3 at the 64 x 64 level: 512 patches
+    (3, 8, 32, 128, 64),
+    (2, 32, 64, 64, 128),
+    (5, 4, 32, 32, 128),          # one chunk pair per tile: the slot parity flips from tile to tile
+    (40, 64, 64, 32, 64),         # 1280 patches on 512 persistent workgroups: 2-3 tiles each, ragged
+]
+
+
+@pytest.mark.parametrize('case', STREAM_CASES)
+@pytest.mark.parametrize('mode', ['plain', 'pro', 'pro_res', 'res', 'bnb'])
+def test_conv3_stream_kernel(case, mode):
+    """dsnt_conv_fwd_f16x3_stream (persistent symmetric 3x3 kernel, weights in stream order) against
+    dsnt_conv_fwd_f16x3_ex on the same operands: the stream planes are the plain planes permuted; without a residual the
+    outputs are bit-identical (same K order, same MFMA order, same epilogue arithmetic); with one they agree to an ulp of
+    the sum; per-patch statistics add up to the same column sums; the BatchNorm-backward epilogue masks identically; and
+    the result holds the fp32 bar against torch fp64."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call, BnBwdEpilogue
+    N, H, W, Cin, Cout = case
+    dev = torch.device('cuda:0')
+    tag = 's3' + '_'.join(map(str, case))
+    g = _geom(N, H, W, Cin, Cout, 3, 3, 1, 1, 1)
+    assert _lib.fn('dsnt_conv_fwd_stream_ok')(C.byref(g)) == 1
+    M = N * H * W
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=1)
+    w = synthetic.tensor(tag + 'w', (Cout, Cin, 3, 3), seed=1, scale=(2.0 / (Cin * 9)) ** 0.5)
+    b = synthetic.tensor(tag + 'b', (Cout,), seed=1, scale=0.1)
+    sc = synthetic.tensor(tag + 's', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'h', (Cin,), seed=1, scale=0.3)
+    res = synthetic.tensor(tag + 'r', (N, Cout, H, W), seed=1)
+    pro = mode in ('pro', 'pro_res')
+    xd = _nhwc(x).to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    n = wd.numel()
+    plain = torch.empty(2 * n, dtype=torch.float16, device=dev)
+    strm = torch.full((2 * n,), float('nan'), dtype=torch.float16, device=dev)
+    wb, wb2 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    table = torch.tensor([[wd.data_ptr(), plain.data_ptr(), wb.data_ptr(), n, n, 0, 0],
+                          [wd.data_ptr(), strm.data_ptr(), wb2.data_ptr(), n, n, Cout, Cin]], dtype=torch.int64).to(dev)
+    call('dsnt_f16_prep_weights', ptr(table), 2)
+    assert torch.equal(wb, wb2)
+    want = plain.view(2, Cout, 9, Cin // 16, 16).permute(0, 3, 2, 1, 4).contiguous().view(-1)
+    assert torch.equal(want.view(torch.int16), strm.view(torch.int16))
+    bd, scd, shd, resd = b.to(dev), sc.to(dev), sh.to(dev), _nhwc(res).to(dev)
+    tiles = M // 128
+    if mode == 'bnb':
+        # the launch as a data gradient: A = a gradient tensor, epilogue = ReLU mask of bn(xin) + the two BN-backward sums
+        xin = _nhwc(synthetic.tensor(tag + 'xin', (N, Cout, H, W), seed=3)).to(dev)
+        mean = synthetic.tensor(tag + 'm', (Cout,), seed=4, scale=0.2).to(dev)
+        invstd = (synthetic.tensor(tag + 'i', (Cout,), seed=5, kind='uniform').abs() + 0.5).to(dev)
+        bsc = (synthetic.tensor(tag + 'bs', (Cout,), seed=6, kind='uniform') + 0.2).to(dev)
+        bsh = synthetic.tensor(tag + 'bh', (Cout,), seed=7, scale=0.3).to(dev)
+        bnb = BnBwdEpilogue(ptr(xin), ptr(bsc), ptr(bsh), ptr(mean), ptr(invstd), 1)
+    ab = torch.zeros(64, device=dev)
+    act = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if pro else x
+    ab[11] = act.abs().max().item() * 3.0
+    outs = []
+    for fn, planes in (('dsnt_conv_fwd_f16x3_ex', plain), ('dsnt_conv_fwd_f16x3_stream', strm)):
+        y = torch.full((N, H, W, Cout), float('nan'), device=dev)
+        stats = torch.full((tiles, 2, Cout), float('nan'), device=dev)
+        amax = torch.zeros(64, device=dev)
+        tail = _lib.BnTail()
+        if mode != 'bnb':
+            tail.amax = amax.data_ptr()
+        call(fn, ptr(xd), ptr(planes), n, ptr(wb), ptr(ab), None if mode == 'bnb' else ptr(bd), ptr(y),
+             ptr(scd) if pro else None, ptr(shd) if pro else None, 1,
+             ptr(resd) if mode in ('res', 'pro_res') else None, None, ptr(stats), C.byref(g),
+             C.byref(bnb) if mode == 'bnb' else None, C.byref(tail))
+        outs.append((y, stats, amax))
+    torch.cuda.synchronize()
+    (y0, st0, am0), (y1, st1, am1) = outs
+    assert not bool(torch.isnan(y1).any()) and not bool(torch.isnan(st1).any())
+    scale = y0.abs().max().item()
+    if mode in ('plain', 'pro', 'bnb') and H % 8 == 0:       # (H % 8 != 0: _ex runs the implicit-GEMM kernel, K order (tap, channel))
+        assert torch.equal(y0, y1)
+    else:
+        assert (y0 - y1).abs().max().item() <= (2.5e-7 if H % 8 == 0 else 2e-6) * scale
+    if mode == 'bnb':
+        assert float((y1 == 0).float().mean()) > 0.2
+    else:
+        assert am1.max().item() == y1.abs().max().item()
+    # statistics: other tiles, other order — the column sums agree to fp32 rounding of a 128-term sum
+    for k in range(2):
+        a0, a1 = st0[:, k].double().sum(0), st1[:, k].double().sum(0)
+        assert (a0 - a1).abs().max().item() <= 2e-6 * max(1.0, st0[:, k].double().abs().sum(0).max().item())
+    if mode != 'bnb':
+        y64 = F.conv2d(act.double(), w.double(), b.double(), padding=1)
+        if mode in ('res', 'pro_res'):
+            y64 = y64 + res.double()
+        y32 = F.conv2d(act, w, b, padding=1) + (res if mode in ('res', 'pro_res') else 0)
+        got = y1.cpu().permute(0, 3, 1, 2).double()
+        err16, err32 = (got - y64).abs().max().item(), (y32.double() - y64).abs().max().item()
+        assert err16 <= max(4 * err32, 2e-6 * y64.abs().max().item()), (err16, err32)
+        cols = y1.double().reshape(M, Cout)
+        assert (st1[:, 0].double().sum(0) - cols.sum(0)).abs().max().item() <= 1e-4 * max(1.0, cols.sum(0).abs().max().item())
+        assert (st1[:, 1].double().sum(0) - (cols * cols).sum(0)).abs().max().item() <= 1e-4 * (cols * cols).sum(0).max().item()
+
+
+def test_conv3_stream_refusals():
+    """dsnt_conv_fwd_f16x3_stream refuses what the kernel does not carry: a second residual, ticket counters, other
+    geometries (the caller keeps dsnt_conv_fwd_f16x3_ex for those)."""
+    from dsnt import _lib
+    from dsnt._lib import ptr
+    dev = torch.device('cuda:0')
+    ok = _lib.fn('dsnt_conv_fwd_stream_ok')
+    assert ok(C.byref(_geom(2, 16, 32, 64, 64, 3, 3, 1, 1, 1))) == 1
+    for bad in [(2, 16, 16, 64, 64, 3, 3, 1, 1, 1), (2, 6, 32, 64, 64, 3, 3, 1, 1, 1), (2, 16, 32, 48, 64, 3, 3, 1, 1, 1),
+                (2, 16, 32, 64, 96, 3, 3, 1, 1, 1), (2, 16, 32, 64, 64, 1, 1, 1, 0, 1), (2, 16, 32, 256, 64, 3, 3, 1, 1, 1),
+                (2, 16, 32, 64, 64, 3, 3, 1, 2, 2)]:
+        assert ok(C.byref(_geom(*bad))) == 0, bad
+    g = _geom(2, 16, 32, 64, 64, 3, 3, 1, 1, 1)
+    x = torch.zeros(2, 16, 32, 64, device=dev)
+    y, r = torch.empty_like(x), torch.zeros_like(x)
+    planes = torch.zeros(2 * 64 * 9 * 64, dtype=torch.float16, device=dev)
+    wb = torch.ones(64, device=dev)
+    f = _lib.fn('dsnt_conv_fwd_f16x3_stream')
+    assert f(ptr(x), ptr(planes), 64 * 9 * 64, ptr(wb), ptr(wb), None, ptr(y), None, None, 0, ptr(r), ptr(r), None,
+             C.byref(g), None, None, None) != 0
+    assert b'stream' in _lib.load().dsnt_last_error()
+    torch.cuda.synchronize()
 
 
 # (N, H, W, Cin [BN'd input channels], Cout [channels of the conv whose data gradient is taken], k)

@@ -25,11 +25,20 @@ _lib.fn('dsnt_amax')(ptr(w), w.numel(), ptr(wb), st)
 _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(planes16), w.numel(), w.numel(), ptr(wb), st)
 _lib.fn('dsnt_amax')(ptr(gy), gy.numel(), ptr(gb), st)
 ab.fill_(float(torch.relu(x * sc + sh).max()) * 4.0)
-for _ in range(5):
+planes16s = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+if k == 3 and _lib.fn('dsnt_conv_fwd_stream_ok')(C.byref(g)):
+    tab = torch.tensor([[w.data_ptr(), planes16s.data_ptr(), wb.data_ptr(), w.numel(), w.numel(), Cout, Cin]], dtype=torch.int64).to(dev)
+    _lib.fn('dsnt_f16_prep_weights')(ptr(tab), 1, st)
+reps = int(os.environ.get('ONE_KERNEL_REPS', '5'))
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+for it in range(reps):
+    ev[it].record()
     if which == 'fwd6':
         _lib.fn('dsnt_conv_fwd_bf16x6')(ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
     elif which == 'fwd16':
         _lib.fn('dsnt_conv_fwd_f16x3_ex')(ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None, None, st)
+    elif which == 'fwd16s':
+        _lib.fn('dsnt_conv_fwd_f16x3_stream')(ptr(x), ptr(planes16s), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None, None, st)
     elif which == 'wgrad16':
         _lib.fn('dsnt_conv_wgrad_f16x3')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g), st)
     elif which == 'wgrad6':
@@ -38,4 +47,6 @@ for _ in range(5):
         _lib.fn('dsnt_conv_fwd')(ptr(x), ptr(w), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
     else:
         _lib.fn('dsnt_conv_wgrad')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), ptr(dw), ptr(db), 0, C.byref(g), st)
+ev[reps].record()
 torch.cuda.synchronize()
+print(which, H, Cin, Cout, k, 'us per launch:', ' '.join('%.1f' % (1e3 * ev[i].elapsed_time(ev[i + 1])) for i in range(reps)))
