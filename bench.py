@@ -108,12 +108,23 @@ def dominant_kernel_roofline(batch, iters=20):
         assert _lib.fn('dsnt_amax')(ptr(w), w.numel(), ptr(wb), stream) == 0
         assert _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(planes16), w.numel(), w.numel(), ptr(wb), stream) == 0
         ab.fill_(float(torch.relu(x * sc + sh).max()) * 4.0)
-        ms16 = timed(_lib.fn('dsnt_conv_fwd_f16x3_ex'),
-                     (ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y)) + common + (None, None))
+        ms16h = timed(_lib.fn('dsnt_conv_fwd_f16x3_ex'),
+                      (ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y)) + common + (None, None))
+        # ... with the weight planes in stream order: the persistent symmetric kernel (csrc/conv3s.hip) the step launches
+        stream16 = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+        tab = torch.tensor([[w.data_ptr(), stream16.data_ptr(), wb.data_ptr(), w.numel(), w.numel(), 128, 128]],
+                           dtype=torch.int64).to(dev)
+        assert _lib.fn('dsnt_f16_prep_weights')(ptr(tab), 1, stream) == 0
+        streamed = os.environ.get('DSNT_CONV3S', '1') != '0' and bool(_lib.fn('dsnt_conv_fwd_stream_ok')(C.byref(g)))
+        ms16 = timed(_lib.fn('dsnt_conv_fwd_f16x3_stream'),
+                     (ptr(x), ptr(stream16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y)) + common + (None, None)) if streamed else ms16h
         achieved, peak, ms = flops / (ms16 * 1e-3) / 1e12, PEAK_BF16_MFMA / 3.0, ms16
         twins['bf16x6_kernel'] = {'achieved': round(flops / (ms6 * 1e-3) / 1e12, 2), 'peak': round(PEAK_BF16_MFMA / 6.0, 1),
                                   'us_per_launch': round(ms6 * 1e3, 1)}
-        kernel = 'conv3x3_bf16x6_kernel<2,true,F16> (fp16x3) 3x3 128->128 @64x64 B=%d' % batch
+        twins['halo_tile_kernel_f16x3'] = {'achieved': round(flops / (ms16h * 1e-3) / 1e12, 2), 'peak': round(PEAK_BF16_MFMA / 3.0, 1),
+                                           'us_per_launch': round(ms16h * 1e3, 1)}
+        kernel = ('conv3s_kernel<128,true,0> (fp16x3, persistent) 3x3 128->128 @64x64 B=%d' if streamed else
+                  'conv3x3_bf16x6_kernel<2,true,F16> (fp16x3) 3x3 128->128 @64x64 B=%d') % batch
         note = ('algorithmic fp32 FLOPs; peak = 2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per product '
                 '(= %.0f fp16 TFLOP/s executed)' % (3 * achieved))
     else:

@@ -18,3 +18,21 @@ if [ "$2" = "bench" ]; then
   rm -rf gpurun_out/prof_bench
   tail -1 gpurun_out/${tag}_prof_bench.log | cut -c1-300
 fi
+# PMC evidence of the round-3 kernels (tools/collect_profiles_r03.sh <tag> pmc): SQ issue accounting (tools/pmc_sweep.sh ->
+# tools/pmc_account.py) and HBM traffic (FETCH_SIZE / WRITE_SIZE / L2 hit rate, one counter group per pass) of
+#   conv3s (3x3 128->128 @64), wgrad3 (3x3 weight gradient), gemm1 (1x1 128->256 and 256->128 @64), wgrad1 (1x1 weight gradient)
+if [ "$2" = "pmc" ]; then
+  for spec in "c3s:conv3s:fwd16s:64 128 128 3" "wg3:wgrad3:wgrad16:64 128 128 3" "g1a:gemm1:fwd16:64 128 256 1" "g1b:gemm1:fwd16:64 256 128 1" "wg1:wgrad1:wgrad16:64 128 256 1"; do
+    IFS=':' read name kern mode geo <<< "$spec"
+    bash tools/pmc_sweep.sh ${tag}_$name $kern $mode $geo > /dev/null || exit 1
+    python3 tools/pmc_account.py gpurun_out/pmcs_${tag}_$name.txt "$kern ($mode $geo, batch 32)" > gpurun_out/${tag}_pmc_$name.txt
+    for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+      bash tools/pmc.sh ${tag}_t_$name $kern "$c" -- python3 tools/one_kernel.py $mode $geo | grep -v "^rc=" >> gpurun_out/${tag}_pmc_$name.txt
+      rm -rf gpurun_out/${tag}_t_$name gpurun_out/${tag}_t_$name.log
+    done
+    timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python3 tools/one_kernel.py $mode $geo > /dev/null 2>&1
+    grep -E "$kern" $(ls gpurun_out/ks/*/*kernel_stats.csv | head -1) | head -2 >> gpurun_out/${tag}_pmc_$name.txt
+    rm -rf gpurun_out/ks
+  done
+  cat gpurun_out/${tag}_pmc_*.txt
+fi
