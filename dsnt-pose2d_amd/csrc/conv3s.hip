@@ -380,8 +380,7 @@ static int c3_enabled = -1;
 
 bool dsnt_conv3s_geom_ok(const dsnt_conv_geom* g) {
     if (c3_enabled < 0) {
-        const char* e = getenv("DSNT_CONV3S");
-        c3_enabled = (e && e[0] == '0') ? 0 : 1;
+        c3_enabled = dsnt_kernel_off("conv3s") ? 0 : 1;
     }
     if (!c3_enabled || !g) return false;
     if (!(g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1 && g->dil == 1 && g->Ho == g->H && g->Wo == g->W)) return false;

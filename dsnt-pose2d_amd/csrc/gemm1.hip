@@ -268,8 +268,7 @@ static const long g1_min_rows = 65536;     // below: too few row blocks to fill 
 
 int dsnt_gemm1_cfg(const ConvP& p) {
     if (g1_enabled < 0) {
-        const char* e = getenv("DSNT_GEMM1");
-        g1_enabled = (e && e[0] == '0') ? 0 : 1;
+        g1_enabled = dsnt_kernel_off("gemm1") ? 0 : 1;
     }
     if (!g1_enabled || !p.a_bound || !p.w_bound || !p.wq) return -1;
     if (!(p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.Ho == p.H && p.Wo == p.W)) return -1;

@@ -245,8 +245,7 @@ Wg1Plan dsnt_wg1_plan(const dsnt_conv_geom* g, bool share) {
     Wg1Plan pl;
     memset(&pl, 0, sizeof(pl));
     if (w1_enabled < 0) {
-        const char* e = getenv("DSNT_WGRAD1");
-        w1_enabled = (e && e[0] == '0') ? 0 : 1;
+        w1_enabled = dsnt_kernel_off("wgrad1") ? 0 : 1;
     }
     if (!w1_enabled || !g) return pl;
     if (!(g->R == 1 && g->S == 1 && g->stride == 1 && g->pad == 0 && g->Ho == g->H && g->Wo == g->W)) return pl;

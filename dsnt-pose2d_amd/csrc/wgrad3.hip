@@ -309,8 +309,7 @@ Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, bool share) {
     // that share the chip
     const long target = 256;
     if (enabled < 0) {
-        const char* e = getenv("DSNT_WGRAD3");
-        enabled = (e && e[0] == '0') ? 0 : 1;
+        enabled = dsnt_kernel_off("wgrad3") ? 0 : 1;
         min_steps = 32;
         small_wg = 1;
     }

@@ -117,7 +117,7 @@ class Tape:
         self.wgrad_lane_res = False
         self.wgrad_lane_from = self.chain_lanes
         # 3x3 forward / data gradient: the symmetric persistent kernel of csrc/conv3s.hip (stream-ordered weight planes)
-        self.conv3s = os.environ.get('DSNT_CONV3S', '1') != '0'
+        self.conv3s = 'conv3s' not in os.environ.get('DSNT_OFF', '').split(',')       # DSNT_OFF=conv3s,gemm1,wgrad3,wgrad1
         self._f16_w_stream = {}
         self.wgrad_share = True    # DSNT_WGRAD_SHARE_CHIP on every launch of that lane (-0.2 ms)
         self._wgrad_lane_reads = set()

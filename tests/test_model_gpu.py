@@ -511,7 +511,7 @@ def test_bn_tails_give_the_same_step(monkeypatch):
     from dsnt.model import build_mpii_pose_model
 
     monkeypatch.setenv('DSNT_FUSE_FINALIZE', '0')          # the baseline: every BatchNorm finalised by its own launch
-    monkeypatch.setenv('DSNT_CONV3S', '0')                 # (the persistent 3x3 kernel carries no tail: same kernels on both sides)
+    monkeypatch.setenv('DSNT_OFF', 'conv3s')                # (the persistent 3x3 kernel carries no tail: same kernels on both sides)
 
     def step(rows):
         monkeypatch.setenv('DSNT_BN_TAIL_ROWS', str(rows))

@@ -1,5 +1,5 @@
 """Time dsnt_conv_wgrad_f16x3 alone (slabs only): python tools/bench_wgrad.py [H Cin Cout k [B]].
-DSNT_WGRAD3=0 routes 3x3 shapes through the implicit-GEMM kernel instead of the halo kernel (A/B)."""
+DSNT_OFF=wgrad3 routes 3x3 shapes through the implicit-GEMM kernel instead of the halo kernel (A/B)."""
 import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 """hg8 smooth network: save (first call) or compare (second call) every parameter gradient and BatchNorm running statistic
-of one step — two processes under different switches (e.g. DSNT_CONV3S=0 / 1): python tools/diag_hg8_ab.py /tmp/a.pt"""
+of one step — two processes under different switches (e.g. DSNT_OFF=conv3s / unset): python tools/diag_hg8_ab.py /tmp/a.pt"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
