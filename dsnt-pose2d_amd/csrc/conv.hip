@@ -1461,10 +1461,12 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     hipStream_t st = (hipStream_t)stream;
     DSNT_REQUIRE(!((p.tail.amax || p.tail.amax_bn) && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
     p.a_bound = a_bound; p.w_bound = w_bound;
+    const bool share_chip = stream_w && (in_relu & DSNT_CONV_SHARE_CHIP) != 0;      // leave room beside this launch
+    if (stream_w) p.in_relu = in_relu & 1;
     if (stream_w) {                  // 3x3, weights in the stream layout: the symmetric kernel (conv3s.hip)
         DSNT_REQUIRE(dsnt_conv3s_ok(p), DSNT_ERR_SHAPE, "dsnt_conv_fwd_f16x3_stream: launch not supported (dsnt_conv_fwd_stream_ok; "
                      "no second residual, no BatchNorm tail counters)");
-        dsnt_conv3s_launch(p, in_scale != nullptr, st);
+        dsnt_conv3s_launch(p, in_scale != nullptr, st, share_chip);
         DSNT_CHECK_LAUNCH("dsnt_conv_fwd_f16x3_stream");
     }
     if (a_bound) {                   // fp16x3: two fp16 weight planes, operand bounds in device memory

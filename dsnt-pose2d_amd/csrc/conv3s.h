@@ -7,4 +7,6 @@
 bool dsnt_conv3s_ok(const ConvP& p);
 // geometry part of the same test (the engine asks before it chooses the weight layout)
 bool dsnt_conv3s_geom_ok(const dsnt_conv_geom* g);
-void dsnt_conv3s_launch(const ConvP& p, bool pro, hipStream_t st);
+// share: the launch runs on a lane beside the dependency chain — fewer persistent workgroups, so that the chain's small
+// kernels find a CU with free LDS (two conv3s workgroups fill a CU's 160 KB)
+void dsnt_conv3s_launch(const ConvP& p, bool pro, hipStream_t st, bool share = false);

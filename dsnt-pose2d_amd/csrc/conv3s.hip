@@ -404,7 +404,7 @@ bool dsnt_conv3s_ok(const ConvP& p) {
 }
 
 template <int CO, bool PRO, int MODE>
-static void c3_launch_m(const ConvP& p, hipStream_t st) {
+static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
     const int lds = 2 * C3_ABUF + 2 * 2 * CO * C3_BP + 1024;       // halo buffers, weight ring, BatchNorm vectors
     static bool attr_done = false;
     if (!attr_done) {
@@ -420,21 +420,25 @@ static void c3_launch_m(const ConvP& p, hipStream_t st) {
     }
     const int ntiles = p.N * (p.H / C3_PH) * (p.W / C3_PW);
     int grid = 2 * cus;                         // two workgroups per CU (LDS), persistent over the tiles
+    // DSNT_CONV_SHARE_CHIP: a launch on a side lane.  Two of these workgroups take a CU's whole LDS for the life of the launch,
+    // and the dependency chain's small kernels on the other streams then wait for a slot (a bn_finalize of 8 workgroups: 63 us
+    // instead of 6).  3/2 workgroups per CU: -0.08 ms per hg2 step (256 / 384 / 448 workgroups measured alike).
+    if (share) grid = cus + cus / 2;
     if (grid > ntiles) grid = ntiles;
     DSNT_LAUNCH((conv3s_kernel<CO, PRO, MODE>), dim3(grid), dim3(256), lds, st, p, ntiles);
 }
 
 template <int CO>
-static void c3_launch(const ConvP& p, bool pro, hipStream_t st) {
-    if (p.bnb_scale) c3_launch_m<CO, false, 3>(p, st);
+static void c3_launch(const ConvP& p, bool pro, hipStream_t st, bool share) {
+    if (p.bnb_scale) c3_launch_m<CO, false, 3>(p, st, share);
     else if (pro) {
-        if (p.res1) c3_launch_m<CO, true, 1>(p, st);
-        else c3_launch_m<CO, true, 0>(p, st);
-    } else if (p.res1) c3_launch_m<CO, false, 1>(p, st);
-    else c3_launch_m<CO, false, 0>(p, st);
+        if (p.res1) c3_launch_m<CO, true, 1>(p, st, share);
+        else c3_launch_m<CO, true, 0>(p, st, share);
+    } else if (p.res1) c3_launch_m<CO, false, 1>(p, st, share);
+    else c3_launch_m<CO, false, 0>(p, st, share);
 }
 
-void dsnt_conv3s_launch(const ConvP& p, bool pro, hipStream_t st) {
-    if (p.Cout == 128) c3_launch<128>(p, pro, st);
-    else c3_launch<64>(p, pro, st);
+void dsnt_conv3s_launch(const ConvP& p, bool pro, hipStream_t st, bool share) {
+    if (p.Cout == 128) c3_launch<128>(p, pro, st, share);
+    else c3_launch<64>(p, pro, st, share);
 }

@@ -803,6 +803,12 @@ def test_conv3_stream_kernel(case, mode):
              ptr(resd) if mode in ('res', 'pro_res') else None, None, ptr(stats), C.byref(g),
              C.byref(bnb) if mode == 'bnb' else None, C.byref(tail))
         outs.append((y, stats, amax))
+    if mode == 'pro':       # DSNT_CONV_SHARE_CHIP (bit 1 of in_relu): fewer persistent workgroups, the same result bit for bit
+        y2 = torch.full((N, H, W, Cout), float('nan'), device=dev)
+        st2 = torch.full((tiles, 2, Cout), float('nan'), device=dev)
+        call('dsnt_conv_fwd_f16x3_stream', ptr(xd), ptr(strm), n, ptr(wb), ptr(ab), ptr(bd), ptr(y2), ptr(scd), ptr(shd), relu | 2,
+             None, None, ptr(st2), C.byref(g), None, None)
+        assert torch.equal(y2, outs[1][0]) and torch.equal(st2, outs[1][1])
     torch.cuda.synchronize()
     (y0, st0, am0), (y1, st1, am1) = outs
     assert not bool(torch.isnan(y1).any()) and not bool(torch.isnan(st1).any())
