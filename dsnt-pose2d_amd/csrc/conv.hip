@@ -1461,8 +1461,8 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     hipStream_t st = (hipStream_t)stream;
     DSNT_REQUIRE(!((p.tail.amax || p.tail.amax_bn) && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
     p.a_bound = a_bound; p.w_bound = w_bound;
-    const bool share_chip = stream_w && (in_relu & DSNT_CONV_SHARE_CHIP) != 0;      // leave room beside this launch
-    if (stream_w) p.in_relu = in_relu & 1;
+    const bool share_chip = a_bound && (in_relu & DSNT_CONV_SHARE_CHIP) != 0;       // (fp16x3 entry points) leave room beside this launch
+    if (a_bound) p.in_relu = in_relu & 1;
     if (stream_w) {                  // 3x3, weights in the stream layout: the symmetric kernel (conv3s.hip)
         DSNT_REQUIRE(dsnt_conv3s_ok(p), DSNT_ERR_SHAPE, "dsnt_conv_fwd_f16x3_stream: launch not supported (dsnt_conv_fwd_stream_ok; "
                      "no second residual, no BatchNorm tail counters)");
@@ -1472,7 +1472,7 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     if (a_bound) {                   // fp16x3: two fp16 weight planes, operand bounds in device memory
         const int ntw = dsnt_gemm1_cfg(p);      // large 1x1 convolutions: the streaming kernel (gemm1.hip)
         if (ntw > 0) {
-            dsnt_gemm1_launch(p, ntw, in_scale != nullptr, st);
+            dsnt_gemm1_launch(p, ntw, in_scale != nullptr, st, share_chip);
             DSNT_CHECK_LAUNCH("dsnt_conv_fwd_f16x3");
         }
         if (conv3x3_halo_ok(g) && !g_force_gemm6) {

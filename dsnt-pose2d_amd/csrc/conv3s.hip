@@ -422,7 +422,8 @@ static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
     int grid = 2 * cus;                         // two workgroups per CU (LDS), persistent over the tiles
     // DSNT_CONV_SHARE_CHIP: a launch on a side lane.  Two of these workgroups take a CU's whole LDS for the life of the launch,
     // and the dependency chain's small kernels on the other streams then wait for a slot (a bn_finalize of 8 workgroups: 63 us
-    // instead of 6).  3/2 workgroups per CU: -0.08 ms per hg2 step (256 / 384 / 448 workgroups measured alike).
+    // instead of 6).  3/2 workgroups per CU: -0.08 ms per hg2 step (256 / 384 / 448 workgroups measured alike; once the side
+    // lane's 1x1 kernel yields half of the CUs — gemm1.hip — this one's share no longer matters: 128 .. 512 workgroups within 0.03 ms).
     if (share) grid = cus + cus / 2;
     if (grid > ntiles) grid = ntiles;
     DSNT_LAUNCH((conv3s_kernel<CO, PRO, MODE>), dim3(grid), dim3(256), lds, st, p, ntiles);

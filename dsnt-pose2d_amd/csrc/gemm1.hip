@@ -290,7 +290,7 @@ int dsnt_gemm1_cfg(const ConvP& p) {
 }
 
 template <int KS, int NTW, bool PRO, int MODE>
-static void g1_launch_k(const ConvP& p, hipStream_t st) {
+static void g1_launch_k(const ConvP& p, hipStream_t st, bool share) {
     constexpr int K = KS * 16, CHUNK = NTW * 32, PB = KS * 32 + 16;
     const int lds = 2 * CHUNK * PB + 2 * K * 4 + 8 * CHUNK * 2 * 4;
     static bool attr_done = false;
@@ -310,30 +310,35 @@ static void g1_launch_k(const ConvP& p, hipStream_t st) {
     }
     // one workgroup per CU (LDS), persistent over its share of the row blocks; column chunks side by side
     int gx = cus / chunks;
+    // DSNT_CONV_SHARE_CHIP: a launch on a side lane.  One of these workgroups takes 139 of a CU's 160 KB of LDS for the whole
+    // (persistent) launch, and the dependency chain's own launches of this kernel need a CU's LDS to themselves: on half of the
+    // CUs the side lane still finishes in time (skip branches have slack) and the chain starts at once.  Same box, ms/step:
+    // 13.83 all CUs, 13.80 at 62 %, 13.69 at 50 %, 13.71 at 38 %, 13.67 at 25 %.
+    if (share) gx = gx / 2 > 0 ? gx / 2 : 1;
     if (gx < 1) gx = 1;
     if (gx > niter) gx = niter;
     DSNT_LAUNCH((gemm1_kernel<KS, NTW, PRO, MODE>), dim3(gx, chunks), dim3(512), lds, st, p, niter);
 }
 
 template <int KS, int NTW>
-static void g1_launch(const ConvP& p, bool pro, hipStream_t st) {
-    if (p.bnb_scale) g1_launch_k<KS, NTW, false, 3>(p, st);         // data gradient with the BatchNorm-backward epilogue
+static void g1_launch(const ConvP& p, bool pro, hipStream_t st, bool share) {
+    if (p.bnb_scale) g1_launch_k<KS, NTW, false, 3>(p, st, share);         // data gradient with the BatchNorm-backward epilogue
     else if (pro) {
-        if (p.res1) g1_launch_k<KS, NTW, true, 1>(p, st);
-        else g1_launch_k<KS, NTW, true, 0>(p, st);
-    } else if (p.res1) g1_launch_k<KS, NTW, false, 1>(p, st);
-    else g1_launch_k<KS, NTW, false, 0>(p, st);
+        if (p.res1) g1_launch_k<KS, NTW, true, 1>(p, st, share);
+        else g1_launch_k<KS, NTW, true, 0>(p, st, share);
+    } else if (p.res1) g1_launch_k<KS, NTW, false, 1>(p, st, share);
+    else g1_launch_k<KS, NTW, false, 0>(p, st, share);
 }
 
-void dsnt_gemm1_launch(const ConvP& p, int ntw, bool pro, hipStream_t st) {
+void dsnt_gemm1_launch(const ConvP& p, int ntw, bool pro, hipStream_t st, bool share) {
     if (p.K == 128) {
-        if (ntw == 8) g1_launch<8, 8>(p, pro, st);
-        else if (ntw == 4) g1_launch<8, 4>(p, pro, st);
-        else g1_launch<8, 2>(p, pro, st);
+        if (ntw == 8) g1_launch<8, 8>(p, pro, st, share);
+        else if (ntw == 4) g1_launch<8, 4>(p, pro, st, share);
+        else g1_launch<8, 2>(p, pro, st, share);
     } else if (p.K == 256) {
-        g1_launch<16, 4>(p, pro, st);
+        g1_launch<16, 4>(p, pro, st, share);
     } else {
-        if (ntw == 4) g1_launch<4, 4>(p, pro, st);
-        else g1_launch<4, 2>(p, pro, st);
+        if (ntw == 4) g1_launch<4, 4>(p, pro, st, share);
+        else g1_launch<4, 2>(p, pro, st, share);
     }
 }

@@ -119,7 +119,9 @@ class Tape:
         # 3x3 forward / data gradient: the symmetric persistent kernel of csrc/conv3s.hip (stream-ordered weight planes)
         self.conv3s = 'conv3s' not in os.environ.get('DSNT_OFF', '').split(',')       # DSNT_OFF=conv3s,gemm1,wgrad3,wgrad1
         self._f16_w_stream = {}
-        self.conv3s_share = True   # DSNT_CONV_SHARE_CHIP on its side-lane launches (-0.08 ms)
+        # DSNT_CONV_SHARE_CHIP on the side lanes' launches of the two persistent kernels (3x3: 3/2 workgroups per CU; 1x1: half of
+        # the CUs): both hold most of a CU's LDS for the whole launch, and the chain's kernels need LDS too (-0.2 ms)
+        self.conv_share = True
         self.wgrad_share = True    # DSNT_WGRAD_SHARE_CHIP on every launch of that lane (-0.2 ms)
         self._wgrad_lane_reads = set()
         # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
@@ -822,8 +824,8 @@ class Tape:
             st = self.stream_ok(p, g, y.M, res2)
             self.f16_weights(p, stream=st)
             ab = self.f16_bn_bound(src) if (normed and self.training) else x_amax
-            # (bit 1 of in_relu, stream kernel only: a launch on a side lane leaves CUs with free LDS for the chain's kernels)
-            shr = 2 if (st and self.lane != 0 and self.conv3s_share) else 0
+            # (bit 1 of in_relu: a persistent kernel on a side lane leaves CUs with free LDS for the chain's kernels)
+            shr = 2 if ((st or p.R == 1) and self.lane != 0 and self.conv_share) else 0
             e = self.f('dsnt_conv_fwd_f16x3_stream' if st else 'dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, ab,
                        p.b, y.buf, sc, sh, relu | shr, r1, r2, part, g, None, tail)
             self.f16_uses.append((e, dict(kind='fwd', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
@@ -976,7 +978,7 @@ class Tape:
                     if d16:
                         e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
                                    self.dgrad_total, wbd, g_amax, None, out, None,
-                                   None, 2 if (d_stream and self.lane != 0 and self.conv3s_share) else 0, res, None, part, gd, bnb, tail)
+                                   None, 2 if ((d_stream or p.R == 1) and self.lane != 0 and self.conv_share) else 0, res, None, part, gd, bnb, tail)
                         self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
                     elif d6:
                         self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,

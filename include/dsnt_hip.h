@@ -265,8 +265,9 @@ int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int64_t plane_s
  * /root/reference/src/dsnt/hourglass.py:22-23).  Needs dsnt_conv_fwd_stream_ok(g) (H % 4 == 0, W % 32 == 0, Cin % 32 == 0 and
  * <= 128, Cout 64 or 128, tensors < 2 GiB), res2 == NULL and no ticket counters in `tail`; DSNT_ERR_SHAPE otherwise.  The
  * convolution sums are bit-identical to dsnt_conv_fwd_f16x3_ex's; stats_partial rows are [N * H/4 * W/32 patches][2][Cout].
- * in_relu: bit 0 = ReLU in the prologue; bit 1 (DSNT_CONV_SHARE_CHIP, this entry point only): the launch runs on a stream of its
- * own beside other work — 384 instead of 512 persistent workgroups, so that CUs with free LDS remain (results unchanged). */
+ * in_relu (this entry point and dsnt_conv_fwd_f16x3_ex): bit 0 = ReLU in the prologue; bit 1 (DSNT_CONV_SHARE_CHIP): the launch runs on
+ * a stream of its own beside other work — the persistent kernels (3x3 stream kernel, streaming 1x1 kernel) then start fewer
+ * workgroups (3/2 per CU; half of the CUs), so that CUs with free LDS remain for the other streams.  Results unchanged. */
 #define DSNT_CONV_SHARE_CHIP 2
 int dsnt_conv_fwd_f16x3_stream(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
                                const float* a_bound, const float* bias, float* y, const float* in_scale,

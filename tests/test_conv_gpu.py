@@ -838,6 +838,38 @@ def test_conv3_stream_kernel(case, mode):
         assert (st1[:, 1].double().sum(0) - (cols * cols).sum(0)).abs().max().item() <= 1e-4 * (cols * cols).sum(0).max().item()
 
 
+def test_share_chip_flag_of_the_streaming_1x1_kernel_changes_no_bit():
+    """DSNT_CONV_SHARE_CHIP (bit 1 of in_relu) on dsnt_conv_fwd_f16x3_ex: the streaming 1x1 kernel (>= 65536 rows) starts half as
+    many persistent workgroups; output, statistics partials and amax slot content are bit-identical."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    dev = torch.device('cuda:0')
+    N, H, W, Cin, Cout = 16, 64, 64, 128, 256
+    g = _geom(N, H, W, Cin, Cout, 1, 1, 1, 0, 1)
+    x = synthetic.tensor('shx', (N, H, W, Cin), seed=1).to(dev)
+    w = synthetic.tensor('shw', (Cout, 1, 1, Cin), seed=2, scale=0.1).to(dev)
+    b = synthetic.tensor('shb', (Cout,), seed=3, scale=0.1).to(dev)
+    sc = (synthetic.tensor('shs', (Cin,), seed=4, kind='uniform').abs() + 0.5).to(dev)
+    sh = synthetic.tensor('shh', (Cin,), seed=5, scale=0.3).to(dev)
+    res = synthetic.tensor('shr', (N, H, W, Cout), seed=6).to(dev)
+    planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+    wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    call('dsnt_amax', ptr(w), w.numel(), ptr(wb))
+    call('dsnt_split_f16x2', ptr(w), ptr(planes), w.numel(), w.numel(), ptr(wb))
+    ab.fill_(float(torch.relu(x * sc + sh).max()) * 2)
+    M = N * H * W
+    outs = []
+    for flag in (1, 1 | 2):
+        y = torch.full((N, H, W, Cout), float('nan'), device=dev)
+        st = torch.full((M // 128, 2, Cout), float('nan'), device=dev)
+        call('dsnt_conv_fwd_f16x3_ex', ptr(x), ptr(planes), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), flag,
+             ptr(res), None, ptr(st), C.byref(g), None, None)
+        outs.append((y, st))
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(outs[1][0]).any()) and not bool(torch.isnan(outs[1][1]).any())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_conv3_stream_refusals():
     """dsnt_conv_fwd_f16x3_stream refuses what the kernel does not carry: a second residual, ticket counters, other
     geometries (the caller keeps dsnt_conv_fwd_f16x3_ex for those)."""
