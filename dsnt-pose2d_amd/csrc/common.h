@@ -110,7 +110,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 #endif
 
-// DSNT_OFF=<name>[,<name>...]: kernels of round 3 to leave out (conv3s, gemm1, wgrad3, wgrad1) — the launch then takes the
+// DSNT_OFF=<name>[,<name>...] (',' or '+' between names): kernels of round 3 to leave out (conv3s, gemm1, wgrad3, wgrad1) — the launch then takes the
 // round-2 kernel of the same contract.  Host side; read at the first launch that asks.
 #include <stdlib.h>
 #include <string.h>
@@ -119,6 +119,6 @@ static inline bool dsnt_kernel_off(const char* name) {
     if (!e) return false;
     const size_t n = strlen(name);
     for (const char* q = e; (q = strstr(q, name)) != nullptr; q += n)
-        if ((q == e || q[-1] == ',') && (q[n] == 0 || q[n] == ',')) return true;
+        if ((q == e || q[-1] == ',' || q[-1] == '+') && (q[n] == 0 || q[n] == ',' || q[n] == '+')) return true;
     return false;
 }

@@ -117,7 +117,7 @@ class Tape:
         self.wgrad_lane_res = False
         self.wgrad_lane_from = self.chain_lanes
         # 3x3 forward / data gradient: the symmetric persistent kernel of csrc/conv3s.hip (stream-ordered weight planes)
-        self.conv3s = 'conv3s' not in os.environ.get('DSNT_OFF', '').split(',')       # DSNT_OFF=conv3s,gemm1,wgrad3,wgrad1
+        self.conv3s = 'conv3s' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')       # DSNT_OFF=conv3s,gemm1,wgrad3,wgrad1
         self._f16_w_stream = {}
         # DSNT_CONV_SHARE_CHIP on the side lanes' launches of the two persistent kernels (3x3: 3/2 workgroups per CU; 1x1: half of
         # the CUs): both hold most of a CU's LDS for the whole launch, and the chain's kernels need LDS too (-0.2 ms)
