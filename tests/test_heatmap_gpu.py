@@ -117,7 +117,9 @@ def test_gauss_strategy_train_step(dev, base):
     assert abs(loss.item() - lo.item()) <= 2e-5 * max(1.0, abs(lo.item()))
     gm = torch.cat([p.grad.reshape(-1).cpu() for p in m.parameters()]).double()
     go = torch.cat([p.grad.reshape(-1) for p in o.parameters()]).double()
-    assert float(gm @ go / (gm.norm() * go.norm())) > 0.9999
+    # (ReLU on, batch 2: one mask bit flipped between two correct fp32 implementations moves the flat gradient by ~1e-4 in
+    # cosine — tests/test_model_gpu.py::_NoRelu; the flip-tolerant bar of the other ReLU-on tests)
+    assert float(gm @ go / (gm.norm() * go.norm())) > 0.999
     last = out[-1] if isinstance(out, list) else out
     coords = m.compute_coords(out)
     assert coords.device.type == 'cpu' and coords.shape == (2, 16, 2)
