@@ -166,6 +166,7 @@ class Program:
         self.token = 0
         dev = arena.device
         tape = Tape(dev, training)
+        tape.want_input_grad = bool(input_grad and training)     # the stem then keeps its data gradient (no space-to-depth form)
         tape.param_arena = arena.params
         self.tape = tape
         names = {id(m): n for n, m in root.named_modules()}
@@ -441,7 +442,7 @@ class Hourglass(TapeModule):
 
 class HourglassNet(TapeModule):
     """Hourglass model from Newell et al. ECCV 2016 (reference hourglass.py:96-177)."""
-    supports_input_grad = False
+    supports_input_grad = True
 
     def __init__(self, block, num_stacks=2, num_blocks=4, num_classes=16):
         super().__init__()
@@ -499,7 +500,10 @@ class HourglassNet(TapeModule):
                                '(stem /4, four 2x2 poolings), got %dx%d' % (x.H, x.W))
         t.mark_bucket(0)
         stem = P.conv(self.conv1)
-        x = t.stem_s2d(x, stem) or t.conv(x, stem, want_stats=True, need_input_grad=False, name='stem')
+        # d loss / d image (the reference's autograd gives it; train.py never asks): the plain 7x7 / stride 2 convolution with its
+        # zero-stuffed data gradient instead of the space-to-depth form
+        gi = getattr(t, 'want_input_grad', False)
+        x = (None if gi else t.stem_s2d(x, stem)) or t.conv(x, stem, want_stats=True, need_input_grad=gi, name='stem')
         x = t.bn_act(x, P.bn(self.bn1), relu=True, name='stem_act')
         x = _trace_seq(self.layer1, t, x, P)
         x = t.maxpool2(x)

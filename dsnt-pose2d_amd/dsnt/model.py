@@ -156,7 +156,7 @@ class ResNetHumanPoseModel(HumanPoseModel, hourglass.TapeModule):
     Same constructor, attributes, quirks and `state_dict()` keys (`fcn.0.weight`, `fcn.4.0.conv1.weight`,
     `hm_conv.weight`, ...).  `forward_part1` runs the traced HIP launch lists of the whole FCN; outputs
     are single tensors, not lists (`:143-171`)."""
-    supports_input_grad = False
+    supports_input_grad = True
 
     def __init__(self, resnet, n_chans=16, dilate=0, truncate=0, output_strat='dsnt',
                  preact='softmax', reg='none', reg_coeff=1.0, hm_sigma=1.0):

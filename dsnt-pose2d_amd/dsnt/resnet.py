@@ -126,7 +126,8 @@ def trace_fcn(fcn, hm_conv, t, x, P):
     conv1, bn1 = fcn[0], fcn[1]
     t.mark_bucket(0)        # one gradient bucket: its all-reduce starts when the stem's weight gradient is done
     stem = P.conv(conv1)
-    x = t.stem_s2d(x, stem) or t.conv(x, stem, want_stats=True, need_input_grad=False, name='stem')
+    gi = getattr(t, 'want_input_grad', False)      # d loss / d image: the plain stem convolution with its data gradient
+    x = (None if gi else t.stem_s2d(x, stem)) or t.conv(x, stem, want_stats=True, need_input_grad=gi, name='stem')
     x = t.bn_act(x, P.bn(bn1), relu=True, name='stem_act')
     x = t.maxpool3s2(x, name='pool')
     for layer in list(fcn)[4:]:

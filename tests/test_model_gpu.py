@@ -271,6 +271,43 @@ def test_gradients_with_the_slab_reduction_inside_every_launch(monkeypatch):
         assert float((a[n] - b[n]).abs().max()) <= 2e-5 * scale + 1e-9, n
 
 
+@pytest.mark.parametrize('base', ['hg1'])
+def test_gradient_with_respect_to_the_input_image(base):
+    """d loss / d image (the reference's autograd provides it for any input that requires a gradient; train.py never asks):
+    a program traced for such an input keeps the stem as the plain 7x7 / stride 2 convolution and takes its data gradient
+    through the zero-stuffed stride-1 kernels.  Smooth network (no ReLU) against the oracle: relative L2 <= 1e-3; and the
+    parameter gradients of that program equal the ordinary program's to the same bar (another stem kernel, same numbers)."""
+    from dsnt.model import build_mpii_pose_model
+    from dsnt_oracle import model as omodel
+    kw = dict(output_strat='dsnt', reg='js')
+    with _NoRelu():
+        m = build_mpii_pose_model(base=base, **kw)
+        o = omodel.build_mpii_pose_model(base=base, **kw)
+        _NoRelu.strip(o)
+        synthetic.fill_state_dict(m, seed=5)
+        synthetic.fill_state_dict(o, seed=5)
+        m.cuda().train()
+        o.train()
+        x, target, mask = synthetic.batch(2, size=128, seed=4, mask_p=0.8)
+        xg = x.to(DEV).requires_grad_()
+        loss = m.forward_loss(m(xg), target.to(DEV), mask.to(DEV))
+        loss.backward()
+        g_in = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+        for p in m.parameters():
+            p.grad = None
+        loss2 = m.forward_loss(m(x.to(DEV)), target.to(DEV), mask.to(DEV))      # the ordinary program of the same shape
+        loss2.backward()
+        xo = x.clone().requires_grad_()
+        lo = o.forward_loss(o(xo), target, mask)
+        lo.backward()
+    assert xg.grad is not None and xg.grad.shape == x.shape
+    assert abs(loss.item() - lo.item()) <= 1e-4 * max(1.0, abs(lo.item()))
+    assert _rel_l2(xg.grad.cpu(), xo.grad) <= 1e-3, _rel_l2(xg.grad.cpu(), xo.grad)
+    floor = 1e-3 * max(v.double().norm().item() for v in g_in.values())
+    for n, p in m.named_parameters():
+        assert _rel_l2(g_in[n], p.grad, floor) <= 1e-3, n
+
+
 def test_hg8_every_gradient_vs_oracle_on_the_smooth_network():
     """hg8 + DSNT + JS (BASELINE config 5's model; batch 2, 128 px) against the CPU oracle: coordinates of all eight
     stacks within 1e-4, the loss, and — with the ReLUs taken out on both sides, so that no mask bit can flip — every

@@ -87,6 +87,30 @@ class _SmoothResNet:
         self.ores.F = self.saved
 
 
+def test_resnet_gradient_with_respect_to_the_input_image():
+    """d loss / d image through the ResNet FCN (stem 7x7 / 2 data gradient by zero-stuffing, 3x3 / 2 max-pool, strided
+    stage transitions) on the smooth network against the oracle: relative L2 <= 1e-3."""
+    from dsnt.model import build_mpii_pose_model
+    from dsnt_oracle import model as omodel
+    import torch.nn as nn
+    kw = dict(base='resnet18', dilate=2, truncate=0, output_strat='dsnt', reg='js')
+    with _SmoothResNet():
+        m = build_mpii_pose_model(**kw)
+        o = omodel.build_mpii_pose_model(**kw)
+        o.fcn[2] = nn.Identity()
+        synthetic.fill_state_dict(m, seed=4)
+        synthetic.fill_state_dict(o, seed=4)
+        m.cuda().train()
+        o.train()
+        x, target, mask = synthetic.batch(2, size=128, seed=6, mask_p=0.8)
+        xg = x.to(DEV).requires_grad_()
+        m.forward_loss(m(xg), target.to(DEV), mask.to(DEV)).backward()
+        xo = x.clone().requires_grad_()
+        o.forward_loss(o(xo), target, mask).backward()
+    e = (xg.grad.cpu().double() - xo.grad.double()).norm().item() / xo.grad.double().norm().item()
+    assert xg.grad.shape == x.shape and e <= 1e-3, e
+
+
 CASES = [
     # base, dilate, truncate, size, batch, mfma
     ('resnet18', 0, 0, 128, 4, 'f32'),
