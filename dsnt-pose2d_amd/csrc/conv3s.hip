@@ -7,8 +7,8 @@
 // the 128 x 128 result) are another 18 k cycles per tile with the matrix pipe idle.  Here:
 //   * four waves, ALL alike: every wave copies its share of the weights and of the input halo between its own MFMAs
 //     (an MFMA holds the vector issue port for 8 of its 32 cycles — the staging work of a step fits beside them);
-//   * a tile is a 4 x 32 patch of output pixels x all Cout (64 / 128) columns; the (4+2) x (32+2) input halo of a
-//     16-channel chunk is transformed (BatchNorm + ReLU, operand scale) and split ONCE into LDS, double-buffered;
+//   * a tile is a 4 x 32 patch (8 x 16 where the image is 16 pixels wide) of output pixels x all Cout (64 / 128) columns; the
+//     (4+2) x (32+2) input halo of a 16-channel chunk is transformed (BatchNorm + ReLU, operand scale) and split ONCE into LDS, double-buffered;
 //   * the weights come pre-split in STREAM order ([chunk][tap][Cout][16]: dsnt_f16_prep_weights, row flag): a K-step
 //     pair is one contiguous 16 KB block, copied with coalesced 16-byte loads one pair ahead into a two-slot ring;
 //   * ONE barrier per pair of K-steps (24 MFMAs per wave), placed between the two steps: the fragments of the step
@@ -25,20 +25,20 @@
 
 typedef unsigned c3_u32x4 __attribute__((ext_vector_type(4)));
 
-#define C3_PH 4
-#define C3_PW 32
-#define C3_HW (C3_PW + 2)
-#define C3_HPX ((C3_PH + 2) * C3_HW)        /* 204 halo pixels */
+#define C3_HPX 204                          /* halo pixels of a 4 x 32 patch (6 x 34); an 8 x 16 patch needs 10 x 18 = 180 */
 #define C3_AP 48                            /* bytes per halo pixel and plane: 16 fp16 + 16 (conflict-free ds_read_b128) */
 #define C3_APL (C3_HPX * C3_AP)
 #define C3_ABUF (2 * C3_APL)
 #define C3_BP 80                            /* bytes per weight row and plane of a slot: 2 x 16 fp16 + 16 */
-#define C3_ITEMS (C3_HPX * 4)
 
 // MODE: 0 no residual, 1 res1, 3 the BatchNorm-backward epilogue of a data-gradient launch (res1 = the BatchNorm input x)
-template <int CO, bool PRO, int MODE>
+// PW: the patch is 128 / PW rows of PW pixels — 4 x 32 (W % 32 == 0), or 8 x 16 for the 16-pixel-wide levels (a 32-pixel MFMA
+// tile then spans two patch rows: a few two-way LDS bank conflicts on the activation fragments, immaterial at that size)
+template <int CO, bool PRO, int MODE, int PW>
 __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     constexpr int WN = CO / 64, WM = 4 / WN, TM = 4 / WM, TN = 2;
+    constexpr int PH = 128 / PW, HW = PW + 2, HPX = (PH + 2) * HW, ITEMS = HPX * 4;
+    static_assert(HPX <= C3_HPX, "halo buffer");
     constexpr int BPL = CO * C3_BP, BSLOT = 2 * BPL;
     constexpr int NJB = CO / 32;                // 16-byte weight units per thread and K-step pair
     constexpr int UPP = 4 * CO;                 // units per plane and pair
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     const int wm = wave / WN, wn = wave % WN;
     const int nchunks = p.Cin >> 4;             // even
     const int npairs = nchunks * 9 / 2;
-    const int tws = p.W / C3_PW, ths = p.H / C3_PH;
+    const int tws = p.W / PW, ths = p.H / PH;
     const float sa = pow2_scale(bound64(p.a_bound)), sw = pow2_scale(bound64(p.w_bound));
     const float osc = 1.f / (sa * sw);
 
@@ -84,13 +84,13 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int px = (tid >> 2) + 64 * j;
-            const int hy = px / C3_HW, hx = px - hy * C3_HW;
-            const int ih = th * C3_PH - 1 + hy, iw = tw * C3_PW - 1 + hx;
-            const bool in = live && px < C3_HPX && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const int hy = px / HW, hx = px - hy * HW;
+            const int ih = th * PH - 1 + hy, iw = tw * PW - 1 + hx;
+            const bool in = live && px < HPX && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             aoffs[j] = in ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + kc * 4) * 4u : OOB;
             aok |= (in ? 1u : 0u) << j;
         }
-        return (img * p.H + th * C3_PH) * p.W + tw * C3_PW;
+        return (img * p.H + th * PH) * p.W + tw * PW;
     };
     c3_u32x4 ra[4];
     const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (j == 3 && tid >= C3_ITEMS - 768) continue;
+            if (tid + 256 * j >= ITEMS) continue;
             float4 v = make_float4(__uint_as_float(ra[j].x), __uint_as_float(ra[j].y),
                                    __uint_as_float(ra[j].z), __uint_as_float(ra[j].w));
             if (PRO) {
@@ -160,13 +160,17 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     struct Frag { f16x8 a[TM][2], b[TN][2]; };
     unsigned aoff[TM], boff[TN];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) aoff[a] = (unsigned)(((wm * TM + a) * C3_HW + lr) * C3_AP + 16 * lh);
+    for (int a = 0; a < TM; ++a) {
+        const int mt = wm * TM + a;              // 32-pixel tile of the patch: one patch row (PW 32) or two (PW 16)
+        const int prow = PW == 32 ? mt : 2 * mt + (lr >> 4), pcol = lr & (PW - 1);
+        aoff[a] = (unsigned)((prow * HW + pcol) * C3_AP + 16 * lh);
+    }
 #pragma unroll
     for (int b = 0; b < TN; ++b) boff[b] = (unsigned)(((wn * TN + b) * 32 + lr) * C3_BP + 16 * lh);
     // local K-step s of a chunk pair (0..17; 18 = step 0 of the next pair): chunk buffer (s / 9) & 1, tap s % 9
     auto rd = [&](Frag& F, const int s, const unsigned slot) {
         const int t = s % 9, buf = (s / 9) & 1;
-        const int toff = buf * C3_ABUF + ((t / 3) * C3_HW + (t % 3)) * C3_AP;
+        const int toff = buf * C3_ABUF + ((t / 3) * HW + (t % 3)) * C3_AP;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
@@ -208,14 +212,19 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
             float rbuf[2][NR];
             auto tile_off = [&](const int i) {       // i = b * TM + a
                 const int a = i % TM, b = i / TM;
-                return (unsigned)((m0 + (wm * TM + a) * p.W + 4 * lh) * p.Cout + (wn * TN + b) * 32 + lr) * 4u;
+                return (unsigned)((m0 + (wm * TM + a) * (PW == 32 ? 1 : 2) * p.W + 4 * lh) * p.Cout + (wn * TN + b) * 32 + lr) * 4u;
+            };
+            // register e -> pixel (e&3) + 8 (e>>2) + 4 lh of the 32-pixel tile; PW 16: pixels 16.. are the next patch row
+            auto reg_off = [&](const int e) {
+                return PW == 32 ? (unsigned)((e & 3) + 8 * (e >> 2)) * rowbytes
+                                : (unsigned)((e >> 3) * p.W + (e & 3) + 8 * ((e >> 2) & 1)) * rowbytes;
             };
             auto loadres = [&](float (&r)[NR], const int i) {
                 if (MODE == 0) return;
                 const unsigned o0 = tile_off(i);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const unsigned so = (unsigned)((e & 3) + 8 * (e >> 2)) * rowbytes;
+                    const unsigned so = reg_off(e);
                     r[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1r, o0, so, 0));
                 }
             };
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 const unsigned o0 = tile_off(i);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const unsigned so = (unsigned)((e & 3) + 8 * (e >> 2)) * rowbytes;
+                    const unsigned so = reg_off(e);
                     float val = acc[a][b][e] * osc;
                     if (MODE == 3) {
                         // val = dL/d relu(bn(x)); r = x: mask by the ReLU, accumulate the BatchNorm-backward sums
@@ -384,7 +393,7 @@ bool dsnt_conv3s_geom_ok(const dsnt_conv_geom* g) {
     }
     if (!c3_enabled || !g) return false;
     if (!(g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1 && g->dil == 1 && g->Ho == g->H && g->Wo == g->W)) return false;
-    if (g->H % C3_PH != 0 || g->W % C3_PW != 0 || g->Cin % 32 != 0 || g->Cin > 128) return false;
+    if (!((g->H % 4 == 0 && g->W % 32 == 0) || (g->H % 8 == 0 && g->W % 16 == 0)) || g->Cin % 32 != 0 || g->Cin > 128) return false;
     if (g->Cout != 64 && g->Cout != 128) return false;
     const size_t M = (size_t)g->N * g->H * g->W;
     if (M * g->Cin * 4u >= (1ull << 31) || M * g->Cout * 4u >= (1ull << 31)) return false;
@@ -403,12 +412,12 @@ bool dsnt_conv3s_ok(const ConvP& p) {
     return true;
 }
 
-template <int CO, bool PRO, int MODE>
-static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
+template <int CO, bool PRO, int MODE, int PW>
+static void c3_launch_k(const ConvP& p, hipStream_t st, bool share) {
     const int lds = 2 * C3_ABUF + 2 * 2 * CO * C3_BP + 1024;       // halo buffers, weight ring, BatchNorm vectors
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv3s_kernel<CO, PRO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)conv3s_kernel<CO, PRO, MODE, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     static int cus = 0;
@@ -418,7 +427,7 @@ static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
         hipGetDevice(&dev);
         cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    const int ntiles = p.N * (p.H / C3_PH) * (p.W / C3_PW);
+    const int ntiles = p.N * (p.H / (128 / PW)) * (p.W / PW);
     int grid = 2 * cus;                         // two workgroups per CU (LDS), persistent over the tiles
     // DSNT_CONV_SHARE_CHIP: a launch on a side lane.  Two of these workgroups take a CU's whole LDS for the life of the launch,
     // and the dependency chain's small kernels on the other streams then wait for a slot (a bn_finalize of 8 workgroups: 63 us
@@ -426,7 +435,13 @@ static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
     // lane's 1x1 kernel yields half of the CUs — gemm1.hip — this one's share no longer matters: 128 .. 512 workgroups within 0.03 ms).
     if (share) grid = cus + cus / 2;
     if (grid > ntiles) grid = ntiles;
-    DSNT_LAUNCH((conv3s_kernel<CO, PRO, MODE>), dim3(grid), dim3(256), lds, st, p, ntiles);
+    DSNT_LAUNCH((conv3s_kernel<CO, PRO, MODE, PW>), dim3(grid), dim3(256), lds, st, p, ntiles);
+}
+
+template <int CO, bool PRO, int MODE>
+static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
+    if (p.W % 32 == 0 && p.H % 4 == 0) c3_launch_k<CO, PRO, MODE, 32>(p, st, share);
+    else c3_launch_k<CO, PRO, MODE, 16>(p, st, share);
 }
 
 template <int CO>

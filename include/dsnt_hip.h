@@ -262,9 +262,9 @@ int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int64_t plane_s
                            const dsnt_bn_tail* tail, void* stream);
 /* The same call for a 3x3 / stride 1 / pad 1 convolution whose weight planes are in the STREAM layout of
  * dsnt_f16_prep_weights (row flag): the symmetric persistent kernel of csrc/conv3s.hip (cuDNN's 3x3 forward / data gradient of
- * /root/reference/src/dsnt/hourglass.py:22-23).  Needs dsnt_conv_fwd_stream_ok(g) (H % 4 == 0, W % 32 == 0, Cin % 32 == 0 and
- * <= 128, Cout 64 or 128, tensors < 2 GiB), res2 == NULL and no ticket counters in `tail`; DSNT_ERR_SHAPE otherwise.  The
- * convolution sums are bit-identical to dsnt_conv_fwd_f16x3_ex's; stats_partial rows are [N * H/4 * W/32 patches][2][Cout].
+ * /root/reference/src/dsnt/hourglass.py:22-23).  Needs dsnt_conv_fwd_stream_ok(g) (H % 4 == 0 and W % 32 == 0, or H % 8 == 0 and
+ * W % 16 == 0; Cin % 32 == 0 and <= 128, Cout 64 or 128, tensors < 2 GiB), res2 == NULL and no ticket counters in `tail`; DSNT_ERR_SHAPE otherwise.  The
+ * convolution sums are bit-identical to dsnt_conv_fwd_f16x3_ex's; stats_partial rows are one per 128-pixel patch (4 x 32, or 8 x 16 when W % 32 != 0): [N * H * W / 128][2][Cout].
  * in_relu (this entry point and dsnt_conv_fwd_f16x3_ex): bit 0 = ReLU in the prologue; bit 1 (DSNT_CONV_SHARE_CHIP): the launch runs on
  * a stream of its own beside other work — the persistent kernels (3x3 stream kernel, streaming 1x1 kernel) then start fewer
  * workgroups (3/2 per CU; half of the CUs), so that CUs with free LDS remain for the other streams.  Results unchanged. */

@@ -735,6 +735,9 @@ STREAM_CASES = [
     (40, 64, 64, 32, 64),         # 1280 patches on 512 persistent workgroups: 2-3 tiles each, ragged
     (2, 32, 32, 128, 128),        # the oracle-sized model tests: 16 patches, one per image row block
     (2, 64, 64, 64, 64),
+    (32, 16, 16, 128, 128),       # 16 pixels wide: 8 x 16 patches (the 16 x 16 hourglass level at batch 32: 64 patches)
+    (3, 8, 16, 64, 64),
+    (2, 24, 48, 32, 128),         # W % 32 != 0 -> 8 x 16 patches, three per row
 ]
 
 
@@ -878,7 +881,8 @@ def test_conv3_stream_refusals():
     dev = torch.device('cuda:0')
     ok = _lib.fn('dsnt_conv_fwd_stream_ok')
     assert ok(C.byref(_geom(2, 16, 32, 64, 64, 3, 3, 1, 1, 1))) == 1
-    for bad in [(2, 16, 16, 64, 64, 3, 3, 1, 1, 1), (2, 6, 32, 64, 64, 3, 3, 1, 1, 1), (2, 16, 32, 48, 64, 3, 3, 1, 1, 1),
+    assert ok(C.byref(_geom(2, 16, 16, 64, 64, 3, 3, 1, 1, 1))) == 1          # 8 x 16 patches
+    for bad in [(2, 12, 16, 64, 64, 3, 3, 1, 1, 1), (2, 6, 32, 64, 64, 3, 3, 1, 1, 1), (2, 16, 32, 48, 64, 3, 3, 1, 1, 1), (2, 16, 24, 64, 64, 3, 3, 1, 1, 1),
                 (2, 16, 32, 64, 96, 3, 3, 1, 1, 1), (2, 16, 32, 64, 64, 1, 1, 1, 0, 1), (2, 16, 32, 256, 64, 3, 3, 1, 1, 1),
                 (2, 16, 32, 64, 64, 3, 3, 1, 2, 2)]:
         assert ok(C.byref(_geom(*bad))) == 0, bad

@@ -103,7 +103,7 @@ def test_eval_mode_schedule_of_hg2(monkeypatch_module):
     assert names.count('dsnt_bn_eval_prep') == 1 and 'dsnt_bn_finalize' not in names and 'dsnt_bn_stats' not in names
     assert names[0] == 'dsnt_fill_zero'
     assert names.count('dsnt_conv_fwd_f16x3_ex') + names.count('dsnt_conv_fwd_f16x3_stream') >= 40
-    assert names.count('dsnt_conv_fwd_f16x3_stream') == 13       # the 3x3 convolutions of the 128 / 64 / 32 pixel levels
+    assert names.count('dsnt_conv_fwd_f16x3_stream') == 19       # the 3x3 convolutions of the 128 / 64 / 32 / 16 pixel levels
     assert {lane for _, lane, _ in fwd} == {0, 1}            # the forward-only trace forks every skip branch onto lane 1
     assert len(fwd) <= 135, len(fwd)
 
