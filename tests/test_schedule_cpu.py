@@ -74,6 +74,26 @@ def test_backward_list_lanes_and_fusions(tape):
     assert [n for n, _, _ in bwd[:3]][0] == 'dsnt_fill_zero' and 'dsnt_conv_pack_dgrad_all' not in [n for n, _, _ in bwd]
 
 
+def test_persistent_kernels_share_the_chip_on_side_lanes(tape):
+    """DSNT_CONV_SHARE_CHIP (bit 1 of in_relu, argument 9 of dsnt_conv_fwd_f16x3_ex / _stream): set on every 1x1 and stream-kernel
+    launch of the skip-branch lanes (1, 3), forward and backward, never on the dependency chain's lane — the persistent 3x3 and
+    1x1 kernels hold most of a CU's LDS for a whole launch (csrc/conv3s.hip, csrc/gemm1.hip)."""
+    seen = collections.Counter()
+    for lst in (tape.fwd, tape.bwd):
+        for name, lane, args in _launches(lst):
+            if name not in ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_f16x3_stream'):
+                continue
+            g = args[13]
+            g = getattr(g, '_obj', g)
+            flag = int(args[9]) & 2
+            if lane == 0:
+                assert flag == 0, (name, lane)
+            elif name.endswith('_stream') or g.R == 1:
+                assert flag == 2, (name, lane)
+                seen[name] += 1
+    assert seen['dsnt_conv_fwd_f16x3_stream'] >= 8 and seen['dsnt_conv_fwd_f16x3_ex'] >= 16, seen
+
+
 def test_launch_counts_stay_bounded(tape):
     nf, nb = len(_launches(tape.fwd)), len(_launches(tape.bwd))
     assert nf <= 235 and nb <= 400, (nf, nb)
