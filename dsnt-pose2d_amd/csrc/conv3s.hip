@@ -20,6 +20,10 @@
 // Same K order (16-channel chunk, tap) and MFMA order as conv3x3_bf16x6_kernel<.., F16>: the convolution sums are
 // bit-identical to that kernel's; the per-tile column statistics are summed in another order.
 // Contract: conv_fwd_bf16x6_kernel<..., F16> minus the second residual and the BatchNorm tail counters (dsnt_conv3s_ok).
+// Measured (DESIGN.md "round 3", profiles/r03_pmc_issue_accounting.txt): 3x3 128->128 @64x64, batch 32: 129 -> 104 us on one box
+// (matrix pipe 53 %, 1.15 PFLOP/s of fp16 MFMA at the ~1.9 GHz this load holds), -0.42 ms per hg2 step.  Built on the same pieces,
+// bit-identical, and dropped: an 8-wave ping-pong form (two groups one phase apart, 101-110 us, but one 124 KB workgroup per CU
+// starves the other lanes: +0.07 ms per step), deeper halo prefetch (108 us), a start-up stagger of the CU's second workgroup (+-0).
 #include "conv3s.h"
 #include <stdlib.h>
 
