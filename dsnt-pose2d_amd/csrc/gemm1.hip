@@ -51,32 +51,9 @@ __global__ __launch_bounds__(512, 2) void gemm1_kernel(ConvP p, int niter) {
     const float sa = pow2_scale(bound64(p.a_bound)), sw = pow2_scale(bound64(p.w_bound));
     const float osc = 1.f / (sa * sw);
 
-    // ---- weights -> LDS (k permuted inside each 16-wide step: positions [0..3, 8..11 | 4..7, 12..15])
-    for (int u = tid; u < 2 * CHUNK * KS * 2; u += 512) {
-        const int half8 = u & 1, s = (u >> 1) % KS, n = (u / (2 * KS)) % CHUNK, pl = u / (2 * KS * CHUNK);
-        const uint4 v = *reinterpret_cast<const uint4*>(p.wq + (size_t)pl * p.wq_stride + (size_t)(n0 + n) * K + 16 * s + 8 * half8);
-        unsigned char* d = Bs + pl * PLB + n * PB + s * 32 + half8 * 8;      // k-quad q = 2 half8 -> position 4 half8 ...
-        *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
-        *reinterpret_cast<uint2*>(d + 16) = make_uint2(v.z, v.w);            // ... q + 1 -> position 8 + 4 half8
-    }
-    if (PRO) {
-        for (int k = tid; k < K; k += 512) {
-            SS[k] = p.in_scale[k] * sa;
-            SS[K + k] = p.in_shift[k] * sa;
-        }
-    }
-    const float relu_lo = (PRO && p.in_relu) ? 0.f : -__builtin_inff();
+    // ---- the first K-steps of this workgroup's first row block go out before anything else: they travel while the weights are copied
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x), 0, (int)((size_t)p.M * K * 4u), 0x00020000);
-    // epilogue tensors through buffer descriptors: 32-bit lane offsets, the 16 row offsets of a tile as scalars
-    const int ybytes = (int)((size_t)p.M * p.Cout * 4u);
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res1 ? p.res1 : p.y), 0, ybytes, 0x00020000);
-    const unsigned rowbytes = (unsigned)p.Cout * 4u;
-    const float am2lo = p.tail.amax_relu ? 0.f : -__builtin_inff();
-    float am = 0.f, am2 = 0.f;
-    __syncthreads();
-
     int it = blockIdx.x;
     unsigned voff[RT];
     g1_u32x4 raw[DD][RT][2];
@@ -97,6 +74,33 @@ __global__ __launch_bounds__(512, 2) void gemm1_kernel(ConvP p, int niter) {
     rows_of(it);
 #pragma unroll
     for (int s = 0; s < DD; ++s) issue(s, s);
+
+
+    // ---- weights -> LDS (k permuted inside each 16-wide step: positions [0..3, 8..11 | 4..7, 12..15])
+    // (four independent 16-byte loads in flight per thread: the copy is 2 * CHUNK * K * 2 bytes = up to 139 KB per workgroup)
+#pragma unroll 4
+    for (int u = tid; u < 2 * CHUNK * KS * 2; u += 512) {
+        const int half8 = u & 1, s = (u >> 1) % KS, n = (u / (2 * KS)) % CHUNK, pl = u / (2 * KS * CHUNK);
+        const uint4 v = *reinterpret_cast<const uint4*>(p.wq + (size_t)pl * p.wq_stride + (size_t)(n0 + n) * K + 16 * s + 8 * half8);
+        unsigned char* d = Bs + pl * PLB + n * PB + s * 32 + half8 * 8;      // k-quad q = 2 half8 -> position 4 half8 ...
+        *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(d + 16) = make_uint2(v.z, v.w);            // ... q + 1 -> position 8 + 4 half8
+    }
+    if (PRO) {
+        for (int k = tid; k < K; k += 512) {
+            SS[k] = p.in_scale[k] * sa;
+            SS[K + k] = p.in_shift[k] * sa;
+        }
+    }
+    const float relu_lo = (PRO && p.in_relu) ? 0.f : -__builtin_inff();
+    // epilogue tensors through buffer descriptors: 32-bit lane offsets, the 16 row offsets of a tile as scalars
+    const int ybytes = (int)((size_t)p.M * p.Cout * 4u);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res1 ? p.res1 : p.y), 0, ybytes, 0x00020000);
+    const unsigned rowbytes = (unsigned)p.Cout * 4u;
+    const float am2lo = p.tail.amax_relu ? 0.f : -__builtin_inff();
+    float am = 0.f, am2 = 0.f;
+    __syncthreads();
 
     for (; it < niter; it += gridDim.x) {
         const int rowbase = it * ROWS_IT + wave * ROWS_W;
