@@ -77,14 +77,26 @@ __global__ __launch_bounds__(512, 2) void gemm1_kernel(ConvP p, int niter) {
 
 
     // ---- weights -> LDS (k permuted inside each 16-wide step: positions [0..3, 8..11 | 4..7, 12..15])
-    // (four independent 16-byte loads in flight per thread: the copy is 2 * CHUNK * K * 2 bytes = up to 139 KB per workgroup)
-#pragma unroll 4
-    for (int u = tid; u < 2 * CHUNK * KS * 2; u += 512) {
-        const int half8 = u & 1, s = (u >> 1) % KS, n = (u / (2 * KS)) % CHUNK, pl = u / (2 * KS * CHUNK);
-        const uint4 v = *reinterpret_cast<const uint4*>(p.wq + (size_t)pl * p.wq_stride + (size_t)(n0 + n) * K + 16 * s + 8 * half8);
-        unsigned char* d = Bs + pl * PLB + n * PB + s * 32 + half8 * 8;      // k-quad q = 2 half8 -> position 4 half8 ...
-        *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
-        *reinterpret_cast<uint2*>(d + 16) = make_uint2(v.z, v.w);            // ... q + 1 -> position 8 + 4 half8
+    // (all of a thread's 16-byte loads in flight at once — the copy is 2 * CHUNK * K * 2 bytes = up to 139 KB per workgroup,
+    // 4 .. 16 loads per thread — then the LDS stores: one L2 round trip instead of one per load)
+    {
+        constexpr int NW = 2 * CHUNK * KS * 2 / 512;
+        static_assert(NW * 512 == 2 * CHUNK * KS * 2, "weight units per thread");
+        uint4 wv[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int u = tid + 512 * j;
+            const int half8 = u & 1, s = (u >> 1) % KS, n = (u / (2 * KS)) % CHUNK, pl = u / (2 * KS * CHUNK);
+            wv[j] = *reinterpret_cast<const uint4*>(p.wq + (size_t)pl * p.wq_stride + (size_t)(n0 + n) * K + 16 * s + 8 * half8);
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int u = tid + 512 * j;
+            const int half8 = u & 1, s = (u >> 1) % KS, n = (u / (2 * KS)) % CHUNK, pl = u / (2 * KS * CHUNK);
+            unsigned char* d = Bs + pl * PLB + n * PB + s * 32 + half8 * 8;      // k-quad q = 2 half8 -> position 4 half8 ...
+            *reinterpret_cast<uint2*>(d) = make_uint2(wv[j].x, wv[j].y);
+            *reinterpret_cast<uint2*>(d + 16) = make_uint2(wv[j].z, wv[j].w);    // ... q + 1 -> position 8 + 4 half8
+        }
     }
     if (PRO) {
         for (int k = tid; k < K; k += 512) {
