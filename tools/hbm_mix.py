@@ -1,3 +1,5 @@
+"""HBM bandwidth of four access mixes with stock torch kernels on 512 MB tensors (write only / copy / two reads + one write /
+read only): a reference for the write-heavy 1x1 kernels.  python tools/hbm_mix.py"""
 import torch, time
 dev='cuda:0'
 n=128*1024*1024
