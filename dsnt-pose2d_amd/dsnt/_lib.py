@@ -131,6 +131,7 @@ SIGNATURES = {
     'dsnt_bn_add_act_fwd': [P, P, P, P, I, P, L, I, P],
     'dsnt_relu_bwd': [P, P, P, L, P],
     'dsnt_zero_insert': [P, P, I, I, I, I, I, I, I, P],
+    'dsnt_conv_dgrad_strided': [P, P, P, P, P, GP, BP, TP, P],
     'dsnt_upsample2_add_fwd': [P, P, P, I, I, I, I, P],
     'dsnt_upsample2_bwd': [P, P, I, I, I, I, I, P],
     'dsnt_axpy': [P, P, F, I, L, P],
@@ -171,6 +172,8 @@ PLAIN = {
     'dsnt_conv_wgrad_splits': (I, [GP]),
     'dsnt_conv_wgrad_halo_ok': (I, [GP]),
     'dsnt_conv_fwd_stream_ok': (I, [GP]),
+    'dsnt_conv_dgrad_strided_ok': (I, [GP]),
+    'dsnt_conv_dgrad_strided_tiles': (I, [GP]),
     'dsnt_conv_fwd_pro_ok': (I, [GP, I, I]),
     'dsnt_conv_wgrad_f16x3_splits': (I, [GP, I]),
     'dsnt_conv_wgrad_f16x3_ws_floats': (L, [GP, I]),

@@ -939,11 +939,16 @@ class Tape:
                 nw = p.w.numel()
                 pad_d = p.dil * (p.R - 1) - p.pad
                 assert pad_d >= 0, 'data gradient needs pad <= dil * (R - 1)'
+                native = p.stride != 1 and slot is not None and self.lib.dsnt_conv_dgrad_strided_ok(C.byref(g))
                 if p.stride == 1:
                     gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
+                elif native:
+                    # strided convolution (ResNet stage transitions): dsnt_conv_dgrad_strided computes the pixels of dX
+                    # phase by phase straight from dY (csrc/dgrad_up.hip)
+                    gd = None
                 else:
-                    # strided convolution (ResNet stage transitions): its data gradient is the stride-1 data
-                    # gradient of dY with stride-1 zeros stuffed between the pixels
+                    # ... or, for the shapes that kernel refuses: the stride-1 data gradient of dY with stride-1
+                    # zeros stuffed between the pixels
                     Hs = x.H + 2 * p.pad - p.dil * (p.R - 1)
                     Ws = x.W + 2 * p.pad - p.dil * (p.S - 1)
                     stuffed = self.scratch('stuffed', x.N * Hs * Ws * p.Cout).view(-1)[:x.N * Hs * Ws * p.Cout]
@@ -953,7 +958,7 @@ class Tape:
                 if slot is not None:
                     wd = self.dgrad_f32[slot:slot + nw]
                     wq, wq_stride = self.dgrad_planes[slot:slot + nw], self.dgrad_total
-                    d6 = self._use6(gd)
+                    d6 = gd is not None and self._use6(gd)
                 else:       # stand-alone use without a parameter arena
                     wd = self.scratch('wdgrad', nw)
                     self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
@@ -962,7 +967,7 @@ class Tape:
                         wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
                         self.b('dsnt_split_bf16x3', wd, wq, nw)
 
-                gsrc = gy if p.stride == 1 else gy_d
+                gsrc = gy if (p.stride == 1 or native) else gy_d
 
                 g_amax = y.grad_amax if (self.use_f16x3 and p.stride == 1) else None
                 d16 = d6 and g_amax is not None and slot is not None and self.dgrad_planes16 is not None
@@ -975,7 +980,9 @@ class Tape:
                                              ([p.Cin, p.Cout] if d_stream else [0, 0]))
 
                 def dgrad(out, res, part=None, bnb=None, tail=None):
-                    if d16:
+                    if native:
+                        self.b('dsnt_conv_dgrad_strided', gy, wd, out, res, part, g, bnb, tail)
+                    elif d16:
                         e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
                                    self.dgrad_total, wbd, g_amax, None, out, None,
                                    None, 2 if ((d_stream or p.R == 1) and self.lane != 0 and self.conv_share) else 0, res, None, part, gd, bnb, tail)
@@ -989,17 +996,20 @@ class Tape:
                     # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
                     # data-gradient epilogue; only finalise + apply remain as separate launches
                     dz = self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
-                    bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
-                    tiles = (x.M + bm - 1) // bm
+                    if native:
+                        tiles = self.lib.dsnt_conv_dgrad_strided_tiles(C.byref(g))
+                    else:
+                        bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
+                        tiles = (x.M + bm - 1) // bm
                     part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
                     bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
                                         _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
-                    tl, _ = self.bwd_tail(src, tiles)
+                    tl, _ = (None, None) if native else self.bwd_tail(src, tiles)
                     dgrad(dz, None, part, bnb, tl)
                     self._norm_backward(src, dz, reduced=(part, tiles), finalised=tl is not None)
                 else:
                     # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
-                    buf, acc = self.grad_target(x, amax=bool(d6) and self.raw_f16)
+                    buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16)
                     tl = None
                     if x.grad_amax is not None:
                         tl = BnTail()

@@ -467,6 +467,20 @@ int dsnt_relu_bwd(const float* dy, const float* y, float* dz, int64_t n, void* s
 int dsnt_zero_insert(const float* dy, float* out, int N, int Ho, int Wo, int C, int Hs, int Ws, int stride,
                      void* stream);
 
+/* Data gradient of a STRIDED convolution, native (csrc/dgrad_up.hip): dx [N][H][W][Cin] (+= when res1 == dx) from
+ * dy [N][Ho][Wo][Cout] and wd = dsnt_conv_pack_dgrad(w) ([Cin][R][S][Cout], taps flipped), g = the FORWARD convolution
+ * (2 <= stride <= 4, Cout % 8 == 0: ask dsnt_conv_dgrad_strided_ok).  The pixels of dx are computed phase by phase
+ * ((ih % stride, iw % stride): a 3x3 / 2 convolution has phases of 1, 2, 2 and 4 taps), so neither the zero-stuffed
+ * copy of dy nor the multiplications by its zeros exist: 1 / stride^2 of the work of dsnt_zero_insert + dsnt_conv_fwd,
+ * which it replaces in the engine.  Exact fp32 (v_mfma_f32_32x32x2_f32).  Optional epilogues, as dsnt_conv_fwd_ex:
+ * res1 (may alias dx), or bnb + stats_partial ([dsnt_conv_dgrad_strided_tiles(g)][2][Cin], every row written),
+ * or tail->amax (the other dsnt_bn_tail fields must be unset).  Replaces cuDNN's backward-data of the torchvision ResNet
+ * stride-2 convolutions (conv1, layerN[0].conv1 / .conv2, downsample[0]) consumed by /root/reference/src/dsnt/model.py:103-121. */
+int dsnt_conv_dgrad_strided(const float* dy, const float* wd, float* dx, const float* res1, float* stats_partial,
+                            const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail, void* stream);
+int dsnt_conv_dgrad_strided_ok(const dsnt_conv_geom* g);
+int dsnt_conv_dgrad_strided_tiles(const dsnt_conv_geom* g);
+
 /* out = up + nearest_upsample2x(low) (hourglass.py:58,88-89); low [N][H/2][W/2][C]. */
 int dsnt_upsample2_add_fwd(const float* up, const float* low, float* out,
                            int N, int H, int W, int C, void* stream);

@@ -69,6 +69,98 @@ def test_block_tail_and_zero_insert():
     assert _lib.fn('dsnt_zero_insert')(ptr(dy), ptr(out), N, Ho, Wo, 8, 4, 8, s, None) != 0   # too small
 
 
+STRIDED_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 16, 16, 64, 128, 3, 2, 1, 1),      # layerN[0].conv1 of a BasicBlock / .conv2 of a Bottleneck
+    (2, 16, 16, 64, 128, 1, 2, 0, 1),      # downsample[0]: three of the four phases have no tap
+    (2, 32, 32, 4, 64, 7, 2, 3, 1),        # the stem (image gradient): 16 / 12 / 12 / 9 taps, 4 of 32 columns used
+    (1, 15, 13, 32, 64, 3, 2, 1, 1),       # odd sizes: the phases have different pixel counts
+    (3, 9, 9, 80, 72, 3, 2, 1, 1),         # ragged column tiles (80 = 2.5 x 32), Cout not a multiple of 32
+    (1, 12, 12, 16, 32, 3, 3, 1, 1),       # stride 3
+    (1, 16, 16, 16, 32, 3, 2, 2, 2),       # stride 2 with dilation 2: only the even taps of even pixels ... contribute
+    (1, 17, 16, 8, 16, 5, 4, 2, 1),        # stride 4, 5x5
+    (2, 8, 8, 256, 512, 3, 2, 1, 1),       # layer4 of resnet34 at 256 px: 32 rows per phase, K = 512 ... 2048
+]
+
+
+@pytest.mark.parametrize('case', STRIDED_CASES)
+def test_native_strided_data_gradient(case):
+    """dsnt_conv_dgrad_strided (csrc/dgrad_up.hip) against torch autograd on the CPU (fp32 kernel: 2e-5 of the scale, as
+    the other fp32 convolution tests), its three epilogues, and against the path it replaces (dsnt_zero_insert + the
+    stride-1 kernel) where that one applies."""
+    import ctypes as C
+    from dsnt import _lib
+    from dsnt._lib import ptr, call, ConvGeom, BnBwdEpilogue, BnTail
+    N, H, W, Cin, Cout, k, s, pad, dil = case
+    tag = 'sd' + '_'.join(map(str, case))
+    x = synthetic.tensor(tag + 'x', (N, Cin, H, W), seed=1).requires_grad_()
+    w = synthetic.tensor(tag + 'w', (Cout, Cin, k, k), seed=1, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    y = F.conv2d(x, w, None, stride=s, padding=pad, dilation=dil)
+    Ho, Wo = y.shape[-2:]
+    gy = synthetic.tensor(tag + 'g', tuple(y.shape), seed=2)
+    y.backward(gy)
+    want = _nhwc(x.grad)
+    scale = want.abs().max().item()
+    g = ConvGeom(N, H, W, Cin, Ho, Wo, Cout, k, k, s, pad, dil)
+    assert _lib.fn('dsnt_conv_dgrad_strided_ok')(C.byref(g)) == 1
+    gyd = _nhwc(gy).to(DEV)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wdg = torch.empty(Cin, k, k, Cout, device=DEV)
+    call('dsnt_conv_pack_dgrad', ptr(wd), ptr(wdg), Cout, k, k, Cin)
+    dx = torch.full((N, H, W, Cin), 7.0, device=DEV)
+    amax = torch.zeros(64, device=DEV)
+    tl = BnTail()
+    tl.amax = amax.data_ptr()
+    call('dsnt_conv_dgrad_strided', ptr(gyd), ptr(wdg), ptr(dx), None, None, C.byref(g), None, C.byref(tl))
+    assert (dx.cpu() - want).abs().max().item() <= 2e-5 * scale
+    assert float(amax.max()) == float(dx.abs().max())                    # the bound of what was written
+    first = dx.clone()
+    call('dsnt_conv_dgrad_strided', ptr(gyd), ptr(wdg), ptr(dx), None, None, C.byref(g), None, None)
+    assert torch.equal(dx, first)                                        # deterministic
+    # accumulate in place
+    call('dsnt_conv_dgrad_strided', ptr(gyd), ptr(wdg), ptr(dx), ptr(dx), None, C.byref(g), None, None)
+    assert (dx.cpu() - 2 * want).abs().max().item() <= 4e-5 * scale
+    # the path it replaces: zeros stuffed between the pixels of dY, stride-1 kernel on that
+    pad_d = dil * (k - 1) - pad
+    if pad_d >= 0 and Cout % 4 == 0:
+        Hs, Ws = H + 2 * pad - dil * (k - 1), W + 2 * pad - dil * (k - 1)
+        stuffed = torch.empty(N, Hs, Ws, Cout, device=DEV)
+        call('dsnt_zero_insert', ptr(gyd), ptr(stuffed), N, Ho, Wo, Cout, Hs, Ws, s)
+        gd = ConvGeom(N, Hs, Ws, Cout, H, W, Cin, k, k, 1, pad_d, dil)
+        old = torch.empty(N, H, W, Cin, device=DEV)
+        call('dsnt_conv_fwd', ptr(stuffed), ptr(wdg), None, ptr(old), None, None, 0, None, None, None, C.byref(gd))
+        assert (old - first).abs().max().item() <= 2e-5 * scale
+    # BatchNorm-backward epilogue: dz = dx * [scale x + shift > 0], per-tile (sum dz, sum dz xhat)
+    xin = synthetic.tensor(tag + 'bx', (N, H, W, Cin), seed=3)
+    sc = synthetic.tensor(tag + 'bs', (Cin,), seed=3, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'bh', (Cin,), seed=3, scale=0.3)
+    mu = synthetic.tensor(tag + 'bm', (Cin,), seed=3, scale=0.2)
+    inv = synthetic.tensor(tag + 'bi', (Cin,), seed=3, kind='uniform').abs() + 0.5
+    tiles = _lib.fn('dsnt_conv_dgrad_strided_tiles')(C.byref(g))
+    assert tiles == s * s * ((N * (-(-H // s)) * (-(-W // s)) + 31) // 32)
+    xin_d, sc_d, sh_d, mu_d, inv_d = (t.to(DEV) for t in (xin, sc, sh, mu, inv))
+    for relu in (1, 0):
+        part = torch.full((tiles, 2, Cin), 5.0, device=DEV)
+        dz = torch.empty(N, H, W, Cin, device=DEV)
+        bnb = BnBwdEpilogue(ptr(xin_d), ptr(sc_d), ptr(sh_d), ptr(mu_d), ptr(inv_d), relu)
+        call('dsnt_conv_dgrad_strided', ptr(gyd), ptr(wdg), ptr(dz), None, ptr(part), C.byref(g), C.byref(bnb), None)
+        mask = (torch.addcmul(sh, xin, sc) > 0) if relu else torch.ones_like(xin, dtype=torch.bool)
+        assert torch.equal(dz.cpu(), torch.where(mask, first.cpu(), torch.zeros(())))
+        dzd = dz.cpu().double().reshape(-1, Cin)
+        xh = ((xin - mu) * inv).double().reshape(-1, Cin)
+        got = part.cpu().double().sum(0)
+        assert (got[0] - dzd.sum(0)).abs().max().item() <= 1e-5 * max(1.0, dzd.abs().sum(0).max().item())
+        assert (got[1] - (dzd * xh).sum(0)).abs().max().item() <= 1e-5 * max(1.0, (dzd * xh).abs().sum(0).max().item())
+    # refusals
+    f = _lib.fn('dsnt_conv_dgrad_strided')
+    g1 = ConvGeom(N, H, W, Cin, H + 2 * pad - dil * (k - 1), W + 2 * pad - dil * (k - 1), Cout, k, k, 1, pad, dil)
+    assert _lib.fn('dsnt_conv_dgrad_strided_ok')(C.byref(g1)) == 0                      # stride 1: the forward kernels
+    assert f(ptr(gyd), ptr(wdg), ptr(dx), None, None, C.byref(g1), None, None, None) != 0
+    assert f(ptr(gyd), ptr(wdg), ptr(dx), None, ptr(part), C.byref(g), None, None, None) != 0   # statistics without bnb
+    assert f(ptr(gyd), ptr(wdg), ptr(dx), ptr(dx), ptr(part), C.byref(g), C.byref(bnb), None, None) != 0
+    torch.cuda.synchronize()
+
+
 class _SmoothResNet:
     """Both implementations without ReLU (see tests/test_model_gpu.py::_NoRelu for why)."""
 

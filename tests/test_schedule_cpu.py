@@ -131,13 +131,15 @@ def test_eval_mode_schedule_of_hg2(monkeypatch_module):
 def test_resnet34_train_schedule(monkeypatch_module):
     """BASELINE config 1's model (ResNet-34 + DSNT, batch 8, 8x8 heat-maps): one lane chain (no skip branches to fork),
     post-activation blocks as conv -> [BN+ReLU in the next conv's load] -> conv -> one bn_add_act launch, strided
-    convolutions' data gradients through zero-stuffing, weight gradients reduced once per bucket."""
+    convolutions' data gradients on the native phase kernel (no zero-stuffed copies), weight gradients reduced once per
+    bucket."""
     tape = _trace(monkeypatch_module, 'resnet34', True, (8, 3, 256, 256))
     fwd, bwd = _launches(tape.fwd), _launches(tape.bwd)
     fn, bn = [n for n, _, _ in fwd], [n for n, _, _ in bwd]
     assert fn.count('dsnt_bn_add_act_fwd') == 16                     # 3 + 4 + 6 + 3 BasicBlocks
     assert fn.count('dsnt_maxpool3s2_fwd') == 1 and bn.count('dsnt_maxpool3s2_bwd') == 1
-    assert bn.count('dsnt_zero_insert') == 6                         # three stage transitions x (conv1 + downsample)
+    assert bn.count('dsnt_conv_dgrad_strided') == 6                  # three stage transitions x (conv1 + downsample)
+    assert bn.count('dsnt_zero_insert') == 0
     assert bn.count('dsnt_wgrad_reduce_all') >= 1 and bn.count('dsnt_wgrad_reduce_all') <= 6
     assert not any(n.startswith('dsnt_axpy') for n in fn)
     assert len(fwd) <= 180 and len(bwd) <= 330, (len(fwd), len(bwd))
