@@ -11,7 +11,7 @@ initialisation is torchvision 0.2's (He-normal fan-out convolutions, unit BN).
 
 As in `dsnt.hourglass` the `torch.nn` sub-modules are parameter holders; `trace()` emits the HIP
 launches: conv -> [BN+ReLU folded into the next conv's operand load] -> conv -> BN + identity + ReLU
-(one elementwise kernel), strided convolutions' data gradients via zero-stuffing, 3x3/2 max-pool.
+(one elementwise kernel), strided convolutions' data gradients on the phase kernel (dsnt_conv_dgrad_strided), 3x3/2 max-pool.
 """
 import math
 
