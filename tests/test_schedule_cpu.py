@@ -12,10 +12,11 @@ import torch
 def tape(monkeypatch_module):
     from dsnt import _lib
     import dsnt.engine as E
-    monkeypatch_module.setattr(_lib, 'ptr', lambda t: C.c_void_p(t.data_ptr()) if t is not None else None)
-    monkeypatch_module.setattr(E._lib, 'ptr', _lib.ptr)
+    # (every module that binds `ptr` by name is imported BEFORE the patch, or it would keep the permissive one for good)
     from dsnt.model import build_mpii_pose_model
     from dsnt.hourglass import Arena, Program
+    monkeypatch_module.setattr(_lib, 'ptr', lambda t: C.c_void_p(t.data_ptr()) if t is not None else None)
+    monkeypatch_module.setattr(E._lib, 'ptr', _lib.ptr)
     m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
     m.train()
     ar = Arena(m.hg, torch.device('cpu'))
@@ -102,10 +103,11 @@ def test_launch_counts_stay_bounded(tape):
 def _trace(monkeypatch_module, base, training, shape, **kw):
     from dsnt import _lib
     import dsnt.engine as E
-    monkeypatch_module.setattr(_lib, 'ptr', lambda t: C.c_void_p(t.data_ptr()) if t is not None else None)
-    monkeypatch_module.setattr(E._lib, 'ptr', _lib.ptr)
+    # (every module that binds `ptr` by name is imported BEFORE the patch, or it would keep the permissive one for good)
     from dsnt.model import build_mpii_pose_model
     from dsnt.hourglass import Arena, Program
+    monkeypatch_module.setattr(_lib, 'ptr', lambda t: C.c_void_p(t.data_ptr()) if t is not None else None)
+    monkeypatch_module.setattr(E._lib, 'ptr', _lib.ptr)
     m = build_mpii_pose_model(base=base, output_strat='dsnt', **kw)
     m.train(training)
     root = m.hg if hasattr(m, 'hg') else m._runner().root
