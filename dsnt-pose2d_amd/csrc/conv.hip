@@ -925,9 +925,20 @@ static int check_geom(const dsnt_conv_geom* g, const char* who) {
 // LDS staging, no barrier in the loop), the eight partial tiles are summed through LDS in wave order
 // (deterministic) and the usual epilogue (bias, residuals, statistics, BN-backward masking) runs on the sum.
 // Same contract and statistics layout (32-row tiles) as conv_fwd_kernel<1, 4, 1, 1>.
-template <bool PRO>
+// CW = k values per chunk and row (8, 16 or 32).  A lane (i, h) owns row i and CW / 2 consecutive k values of a chunk:
+// CW / 8 16-byte loads per operand, issued back to back.  With CW = 8 the two lanes of a row use 32 bytes of a
+// 128-byte line per load instruction, the next 32 bytes a whole MFMA batch (and 15 other waves' loads) later: the L1
+// (32 KB against 16 waves x 64 lines in flight) has dropped the line by then, every chunk re-fetches it from L2, and the
+// loads cost L1 fills at 4x the operand bytes on top of 32 tag look-ups per instruction (a lane is a row: the MFMA operand
+// layout), which together take about as long as the MFMAs (3x3 256->256 at M = 2048: 49 us for 18 us of matrix pipe;
+// deeper prefetch makes it worse: 57 / 70 us with 4 / 6 chunks in flight).  Measured, CW = 8 / 16 / 32: that launch 49 /
+// 45 / 49 us, 3x3 512->512 at M = 512 51 / 43 / 41 us, the hourglass's 128-channel forms 18 / 16.5 / 18.8 us (CW = 32
+// holds 96 load registers: occupancy 3-4 waves per SIMD); resnet34 batch 8 5.18 / 5.02 / 5.05 ms per step, hg2 batch 32
+// 13.58 / 13.57 / 13.74 ms.  CW = 16 ships.  Needs Cin % CW == 0 (a chunk never straddles a filter tap); else CW = 8.
+template <bool PRO, int CW>
 __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NL = CW / 8;                      // 16-byte loads per operand, lane and chunk
     __shared__ __attribute__((aligned(16))) float part[8][32][33];
     const int nt32 = (p.Cout + 31) >> 5;
     const int ntile = blockIdx.x % nt32, mtile = blockIdx.x / nt32;
@@ -939,6 +950,13 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
         bn_pro_forward<512>(p.pro, reinterpret_cast<double*>(&part[0][0][0]), blockIdx.x == 0);
         __syncthreads();                 // this workgroup's stores to in_scale / in_shift are visible to its loads
     }
+    // the BatchNorm vectors of the A operand live in LDS during the loop (in `part`, which is only written after it; Cin <=
+    // 4096): as global loads inside the loop they would queue behind the prefetched chunks (loads return in order)
+    float* const ssc = &part[0][0][0];
+    if (PRO) {
+        for (int c = tid; c < p.Cin; c += 512) { ssc[c] = p.in_scale[c]; ssc[p.Cin + c] = p.in_shift[c]; }
+        __syncthreads();
+    }
     // A row of this lane
     const int m = mtile * 32 + i;
     const bool vm = m < p.M;
@@ -949,47 +967,53 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
     const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
     // weight row of this lane
     const int nb = ntile * 32 + i;
-    const unsigned boff = nb < p.Cout ? (unsigned)((size_t)nb * p.K + 4 * h) * 4u : OOB;
+    const int kl = (CW / 2) * h;                    // this lane's k offset inside a chunk
+    const unsigned boff = nb < p.Cout ? (unsigned)((size_t)nb * p.K + kl) * 4u : OOB;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x), 0, (int)((size_t)p.N * p.H * p.W * p.Cin * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w), 0, (int)((size_t)p.Cout * p.K * 4u), 0x00020000);
-    const int nch = p.K >> 3;                       // 8-wide k chunks; a chunk never straddles a filter tap
+    const int nch = p.K / CW;                       // a chunk never straddles a filter tap
     const int c0 = wave * nch / 8, c1 = (wave + 1) * nch / 8;
     const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
-    struct Frag { u32x4 a, b; float4 sc, sh; bool ok; };
+    struct Frag { u32x4 a[NL], b[NL]; bool ok; int cb; };
     auto load = [&](int ch) {
         Frag f;
-        const int kb = ch << 3;
+        const int kb = ch * CW;
         const int tap = kb / p.Cin, cb = kb - tap * p.Cin;
         const int r = tap / p.S, s_ = tap - r * p.S;
         const int ih = ih0 + r * p.dil, iw = iw0 + s_ * p.dil;
         f.ok = vm && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-        const unsigned aoff = (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + cb + 4 * h) * 4u;
-        f.a = __builtin_amdgcn_raw_buffer_load_b128(xr, f.ok ? aoff : OOB, 0, 0);
-        f.b = __builtin_amdgcn_raw_buffer_load_b128(wr, boff, kb * 4, 0);
-        if (PRO) {
-            f.sc = *reinterpret_cast<const float4*>(p.in_scale + cb + 4 * h);
-            f.sh = *reinterpret_cast<const float4*>(p.in_shift + cb + 4 * h);
-        }
+        f.cb = cb;
+        const unsigned aoff = f.ok ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + cb + kl) * 4u : OOB;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) f.a[q] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff + 16u * q, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) f.b[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, boff + 16u * q, kb * 4, 0);
         return f;
     };
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     auto mma = [&](const Frag& f) {
-        float4 a = make_float4(__uint_as_float(f.a.x), __uint_as_float(f.a.y), __uint_as_float(f.a.z), __uint_as_float(f.a.w));
-        if (PRO) {
-            const float lo = f.ok ? lo_valid : 0.f, hi = f.ok ? __builtin_inff() : 0.f;
-            a.x = __builtin_amdgcn_fmed3f(fmaf(a.x, f.sc.x, f.sh.x), lo, hi);
-            a.y = __builtin_amdgcn_fmed3f(fmaf(a.y, f.sc.y, f.sh.y), lo, hi);
-            a.z = __builtin_amdgcn_fmed3f(fmaf(a.z, f.sc.z, f.sh.z), lo, hi);
-            a.w = __builtin_amdgcn_fmed3f(fmaf(a.w, f.sc.w, f.sh.w), lo, hi);
+        const float lo = f.ok ? lo_valid : 0.f, hi = f.ok ? __builtin_inff() : 0.f;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            float4 a = make_float4(__uint_as_float(f.a[q].x), __uint_as_float(f.a[q].y), __uint_as_float(f.a[q].z),
+                                   __uint_as_float(f.a[q].w));
+            if (PRO) {
+                const float4 sc = *reinterpret_cast<const float4*>(ssc + f.cb + kl + 4 * q);
+                const float4 sh = *reinterpret_cast<const float4*>(ssc + p.Cin + f.cb + kl + 4 * q);
+                a.x = __builtin_amdgcn_fmed3f(fmaf(a.x, sc.x, sh.x), lo, hi);
+                a.y = __builtin_amdgcn_fmed3f(fmaf(a.y, sc.y, sh.y), lo, hi);
+                a.z = __builtin_amdgcn_fmed3f(fmaf(a.z, sc.z, sh.z), lo, hi);
+                a.w = __builtin_amdgcn_fmed3f(fmaf(a.w, sc.w, sh.w), lo, hi);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, __uint_as_float(f.b[q].x), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, __uint_as_float(f.b[q].y), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, __uint_as_float(f.b[q].z), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, __uint_as_float(f.b[q].w), acc, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, __uint_as_float(f.b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, __uint_as_float(f.b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, __uint_as_float(f.b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, __uint_as_float(f.b.w), acc, 0, 0, 0);
     };
     if (c0 < c1) {
         // two chunks in flight; the tail re-loads the last chunk (never used) to stay straight-line
@@ -1000,6 +1024,7 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
             f0 = f1; f1 = f2;
         }
     }
+    if (PRO) __syncthreads();                       // every wave is done with the vectors in `part`
     // partial tiles -> LDS (C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5))
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[wave][(e & 3) + 8 * (e >> 2) + 4 * h][i] = acc[e];
@@ -1118,10 +1143,18 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
     const bool pro = in_scale != nullptr;
     DSNT_REQUIRE(!((p.tail.amax || p.tail.amax_bn) && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
     if (BM == 32 && p.M <= ksplit_rows() && p.Cin % 8 == 0 && (size_t)p.N * p.H * p.W * p.Cin * 4u < (1ull << 31) &&
-        (size_t)p.Cout * p.K * 4u < (1ull << 31) && !p.tail.amax && !p.tail.amax_bn) {       // (the K-split epilogue has no amax)
+        (size_t)p.Cout * p.K * 4u < (1ull << 31) && !p.tail.amax && !p.tail.amax_bn &&        // (the K-split epilogue has no amax)
+        (!pro || p.Cin <= 4096)) {
         const int grid = p.mtiles * ((p.Cout + 31) / 32);
-        if (pro) DSNT_LAUNCH(conv_ksplit_kernel<true>, dim3(grid), dim3(512), 0, st, p);
-        else DSNT_LAUNCH(conv_ksplit_kernel<false>, dim3(grid), dim3(512), 0, st, p);
+        // (KS_CW: experiments only)
+#ifndef KS_CW
+#define KS_CW 16
+#endif
+        if (p.Cin % KS_CW == 0) {
+            if (pro) DSNT_LAUNCH((conv_ksplit_kernel<true, KS_CW>), dim3(grid), dim3(512), 0, st, p);
+            else DSNT_LAUNCH((conv_ksplit_kernel<false, KS_CW>), dim3(grid), dim3(512), 0, st, p);
+        } else if (pro) DSNT_LAUNCH((conv_ksplit_kernel<true, 8>), dim3(grid), dim3(512), 0, st, p);
+        else DSNT_LAUNCH((conv_ksplit_kernel<false, 8>), dim3(grid), dim3(512), 0, st, p);
     } else if (BM == 128 && BN == 128) launch_fwd<2, 2, 2, 2>(p, pro, st);
     else if (BM == 128 && BN == 64) launch_fwd<2, 2, 2, 1>(p, pro, st);
     else if (BM == 128 && BN == 32) launch_fwd<4, 1, 1, 1>(p, pro, st);
