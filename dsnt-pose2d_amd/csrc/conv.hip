@@ -977,19 +977,30 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
     const int c0 = wave * nch / 8, c1 = (wave + 1) * nch / 8;
     const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
     struct Frag { u32x4 a[NL], b[NL]; bool ok; int cb; };
-    auto load = [&](int ch) {
+    // position of the next chunk to load (scalars; stepped, not divided: the loop's issue slots belong to the MFMAs —
+    // fp32 MFMAs and VALU instructions exclude each other on a SIMD, profiles/r03_pmc_ksplit.txt); it stops at the
+    // wave's last chunk, which the tail of the loop re-loads (never used) to stay straight-line
+    int pos = c0, pr, ps, pcb;
+    {
+        const int kb = c0 * CW, tap = kb / p.Cin;
+        pcb = kb - tap * p.Cin; pr = tap / p.S; ps = tap - pr * p.S;
+    }
+    auto load_next = [&]() {
         Frag f;
-        const int kb = ch * CW;
-        const int tap = kb / p.Cin, cb = kb - tap * p.Cin;
-        const int r = tap / p.S, s_ = tap - r * p.S;
-        const int ih = ih0 + r * p.dil, iw = iw0 + s_ * p.dil;
-        f.ok = vm && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-        f.cb = cb;
-        const unsigned aoff = f.ok ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + cb + kl) * 4u : OOB;
+        const int ih = ih0 + pr * p.dil, iw = iw0 + ps * p.dil;
+        f.ok = vm && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        f.cb = pcb;
+        const unsigned aoff = f.ok ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + pcb + kl) * 4u : OOB;
+        const int kb4 = ((pr * p.S + ps) * p.Cin + pcb) * 4;
 #pragma unroll
         for (int q = 0; q < NL; ++q) f.a[q] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff + 16u * q, 0, 0);
 #pragma unroll
-        for (int q = 0; q < NL; ++q) f.b[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, boff + 16u * q, kb * 4, 0);
+        for (int q = 0; q < NL; ++q) f.b[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, boff + 16u * q, kb4, 0);
+        if (pos < c1 - 1) {
+            ++pos;
+            pcb += CW;
+            if (pcb == p.Cin) { pcb = 0; if (++ps == p.S) { ps = 0; ++pr; } }
+        }
         return f;
     };
     f32x16 acc;
@@ -1016,12 +1027,12 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
         }
     };
     if (c0 < c1) {
-        // two chunks in flight; the tail re-loads the last chunk (never used) to stay straight-line
-        Frag f0 = load(c0), f1 = load(min(c0 + 1, c1 - 1));
-        for (int ch = c0; ch < c1; ++ch) {
-            const Frag f2 = load(min(ch + 2, c1 - 1));
-            mma(f0);
-            f0 = f1; f1 = f2;
+        // two chunks in flight beside the one being multiplied; three register sets in rotation (no copies)
+        Frag f0 = load_next(), f1 = load_next(), f2;
+        for (int ch = c0;;) {
+            f2 = load_next(); mma(f0); if (++ch >= c1) break;
+            f0 = load_next(); mma(f1); if (++ch >= c1) break;
+            f1 = load_next(); mma(f2); if (++ch >= c1) break;
         }
     }
     if (PRO) __syncthreads();                       // every wave is done with the vectors in `part`
