@@ -14,7 +14,7 @@ x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, devi
 b = torch.zeros(Cout, device=dev); sc = torch.rand(Cin, device=dev) + 0.5; sh = torch.randn(Cin, device=dev) * 0.1
 y = torch.empty(B, H, H, Cout, device=dev); gy = torch.randn(B, H, H, Cout, device=dev)
 M = B * H * H
-stats = torch.empty((M + 127) // 128, 2, Cout, device=dev)
+stats = torch.empty((M + 63) // 64, 2, Cout, device=dev)     # (room for 64-row tiles: kernel experiments)
 st = torch.cuda.current_stream().cuda_stream
 ws = torch.empty(max(_lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)), _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 0)), device=dev); dw = torch.empty_like(w); db = torch.empty(Cout, device=dev)
 planes = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=dev)
