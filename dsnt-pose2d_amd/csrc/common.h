@@ -110,7 +110,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 #endif
 
-// DSNT_OFF=<name>[,<name>...] (',' or '+' between names): kernels of round 3 to leave out (conv3s, gemm1, wgrad3, wgrad1) — the launch then takes the
+// DSNT_OFF=<name>[,<name>...] (',' or '+' between names): kernels of round 3 to leave out (conv3s, gemm1, wgrad3, wgrad1, dgrad_up) — the launch then takes the
 // round-2 kernel of the same contract.  Host side; read at the first launch that asks.
 #include <stdlib.h>
 #include <string.h>

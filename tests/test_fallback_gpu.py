@@ -17,29 +17,32 @@ import os, sys, torch
 sys.path[:0] = [os.path.join(%(root)r, 'dsnt-pose2d_amd')]
 from dsnt.model import build_mpii_pose_model
 from dsnt import synthetic
-m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+m = build_mpii_pose_model(base=%(base)r, output_strat='dsnt', reg='js')
 synthetic.fill_state_dict(m, seed=0)
 m.cuda().train()
-x, t, k = synthetic.batch(16, size=256, seed=1, mask_p=0.9)
+x, t, k = synthetic.batch(%(batch)d, size=%(size)d, seed=1, mask_p=0.9)
 out = m(x.cuda())
 loss = m.forward_loss(out, t.cuda(), k.cuda())
 loss.backward()
-prog = [p for p in m.hg._runner().programs.values() if p.training][0]
+prog = [p for p in (m.hg if hasattr(m, 'hg') else m)._runner().programs.values() if p.training][0]
 names = [e[2] for e in prog.tape.fwd + prog.tape.bwd if e[0] is not None]
-torch.save({'loss': loss.item(), 'coords': out[-1].detach().cpu(),
+torch.save({'loss': loss.item(), 'coords': (out[-1] if isinstance(out, (list, tuple)) else out).detach().cpu(),
             'grads': {n: p.grad.detach().cpu() for n, p in m.named_parameters()},
             'running': {n: b.detach().cpu() for n, b in m.named_buffers() if 'running' in n},
-            'stream_launches': names.count('dsnt_conv_fwd_f16x3_stream')}, sys.argv[1])
+            'stream_launches': names.count('dsnt_conv_fwd_f16x3_stream'),
+            'strided_launches': names.count('dsnt_conv_dgrad_strided'), 'stuffed_launches': names.count('dsnt_zero_insert')},
+           sys.argv[1])
 '''
 
 
-def _run(tmp_path, tag, off):
+def _run(tmp_path, tag, off, base='hg2', batch=16, size=256):
     env = dict(os.environ)
     env.pop('DSNT_OFF', None)
     if off:
         env['DSNT_OFF'] = off
     path = str(tmp_path / (tag + '.pt'))
-    subprocess.run([sys.executable, '-c', SCRIPT % {'root': ROOT}, path], check=True, env=env, timeout=600)
+    subprocess.run([sys.executable, '-c', SCRIPT % {'root': ROOT, 'base': base, 'batch': batch, 'size': size}, path],
+                   check=True, env=env, timeout=600)
     return torch.load(path)
 
 
@@ -59,3 +62,18 @@ def test_round3_kernels_agree_with_the_kernels_they_replace(tmp_path):
     assert (fn @ fo / (fn.norm() * fo.norm())).item() >= 0.9999
     for n, v in old['running'].items():
         assert (new['running'][n] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), n
+
+
+def test_native_strided_data_gradient_agrees_with_zero_stuffing(tmp_path):
+    """resnet18 + DSNT + JS, one train step: the stage transitions' data gradients on dsnt_conv_dgrad_strided (default) and, with
+    DSNT_OFF=dgrad_up, on dsnt_zero_insert + the stride-1 kernels.  Only backward launches differ (no ReLU mask can flip), and
+    the new kernel is exact fp32: tight bars."""
+    new = _run(tmp_path, 'rn_new', None, 'resnet18', 8, 128)
+    old = _run(tmp_path, 'rn_old', 'dgrad_up', 'resnet18', 8, 128)
+    assert new['strided_launches'] == 6 and new['stuffed_launches'] == 0
+    assert old['strided_launches'] == 0 and old['stuffed_launches'] == 6
+    assert new['loss'] == old['loss'] and torch.equal(new['coords'], old['coords'])          # the forward is the same program
+    floor = 1e-3 * max(v.double().norm().item() for v in old['grads'].values())
+    worst = max(((new['grads'][n].double() - v.double()).norm().item() / max(v.double().norm().item(), floor), n)
+                for n, v in old['grads'].items())
+    assert worst[0] <= 1e-4, worst
