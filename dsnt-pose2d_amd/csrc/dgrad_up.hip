@@ -12,7 +12,7 @@
 //
 // Kernel: the K-split form of conv.hip (conv_ksplit_kernel) — these launches have few rows and long reductions.  A
 // 512-thread workgroup owns one 32 x 32 tile (32 pixels of ONE phase x 32 channels of dX); its eight waves split the
-// phase's reduction (taps x Cout, 8 channels at a time), every lane streaming its operands straight from memory into
+// phase's reduction (taps x Cout, 16 channels at a time), every lane streaming its operands straight from memory into
 // v_mfma_f32_32x32x2_f32 (exact fp32: the results match the stuffed path to accumulation order), the eight partial
 // tiles are summed through LDS in wave order (deterministic), and the epilogue offers what the engine's data-gradient
 // launches use: accumulate into dX (res1), the BatchNorm-backward mask + per-tile sums (Bottleneck: the strided 3x3
@@ -64,43 +64,62 @@ __global__ __launch_bounds__(512) void conv_dgrad_up_kernel(UpP p) {
     const int a = Wp ? rem / Wp : 0, b = rem - a * Wp;
     // weight row of this lane
     const int nb = ntile * 32 + i;
-    const unsigned boff = nb < p.Cx ? (unsigned)((size_t)nb * p.K + 4 * h) * 4u : OOB;
+    // a lane owns row i and CW / 2 = 8 consecutive k values of a 16-wide chunk: two adjacent 16-byte loads per operand, so
+    // that a row's two lanes use 64 bytes of a line at once (conv_ksplit_kernel in conv.hip has the measurements)
+    constexpr int CW = 16, NL = CW / 8;
+    const int kl = (CW / 2) * h;
+    const unsigned boff = nb < p.Cx ? (unsigned)((size_t)nb * p.K + kl) * 4u : OOB;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.dy), 0, (int)((size_t)p.N * p.Hy * p.Wy * p.Cy * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.wd), 0, (int)((size_t)p.Cx * p.K * 4u), 0x00020000);
-    const int cpt = p.Cy >> 3;                      // 8-wide k chunks per tap
+    const int cpt = p.Cy / CW;                      // chunks per tap
     const int nch = cy * cx * cpt;
     const int c0 = wave * nch / 8, c1 = (wave + 1) * nch / 8;
-    struct Frag { u32x4 a, b; };
-    auto load = [&](int ch) {
+    struct Frag { u32x4 a[NL], b[NL]; };
+    // position of the next chunk to load: (tap row, tap column, channel base), stepped; it stops at the wave's last chunk,
+    // which the tail of the loop re-loads (never used) to stay straight-line
+    int pos = c0, piy, pix, pcb;
+    {
+        const int tap = c0 / cpt;
+        pcb = (c0 - tap * cpt) * CW; piy = cx ? tap / cx : 0; pix = tap - piy * cx;
+    }
+    auto load_next = [&]() {
         Frag f;
-        const int tap = ch / cpt, cb = (ch - tap * cpt) << 3;
-        const int iy = tap / cx, ix = tap - iy * cx;
-        const int ih = a + dy0 + iy * p.dstep[0], iw = b + dx0 + ix * p.dstep[1];
-        const bool ok = vm && ih >= 0 && ih < p.Hy && iw >= 0 && iw < p.Wy;
-        const unsigned aoff = (unsigned)(((img * p.Hy + ih) * p.Wy + iw) * p.Cy + cb + 4 * h) * 4u;
-        const int kb = ((ry0 + iy * p.per[0]) * p.S + rx0 + ix * p.per[1]) * p.Cy + cb;
-        f.a = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? aoff : OOB, 0, 0);
-        f.b = __builtin_amdgcn_raw_buffer_load_b128(wr, boff, kb * 4, 0);
+        const int ih = a + dy0 + piy * p.dstep[0], iw = b + dx0 + pix * p.dstep[1];
+        const bool ok = vm && (unsigned)ih < (unsigned)p.Hy && (unsigned)iw < (unsigned)p.Wy;
+        const unsigned aoff = ok ? (unsigned)(((img * p.Hy + ih) * p.Wy + iw) * p.Cy + pcb + kl) * 4u : OOB;
+        const int kb4 = (((ry0 + piy * p.per[0]) * p.S + rx0 + pix * p.per[1]) * p.Cy + pcb) * 4;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) f.a[q] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoff + 16u * q, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) f.b[q] = __builtin_amdgcn_raw_buffer_load_b128(wr, boff + 16u * q, kb4, 0);
+        if (pos < c1 - 1) {
+            ++pos;
+            pcb += CW;
+            if (pcb == p.Cy) { pcb = 0; if (++pix == cx) { pix = 0; ++piy; } }
+        }
         return f;
     };
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     auto mma = [&](const Frag& f) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(f.a.x), __uint_as_float(f.b.x), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(f.a.y), __uint_as_float(f.b.y), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(f.a.z), __uint_as_float(f.b.z), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(f.a.w), __uint_as_float(f.b.w), acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(f.a[q].x), __uint_as_float(f.b[q].x), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(f.a[q].y), __uint_as_float(f.b[q].y), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(f.a[q].z), __uint_as_float(f.b[q].z), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(f.a[q].w), __uint_as_float(f.b[q].w), acc, 0, 0, 0);
+        }
     };
     if (c0 < c1) {
-        // three chunks in flight; the tail re-loads the last chunk (never used) to stay straight-line
-        Frag f0 = load(c0), f1 = load(min(c0 + 1, c1 - 1)), f2 = load(min(c0 + 2, c1 - 1));
-        for (int ch = c0; ch < c1; ++ch) {
-            const Frag f3 = load(min(ch + 3, c1 - 1));
-            mma(f0);
-            f0 = f1; f1 = f2; f2 = f3;
+        // two chunks in flight beside the one being multiplied; three register sets in rotation (no copies)
+        Frag f0 = load_next(), f1 = load_next(), f2;
+        for (int ch = c0;;) {
+            f2 = load_next(); mma(f0); if (++ch >= c1) break;
+            f0 = load_next(); mma(f1); if (++ch >= c1) break;
+            f1 = load_next(); mma(f2); if (++ch >= c1) break;
         }
     }
     // partial tiles -> LDS (C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5))
@@ -160,7 +179,7 @@ static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; 
 static int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
 static bool up_geom_ok(const dsnt_conv_geom* g) {
-    if (!g || g->stride < 2 || g->stride > UP_MAX_STRIDE || g->Cout % 8 != 0) return false;
+    if (!g || g->stride < 2 || g->stride > UP_MAX_STRIDE || g->Cout % 16 != 0) return false;
     if (g->N <= 0 || g->H <= 0 || g->W <= 0 || g->Cin <= 0 || g->R <= 0 || g->S <= 0 || g->dil <= 0 || g->pad < 0) return false;
     if ((size_t)g->N * g->Ho * g->Wo * g->Cout * 4u >= (1ull << 31) || (size_t)g->N * g->H * g->W * g->Cin * 4u >= (1ull << 31) ||
         (size_t)g->Cin * g->R * g->S * g->Cout * 4u >= (1ull << 31)) return false;
@@ -184,7 +203,7 @@ extern "C" int dsnt_conv_dgrad_strided(const float* dy, const float* wd, float* 
     const int wo = (g->W + 2 * g->pad - g->dil * (g->S - 1) - 1) / g->stride + 1;
     DSNT_REQUIRE(ho == g->Ho && wo == g->Wo, DSNT_ERR_SHAPE, "dsnt_conv_dgrad_strided: output %dx%d inconsistent with "
                  "input/filter (expected %dx%d)", g->Ho, g->Wo, ho, wo);
-    DSNT_REQUIRE(up_geom_ok(g), DSNT_ERR_SHAPE, "dsnt_conv_dgrad_strided: needs 2 <= stride <= %d, Cout %% 8 == 0, "
+    DSNT_REQUIRE(up_geom_ok(g), DSNT_ERR_SHAPE, "dsnt_conv_dgrad_strided: needs 2 <= stride <= %d, Cout %% 16 == 0, "
                  "tensors under 2 GiB (ask dsnt_conv_dgrad_strided_ok)", UP_MAX_STRIDE);
     DSNT_REQUIRE(dsnt_aligned16(dy) && dsnt_aligned16(wd), DSNT_ERR_ALIGN, "dsnt_conv_dgrad_strided: dy / wd must be 16-byte aligned");
     DSNT_REQUIRE(!bnb || (bnb->x && bnb->scale && bnb->shift && bnb->mean && bnb->invstd && stats_partial && !res1), DSNT_ERR_ARG,

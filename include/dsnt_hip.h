@@ -469,7 +469,7 @@ int dsnt_zero_insert(const float* dy, float* out, int N, int Ho, int Wo, int C, 
 
 /* Data gradient of a STRIDED convolution, native (csrc/dgrad_up.hip): dx [N][H][W][Cin] (+= when res1 == dx) from
  * dy [N][Ho][Wo][Cout] and wd = dsnt_conv_pack_dgrad(w) ([Cin][R][S][Cout], taps flipped), g = the FORWARD convolution
- * (2 <= stride <= 4, Cout % 8 == 0: ask dsnt_conv_dgrad_strided_ok).  The pixels of dx are computed phase by phase
+ * (2 <= stride <= 4, Cout % 16 == 0: ask dsnt_conv_dgrad_strided_ok).  The pixels of dx are computed phase by phase
  * ((ih % stride, iw % stride): a 3x3 / 2 convolution has phases of 1, 2, 2 and 4 taps), so neither the zero-stuffed
  * copy of dy nor the multiplications by its zeros exist: 1 / stride^2 of the work of dsnt_zero_insert + dsnt_conv_fwd,
  * which it replaces in the engine.  Exact fp32 (v_mfma_f32_32x32x2_f32).  Optional epilogues, as dsnt_conv_fwd_ex:

@@ -75,7 +75,7 @@ STRIDED_CASES = [
     (2, 16, 16, 64, 128, 1, 2, 0, 1),      # downsample[0]: three of the four phases have no tap
     (2, 32, 32, 4, 64, 7, 2, 3, 1),        # the stem (image gradient): 16 / 12 / 12 / 9 taps, 4 of 32 columns used
     (1, 15, 13, 32, 64, 3, 2, 1, 1),       # odd sizes: the phases have different pixel counts
-    (3, 9, 9, 80, 72, 3, 2, 1, 1),         # ragged column tiles (80 = 2.5 x 32), Cout not a multiple of 32
+    (3, 9, 9, 80, 48, 3, 2, 1, 1),         # ragged column tiles (80 = 2.5 x 32), Cout not a multiple of 32
     (1, 12, 12, 16, 32, 3, 3, 1, 1),       # stride 3
     (1, 16, 16, 16, 32, 3, 2, 2, 2),       # stride 2 with dilation 2: only the even taps of even pixels ... contribute
     (1, 17, 16, 8, 16, 5, 4, 2, 1),        # stride 4, 5x5
