@@ -58,6 +58,15 @@ class BnTail(C.Structure):
 
 TP = C.POINTER(BnTail)
 
+
+class BnBwdApply(C.Structure):
+    """dsnt_bn_bwd_apply: the BatchNorm backward of a convolution's consumer, folded into dsnt_conv1x1_bwd_f16x3."""
+    _fields_ = [('y', C.c_void_p), ('scale', C.c_void_p), ('mean', C.c_void_p), ('invstd', C.c_void_p),
+                ('coef', C.c_void_p)]
+
+
+AP = C.POINTER(BnBwdApply)
+
 # name -> argtypes (the trailing `void* stream` included where the C signature has it)
 SIGNATURES = {
     'dsnt_preact_fwd': [P, P, L, I, I, F, F, P],
@@ -102,6 +111,7 @@ SIGNATURES = {
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_bf16x6': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_f16x3': [P, P, P, I, P, P, P, P, I, P, P, GP, P],
+    'dsnt_conv1x1_bwd_f16x3': [BP, P, AP, P, L, P, P, P, P, P, P, P, GP, P],
     'dsnt_wgrad_reduce_all': [P, I, I, P],
     'dsnt_conv_wgrad_group': [P, I, I, P],
     'dsnt_bn_stats': [P, P, L, I, P],
@@ -178,6 +188,9 @@ PLAIN = {
     'dsnt_conv_wgrad_f16x3_splits': (I, [GP, I]),
     'dsnt_conv_wgrad_f16x3_ws_floats': (L, [GP, I]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
+    'dsnt_conv1x1_bwd_ok': (I, [GP]),
+    'dsnt_conv1x1_bwd_splits': (I, [GP]),
+    'dsnt_conv1x1_bwd_ws_floats': (L, [GP]),
     'dsnt_conv_wgrad_desc_bytes': (I, []),
     'dsnt_conv_wgrad_desc': (I, [P, P, P, I, P, P, GP, P]),
     'dsnt_conv_wgrad_desc_f16x3': (I, [P, P, P, I, P, P, P, P, GP, P]),

@@ -363,6 +363,34 @@ int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g);
 int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g, int accumulate);
 int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate);
 
+/* The WHOLE backward of a 1x1 / stride 1 convolution y = conv(relu?(bn(x))) in one pass over its tensors — what
+ * autograd runs as cuDNN backward-data + backward-filter of /root/reference/src/dsnt/hourglass.py:20,25 (conv1 / conv3 of
+ * every Bottleneck) plus, with `ap`, the BatchNorm backward of the layer behind (hourglass.py:21,36-37):
+ *   dz_out[m][c]  = (sum_n dY[m][n] W[n][c]) * [bn(x) > 0]     (the ReLU mask as dsnt_bn_bwd_epilogue defines it: xs)
+ *   stats_partial = [splits][2][Cin] partial (sum dz_out, sum dz_out * xhat) for dsnt_bn_bwd_finalize (ntiles = splits)
+ *   ws            = [splits][Cout][Cin] slabs of dW[n][c] = sum_m dY[m][n] act(x)[m][c], then [splits][Cout] bias partials
+ *                   (reduce with dsnt_wgrad_reduce_all, `splits` = dsnt_conv1x1_bwd_splits(g))
+ * dY is `dy` itself (ap == NULL) or is formed in registers from dy = dz of the BatchNorm that consumes y:
+ *   dY = ap->scale * (dz - coef[0] - (y - mean) * invstd * coef[1])          (dsnt_bn_act_bwd_apply's arithmetic; that
+ * launch and its 12 bytes per element disappear).  xs->x is read ONCE (mask, xhat and weight-gradient operand from the
+ * same registers), dy (and ap->y) once: 402 MB instead of 737 MB for 256 -> 128 channels at 64 x 64, batch 32.
+ * wd_planes: the data-gradient weights [Cin][Cout] (dsnt_conv_pack_dgrad) as two fp16 planes with bound w_bound
+ * (dsnt_f16_prep_weights); a_bound >= max|act(x)|, g_bound >= max|dY| (64-slot bounds; with `ap`:
+ * dsnt_bn_bwd_finalize_bound leaves it); dz_amax (may be NULL): raised to max|dz_out|.
+ * dsnt_conv1x1_bwd_ok(g) != 0: (Cout, Cin) in {(128, 256), (256, 128), (128, 128)}, N*H*W % 32 == 0 and >= 16384. */
+typedef struct {
+    const float* y;            /* the convolution's own output = the BatchNorm's input, [M][Cout] */
+    const float* scale; const float* mean; const float* invstd;   /* [Cout] */
+    const float* coef;         /* [2][Cout] as dsnt_bn_bwd_finalize leaves it */
+} dsnt_bn_bwd_apply;
+int dsnt_conv1x1_bwd_ok(const dsnt_conv_geom* g);
+int dsnt_conv1x1_bwd_splits(const dsnt_conv_geom* g);
+int64_t dsnt_conv1x1_bwd_ws_floats(const dsnt_conv_geom* g);
+int dsnt_conv1x1_bwd_f16x3(const dsnt_bn_bwd_epilogue* xs, const float* dy, const dsnt_bn_bwd_apply* ap,
+                           const void* wd_planes, int64_t plane_stride, const float* w_bound, const float* a_bound,
+                           const float* g_bound, float* dz_out, float* stats_partial, float* ws, float* dz_amax,
+                           const dsnt_conv_geom* g, void* stream);
+
 /* ----------------------------------------------------- heat-map matching ("gauss" output strategy)
  * Rows = (image, joint) maps of h x w floats, target = normalised coordinates [rows][2].
  * dsnt_encode_heatmaps: /root/reference/src/dsnt/util.py:129-147 (encode_heatmaps) + :70-126 (draw_gaussian with

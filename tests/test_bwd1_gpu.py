@@ -1,0 +1,141 @@
+"""The one-pass backward of a 1x1 convolution (csrc/bwd1.hip, dsnt_conv1x1_bwd_f16x3) against fp64: what autograd runs as
+backward-data + backward-filter of /root/reference/src/dsnt/hourglass.py:20,25 (conv1 / conv3 of a Bottleneck) and, in
+the `apply` mode, the BatchNorm backward of the layer behind (hourglass.py:21,36-37), through the C ABI."""
+import ctypes as C
+
+import pytest
+import torch
+
+from dsnt import synthetic
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, H, W, Cin, Cout
+    (4, 64, 64, 256, 128),     # conv1 of a Bottleneck (n = 128, two 16-column tiles per wave)
+    (4, 64, 64, 128, 256),     # conv3 (n = 256, one tile per wave)
+    (4, 64, 64, 128, 128),     # conv1 of a 128-wide Bottleneck
+    (5, 64, 64, 256, 128),     # 640 stages over 214 workgroups: the last one is short
+    (16, 32, 32, 128, 256),
+]
+
+
+def _bound(value, dev):
+    return torch.full((64,), float(value), device=dev)
+
+
+def _reference(x, sc, sh, mu, istd, relu, dy, w):
+    """fp64: dz_out, the two BatchNorm-backward sums, dW, db for y = conv1x1(relu?(x * sc + sh)) given dL/dy."""
+    z = x * sc + sh
+    act = torch.relu(z) if relu else z
+    dx = dy @ w                                   # [M, Cin]
+    if relu:
+        dx = dx * (z > 0)
+    xhat = (x - mu) * istd
+    return dx, dx.sum(0), (dx * xhat).sum(0), dy.t() @ act, dy.sum(0), z
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('mode,relu', [('apply', 1), ('given', 1), ('apply', 0)])
+def test_conv1x1_backward_in_one_pass(case, mode, relu):
+    from dsnt import _lib
+    from dsnt._lib import ptr, call, ConvGeom, BnBwdEpilogue, BnBwdApply
+    N, H, W, Cin, Cout = case
+    dev = torch.device('cuda:0')
+    tag = 'b1' + '_'.join(map(str, case)) + mode
+    M = N * H * W
+    g = ConvGeom(N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1)
+    assert _lib.fn('dsnt_conv1x1_bwd_ok')(C.byref(g))
+    x = synthetic.tensor(tag + 'x', (M, Cin), seed=1)
+    gamma = synthetic.tensor(tag + 'ga', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    beta = synthetic.tensor(tag + 'be', (Cin,), seed=1, scale=0.3)
+    mu = x.double().mean(0).float()
+    istd = (1.0 / (x.double().var(0, unbiased=False) + 1e-5).sqrt()).float()
+    sc = gamma * istd
+    sh = beta - mu * sc
+    w = synthetic.tensor(tag + 'w', (Cout, Cin), seed=2) * 0.05
+    if mode == 'apply':
+        # dY = y_scale (dz - c0 - (y - y_mean) y_invstd c1): the BatchNorm backward of the layer behind, folded in
+        y = synthetic.tensor(tag + 'y', (M, Cout), seed=3)
+        dz = synthetic.tensor(tag + 'dz', (M, Cout), seed=4) * 1e-3
+        dz = dz * (synthetic.tensor(tag + 'mk', (M, Cout), seed=5) > 0)          # masked, as a data-gradient epilogue leaves it
+        y_mean = y.double().mean(0).float()
+        y_istd = (1.0 / (y.double().var(0, unbiased=False) + 1e-5).sqrt()).float()
+        y_scale = (synthetic.tensor(tag + 'yg', (Cout,), seed=6, kind='uniform').abs() + 0.5) * y_istd
+        yhat = (y.double() - y_mean.double()) * y_istd.double()
+        coef = torch.stack([dz.double().mean(0), (dz.double() * yhat).mean(0)]).float()
+        dy64 = y_scale.double() * (dz.double() - coef[0].double() - yhat * coef[1].double())
+    else:
+        dy = synthetic.tensor(tag + 'dy', (M, Cout), seed=4) * 1e-3
+        dy64 = dy.double()
+    ref_dz, ref_s1, ref_s2, ref_dw, ref_db, z64 = _reference(x.double(), sc.double(), sh.double(), mu.double(), istd.double(),
+                                                              relu, dy64, w.double())
+    # device side
+    xd, scd, shd, mud, isd = (t.to(dev) for t in (x, sc, sh, mu, istd))
+    wdt = w.t().contiguous().to(dev)                                  # the data gradient's filter [Cin][Cout]
+    wb = torch.zeros(64, device=dev)
+    call('dsnt_amax', ptr(wdt), wdt.numel(), ptr(wb))
+    planes = torch.empty(2 * wdt.numel(), dtype=torch.float16, device=dev)
+    call('dsnt_split_f16x2', ptr(wdt), ptr(planes), wdt.numel(), wdt.numel(), ptr(wb))
+    act_max = (torch.relu(z64) if relu else z64).abs().max().item()
+    ab = _bound(act_max * 3.0, dev)
+    gb = _bound(dy64.abs().max().item() * 5.0, dev)                  # loose, as the analytic bound of the engine is
+    xs = BnBwdEpilogue(ptr(xd), ptr(scd), ptr(shd), ptr(mud), ptr(isd), relu)
+    if mode == 'apply':
+        yd, dzd = y.to(dev), dz.to(dev)
+        ysd, ymd, yid, cfd = y_scale.to(dev), y_mean.to(dev), y_istd.to(dev), coef.contiguous().to(dev)
+        ap = BnBwdApply(ptr(yd), ptr(ysd), ptr(ymd), ptr(yid), ptr(cfd))
+        dyd, apref = dzd, C.byref(ap)
+    else:
+        dyd, apref = dy.to(dev), None
+    splits = _lib.fn('dsnt_conv1x1_bwd_splits')(C.byref(g))
+    nws = _lib.fn('dsnt_conv1x1_bwd_ws_floats')(C.byref(g))
+    assert nws == splits * Cout * (Cin + 1) and 0 < splits <= 256
+    ws = torch.full((nws,), float('nan'), device=dev)
+    stats = torch.full((splits, 2, Cin), float('nan'), device=dev)
+    dz_out = torch.full((M, Cin), float('nan'), device=dev)
+    amax = torch.zeros(64, device=dev)
+    call('dsnt_conv1x1_bwd_f16x3', C.byref(xs), ptr(dyd), apref, ptr(planes), wdt.numel(), ptr(wb), ptr(ab), ptr(gb),
+         ptr(dz_out), ptr(stats), ptr(ws), ptr(amax), C.byref(g))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ws).all()) and bool(torch.isfinite(stats).all()) and bool(torch.isfinite(dz_out).all())
+    # data gradient (elements whose pre-activation sits at the kink may take either side)
+    got = dz_out.cpu().double()
+    sure = (z64.abs() > 1e-5) if relu else torch.ones_like(z64, dtype=torch.bool)
+    scale = ref_dz.abs().max().item()
+    e = ((got - ref_dz) * sure).abs().max().item()
+    assert e <= 2e-6 * scale, (e, scale)
+    assert abs(amax.max().item() - dz_out.abs().max().item()) == 0.0
+    # the BatchNorm-backward sums: one partial row per workgroup
+    s = stats.cpu().double().sum(0)
+    unsure1 = ((got.abs() + ref_dz.abs()) * ~sure).sum(0)
+    assert ((s[0] - ref_s1).abs() <= 1e-5 * ref_dz.abs().sum(0) + unsure1 + 1e-12).all()
+    xhat = ((x.double() - mu.double()) * istd.double()).abs()
+    assert ((s[1] - ref_s2).abs() <= 1e-5 * (ref_dz.abs() * xhat).sum(0) + unsure1 * xhat.max() + 1e-12).all()
+    # weight and bias gradient through the table-driven slab reduction
+    dw, db = torch.zeros(Cout, Cin, device=dev), torch.zeros(Cout, device=dev)
+    table = torch.tensor([[ws.data_ptr(), dw.data_ptr(), db.data_ptr(), splits, Cout * Cin, Cout, 0]],
+                         dtype=torch.int64).to(dev)
+    call('dsnt_wgrad_reduce_all', ptr(table), 1, (Cout * Cin // 4 + (Cout + 3) // 4 + 63) // 64)
+    ew = (dw.cpu().double() - ref_dw).abs().max().item()
+    assert ew <= 3e-6 * ref_dw.abs().max().item(), (ew, ref_dw.abs().max().item())
+    eb = (db.cpu().double() - ref_db).abs().max().item()
+    assert eb <= 3e-6 * max(ref_db.abs().max().item(), dy64.abs().sum(0).max().item() * 1e-2), eb
+    # a second launch writes the same bits (fixed summation order, no atomics on the results)
+    ws2, stats2, dz2 = torch.empty_like(ws), torch.empty_like(stats), torch.empty_like(dz_out)
+    call('dsnt_conv1x1_bwd_f16x3', C.byref(xs), ptr(dyd), apref, ptr(planes), wdt.numel(), ptr(wb), ptr(ab), ptr(gb),
+         ptr(dz2), ptr(stats2), ptr(ws2), None, C.byref(g))
+    assert torch.equal(ws, ws2) and torch.equal(stats, stats2) and torch.equal(dz_out, dz2)
+
+
+def test_conv1x1_backward_refusals():
+    from dsnt import _lib
+    from dsnt._lib import ConvGeom
+    ok = _lib.fn('dsnt_conv1x1_bwd_ok')
+    assert not ok(C.byref(ConvGeom(4, 64, 64, 256, 64, 64, 256, 1, 1, 1, 0, 1)))      # 256 -> 256: not built
+    assert not ok(C.byref(ConvGeom(4, 64, 64, 128, 64, 64, 128, 3, 3, 1, 1, 1)))      # 3x3
+    assert not ok(C.byref(ConvGeom(2, 16, 16, 256, 16, 16, 128, 1, 1, 1, 0, 1)))      # 512 rows
+    g = ConvGeom(2, 16, 16, 256, 16, 16, 128, 1, 1, 1, 0, 1)
+    rc = _lib.fn('dsnt_conv1x1_bwd_f16x3')(None, None, None, None, 0, None, None, None, None, None, None, None,
+                                           C.byref(g), None)
+    assert rc == 3
