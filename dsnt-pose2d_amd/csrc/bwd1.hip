@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
 // ---------------------------------------------------------------- host side
 static int b1_enabled = -1;
 
-Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g) {
+Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g, bool share) {
     Bwd1Plan pl;
     memset(&pl, 0, sizeof(pl));
     if (b1_enabled < 0) b1_enabled = dsnt_kernel_off("bwd1") ? 0 : 1;
@@ -361,7 +361,10 @@ Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g) {
                prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const int nstages = (int)(M / 32);
-    int nwg = cus < nstages ? cus : nstages;
+    // share (DSNT_CONV_SHARE_CHIP): the launch runs on a lane beside the dependency chain; a workgroup holds 113-140 KB of a
+    // CU's LDS for the whole launch, so it keeps to half of the CUs (as the streaming 1x1 kernel does: gemm1.hip)
+    int nwg = share ? (cus / 2 > 0 ? cus / 2 : 1) : cus;
+    if (nwg > nstages) nwg = nstages;
     const int spw = (nstages + nwg - 1) / nwg;
     nwg = (nstages + spw - 1) / spw;                        // no workgroup without a stage
     const int NN = g->Cout, CC = g->Cin;
@@ -402,22 +405,22 @@ void dsnt_bwd1_launch(const Bwd1Plan& pl, const dsnt_bn_bwd_epilogue* xs, const 
     else { if (ap) b1_launch_k<128, 1, 0>(pl, p, st); else b1_launch_k<128, 1, 1>(pl, p, st); }
 }
 
-extern "C" int dsnt_conv1x1_bwd_ok(const dsnt_conv_geom* g) { return dsnt_bwd1_plan(g).ok; }
-extern "C" int dsnt_conv1x1_bwd_splits(const dsnt_conv_geom* g) { return dsnt_bwd1_plan(g).nwg; }
-extern "C" int64_t dsnt_conv1x1_bwd_ws_floats(const dsnt_conv_geom* g) {
-    const Bwd1Plan pl = dsnt_bwd1_plan(g);
+extern "C" int dsnt_conv1x1_bwd_ok(const dsnt_conv_geom* g) { return dsnt_bwd1_plan(g, false).ok; }
+extern "C" int dsnt_conv1x1_bwd_splits(const dsnt_conv_geom* g, int flags) { return dsnt_bwd1_plan(g, (flags & DSNT_CONV_SHARE_CHIP) != 0).nwg; }
+extern "C" int64_t dsnt_conv1x1_bwd_ws_floats(const dsnt_conv_geom* g, int flags) {
+    const Bwd1Plan pl = dsnt_bwd1_plan(g, (flags & DSNT_CONV_SHARE_CHIP) != 0);
     return pl.ok ? (int64_t)pl.nwg * g->Cout * (g->Cin + 1) : 0;
 }
 
 extern "C" int dsnt_conv1x1_bwd_f16x3(const dsnt_bn_bwd_epilogue* xs, const float* dy, const dsnt_bn_bwd_apply* ap,
                                       const void* wd_planes, int64_t plane_stride, const float* w_bound,
                                       const float* a_bound, const float* g_bound, float* dz_out, float* stats_partial,
-                                      float* ws, float* dz_amax, const dsnt_conv_geom* g, void* stream) {
+                                      float* ws, float* dz_amax, int flags, const dsnt_conv_geom* g, void* stream) {
     DSNT_REQUIRE(xs && xs->x && xs->scale && xs->shift && xs->mean && xs->invstd && dy && wd_planes && w_bound && a_bound &&
                  g_bound && dz_out && stats_partial && ws && g, DSNT_ERR_ARG, "dsnt_conv1x1_bwd_f16x3: bad argument");
     DSNT_REQUIRE(!ap || (ap->y && ap->scale && ap->mean && ap->invstd && ap->coef), DSNT_ERR_ARG,
                  "dsnt_conv1x1_bwd_f16x3: incomplete dsnt_bn_bwd_apply");
-    const Bwd1Plan pl = dsnt_bwd1_plan(g);
+    const Bwd1Plan pl = dsnt_bwd1_plan(g, (flags & DSNT_CONV_SHARE_CHIP) != 0);
     DSNT_REQUIRE(pl.ok, DSNT_ERR_SHAPE, "dsnt_conv1x1_bwd_f16x3: geometry not supported (dsnt_conv1x1_bwd_ok)");
     DSNT_REQUIRE(dsnt_aligned16(xs->x) && dsnt_aligned16(dy) && dsnt_aligned16(wd_planes) && dsnt_aligned16(dz_out) &&
                  dsnt_aligned16(ws) && (!ap || dsnt_aligned16(ap->y)) && plane_stride % 8 == 0, DSNT_ERR_ALIGN,

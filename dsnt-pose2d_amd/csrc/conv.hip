@@ -152,6 +152,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x = fmaf(v.x, (xv.x - bmu.x) * bis.x, s2.x); s2.y = fmaf(v.y, (xv.y - bmu.y) * bis.y, s2.y);
                 s2.z = fmaf(v.z, (xv.z - bmu.z) * bis.z, s2.z); s2.w = fmaf(v.w, (xv.w - bmu.w) * bis.w, s2.w);
+                am = fmaxf(fmaxf(am, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));      // max |dz| (p.tail.amax)
                 continue;
             }
             v.x += bias4.x + r1[j].x + r2[j].x; v.y += bias4.y + r1[j].y + r2[j].y;
@@ -1152,7 +1153,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
     p.mtiles = (p.M + BM - 1) / BM; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
     const bool pro = in_scale != nullptr;
-    DSNT_REQUIRE(!((p.tail.amax || p.tail.amax_bn) && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
+    DSNT_REQUIRE(!(p.tail.amax_bn && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_ex: dsnt_bn_tail.amax_bn excludes the batch-norm-backward epilogue");
     if (BM == 32 && p.M <= ksplit_rows() && p.Cin % 8 == 0 && (size_t)p.N * p.H * p.W * p.Cin * 4u < (1ull << 31) &&
         (size_t)p.Cout * p.K * 4u < (1ull << 31) && !p.tail.amax && !p.tail.amax_bn &&        // (the K-split epilogue has no amax)
         (!pro || p.Cin <= 4096)) {
@@ -1503,7 +1504,7 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     const int BN = g->Cout <= 64 ? 64 : 128;
     p.mtiles = (p.M + 127) / 128; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
-    DSNT_REQUIRE(!((p.tail.amax || p.tail.amax_bn) && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
+    DSNT_REQUIRE(!(p.tail.amax_bn && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_bn_tail.amax_bn excludes the batch-norm-backward epilogue");
     p.a_bound = a_bound; p.w_bound = w_bound;
     const bool share_chip = a_bound && (in_relu & DSNT_CONV_SHARE_CHIP) != 0;       // (fp16x3 entry points) leave room beside this launch
     if (a_bound) p.in_relu = in_relu & 1;

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), yr, o0, so, 0);
                         s1 += val;
                         s2 = fmaf(val, (xv - col.mu) * col.is, s2);
+                        am = fmaxf(am, fabsf(val));          // max |dz| (p.tail.amax: the bound of a folded BatchNorm backward)
                     } else {
                         val += col.cb;
                         if (MODE >= 1) val += r[e];

@@ -7,6 +7,7 @@
 #include "common.h"
 #include <string.h>
 #include "bn_tail.h"
+#include "conv_split.h"
 
 #define TILE_ROWS 128
 
@@ -296,12 +297,16 @@ extern "C" int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const flo
 #define FIN_T 1024
 #endif
 #define FIN_P (FIN_T / 16)
+// MODE 1, optional: the bound of dx = scale (dz - coef0 - xhat coef1) for a consumer that forms dx in registers
+// (dsnt_conv1x1_bwd_f16x3): max_c |scale_c| (max|dz| + |coef0_c| + |coef1_c| sqrt(M)), |xhat| <= sqrt(M) for the batch
+// statistics of M samples; raised into the 64 slots of `out` like every other bound
+struct BnBoundP { const float* scale; const float* dz_amax; float sqrtM; unsigned* out; };
 template <int MODE>
 __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
     const float* __restrict__ partial, int ntiles, double invM, double unbias, int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, float momentum, float eps, int training, float* o0, float* o1, float* o2,
-    float* o3, int accumulate) {
+    float* o3, int accumulate, BnBoundP bp) {
     __shared__ double r0[FIN_T], r1[FIN_T];
     const int tid = threadIdx.x, cl = tid & 15, part = tid >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -350,6 +355,15 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
             o2[C + c] = (float)(a1 * invM);
         }
     }
+    if (MODE == 1 && bp.out) {
+        const float dzmax = bound64(bp.dz_amax);                 // (every thread: the shuffles need whole waves)
+        float b = 0.f;
+        if (part == 0 && c < C)
+            b = fabsf(bp.scale[c]) * (dzmax + fabsf((float)(r0[tid] * invM)) + fabsf((float)(r1[tid] * invM)) * bp.sqrtM);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+        if (tid == 0 && b > 0.f) atomicMax(bp.out + (blockIdx.x & 63), __float_as_uint(b));
+    }
 }
 
 extern "C" int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int C,
@@ -366,7 +380,7 @@ extern "C" int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int
     const double unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
     DSNT_LAUNCH(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
                        partial, ntiles, 1.0 / (double)M, unbias, C, gamma, beta, running_mean,
-                       running_var, momentum, eps, training, mean, invstd, scale, shift, 0);
+                       running_var, momentum, eps, training, mean, invstd, scale, shift, 0, BnBoundP{nullptr, nullptr, 0.f, nullptr});
     DSNT_CHECK_LAUNCH("dsnt_bn_finalize");
 }
 
@@ -408,8 +422,23 @@ extern "C" int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M,
                  "dsnt_bn_bwd_finalize: bad argument");
     DSNT_LAUNCH(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
                        partial, ntiles, 1.0 / (double)M, 1.0, C, nullptr, nullptr, nullptr, nullptr,
-                       0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate);
+                       0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate, BnBoundP{nullptr, nullptr, 0.f, nullptr});
     DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize");
+}
+
+// dsnt_bn_bwd_finalize that also leaves the bound of the BatchNorm's dx for a consumer that never sees dx in memory
+// (dsnt_conv1x1_bwd_f16x3 with a dsnt_bn_bwd_apply): scale = the BatchNorm's forward scale vector (gamma * invstd), dz_amax = the
+// 64-slot max |dz| its data-gradient producer left (dsnt_bn_tail.amax), bound_out = 64 slots, zeroed by the caller once per step.
+extern "C" int dsnt_bn_bwd_finalize_bound(const float* partial, int ntiles, int64_t M, int C, float* dgamma, float* dbeta,
+                                          int accumulate, float* coef, const float* scale, const float* dz_amax,
+                                          float* bound_out, void* stream) {
+    DSNT_REQUIRE(partial && coef && scale && dz_amax && bound_out && ntiles > 0 && C > 0 && M > 0, DSNT_ERR_ARG,
+                 "dsnt_bn_bwd_finalize_bound: bad argument");
+    DSNT_LAUNCH(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
+                       partial, ntiles, 1.0 / (double)M, 1.0, C, nullptr, nullptr, nullptr, nullptr,
+                       0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate,
+                       BnBoundP{scale, dz_amax, sqrtf((float)M), reinterpret_cast<unsigned*>(bound_out)});
+    DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize_bound");
 }
 
 // ---------------------------------------------------------------- flat elementwise

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm1_kernel(ConvP p, int niter) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, o0, so, 0);
                         s1 += v;
                         s2 = fmaf(v, (xv - col.mu) * col.is, s2);
+                        am = fmaxf(am, fabsf(v));            // max |dz| (p.tail.amax)
                     } else {
                         v += col.cb;
                         if (MODE >= 1) v += r[e];

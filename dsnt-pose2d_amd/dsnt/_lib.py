@@ -111,7 +111,7 @@ SIGNATURES = {
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_bf16x6': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_f16x3': [P, P, P, I, P, P, P, P, I, P, P, GP, P],
-    'dsnt_conv1x1_bwd_f16x3': [BP, P, AP, P, L, P, P, P, P, P, P, P, GP, P],
+    'dsnt_conv1x1_bwd_f16x3': [BP, P, AP, P, L, P, P, P, P, P, P, P, I, GP, P],
     'dsnt_wgrad_reduce_all': [P, I, I, P],
     'dsnt_conv_wgrad_group': [P, I, I, P],
     'dsnt_bn_stats': [P, P, L, I, P],
@@ -119,6 +119,7 @@ SIGNATURES = {
     'dsnt_bn_act_fwd': [P, P, P, I, P, L, I, P],
     'dsnt_bn_act_bwd_reduce': [P, P, P, P, P, P, I, P, L, I, P],
     'dsnt_bn_bwd_finalize': [P, I, L, I, P, P, I, P, P],
+    'dsnt_bn_bwd_finalize_bound': [P, I, L, I, P, P, I, P, P, P, P, P],
     'dsnt_bn_eval_prep': [P, I, P],
     'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
     'dsnt_bn_act_bwd_apply_amax': [P, P, P, P, P, P, P, I, P, I, L, I, P, P],
@@ -189,8 +190,8 @@ PLAIN = {
     'dsnt_conv_wgrad_f16x3_ws_floats': (L, [GP, I]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
     'dsnt_conv1x1_bwd_ok': (I, [GP]),
-    'dsnt_conv1x1_bwd_splits': (I, [GP]),
-    'dsnt_conv1x1_bwd_ws_floats': (L, [GP]),
+    'dsnt_conv1x1_bwd_splits': (I, [GP, I]),
+    'dsnt_conv1x1_bwd_ws_floats': (L, [GP, I]),
     'dsnt_conv_wgrad_desc_bytes': (I, []),
     'dsnt_conv_wgrad_desc': (I, [P, P, P, I, P, P, GP, P]),
     'dsnt_conv_wgrad_desc_f16x3': (I, [P, P, P, I, P, P, P, P, GP, P]),

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvGeom, BnBwdEpilogue, BnTail, BnPrologue
+from ._lib import ConvGeom, BnBwdEpilogue, BnTail, BnPrologue, BnBwdApply
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -32,7 +32,8 @@ BN_MOMENTUM = 0.1
 
 class Act:
     """An activation on the tape: NHWC buffer + lazily created gradient / batch statistics."""
-    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'stats_tail', 'amax_tail')
+    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'stats_tail', 'amax_tail', 'fold_ok',
+                 'pending_apply')
 
     def __init__(self, buf, name=''):
         self.buf = buf
@@ -42,6 +43,8 @@ class Act:
         self.stats_tail = None  # BnTail of the launch that writes `stats`: the first BatchNorm over this tensor claims it
         self.amax_tail = None   # fp16x3: the dsnt_bn_tail of the producing launch if it can leave max|buf| (operand_amax)
         self.grad_amax = None   # fp16x3: device scalar max|grad| when ONE bn-backward apply wrote the whole gradient
+        self.fold_ok = False    # the producing 1x1 convolution can take the BatchNorm backward of its consumer into its own backward
+        self.pending_apply = None   # ... and this is that BatchNorm backward, reduced but not applied (Tape._norm_backward)
         self.name = name
 
     @property
@@ -118,6 +121,9 @@ class Tape:
         self.wgrad_lane_from = self.chain_lanes
         # 3x3 forward / data gradient: the symmetric persistent kernel of csrc/conv3s.hip (stream-ordered weight planes)
         self.conv3s = 'conv3s' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')       # DSNT_OFF=conv3s,gemm1,wgrad3,wgrad1
+        # the whole backward of a 1x1 convolution in one launch (csrc/bwd1.hip): data gradient with the BatchNorm-backward
+        # epilogue + weight gradient + (conv1 of a Bottleneck) the BatchNorm backward of the layer behind, each tensor read once
+        self.bwd1 = 'bwd1' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
         self._f16_w_stream = {}
         # DSNT_CONV_SHARE_CHIP on the side lanes' launches of the two persistent kernels (3x3: 3/2 workgroups per CU; 1x1: half of
         # the CUs): both hold most of a CU's LDS for the whole launch, and the chain's kernels need LDS too (-0.2 ms)
@@ -402,7 +408,7 @@ class Tape:
                     else:
                         self.bytes_bwd += nb
                 conv.append(_lib.ptr(a))
-            elif isinstance(a, (ConvGeom, BnBwdEpilogue, BnTail, BnPrologue)):
+            elif isinstance(a, (ConvGeom, BnBwdEpilogue, BnTail, BnPrologue, BnBwdApply)):
                 self._keep.append(a)
                 conv.append(C.byref(a))
             else:
@@ -655,6 +661,8 @@ class Tape:
         """(buffer, accumulate flag) for a kernel about to write a's gradient.  `amax`: the kernel leaves max|written|
         in a.grad_amax (fp16x3 operand bound).  Every writer rewrites the whole tensor, so the slot stays a valid bound
         while all writers since its creation report into it; a writer that cannot invalidates it."""
+        if a.pending_apply is not None:          # a BatchNorm backward left to a's producer, and now a second contribution
+            self.materialize_apply(a)
         acc = 1
         if a.grad is None:
             a.grad = self.empty(a.N, a.H, a.W, a.C)
@@ -674,6 +682,8 @@ class Tape:
         """a.grad (+)= g.  With `donate`, g's buffer is handed over when a has no gradient yet
         (the caller guarantees g is dead after its own launches).  Returns True if donated.
         g_amax: the bound slot of g, if it has one (it moves with a donated buffer)."""
+        if a.pending_apply is not None:
+            self.materialize_apply(a)
         if a.grad is None and donate:
             a.grad = g
             a.grad_amax = g_amax if self.amax_all else None
@@ -755,10 +765,30 @@ class Tape:
         tl.out0, tl.out1, tl.out2 = _lib.ptr(bn.ggamma), _lib.ptr(bn.gbeta), _lib.ptr(coef)
         return tl, coef
 
-    def _norm_backward(self, n, da, reduced=None, finalised=False):
+    def fold_ok(self, n):
+        """The BatchNorm backward of Normed n can be left to the backward of the convolution that produced n.x."""
+        x = n.x
+        return bool(self.bwd1 and x.fold_ok and x.grad is None and x.pending_apply is None)
+
+    def materialize_apply(self, x):
+        """The apply launch of a BatchNorm backward that was left to x's producer (`_norm_backward` with dz_amax) after all:
+        x got a second gradient contribution, so its gradient has to exist in memory."""
+        ap, x.pending_apply = x.pending_apply, None
+        n = ap['n']
+        buf, acc = self.grad_target(x, amax='apply')
+        if x.grad_amax is not None:
+            self.b('dsnt_bn_act_bwd_apply_amax', ap['dz'], x.buf, n.scale, n.shift, n.mean, n.invstd, ap['coef'], 0,
+                   buf, acc, x.M, n.bn.C, x.grad_amax)
+        else:
+            self.b('dsnt_bn_act_bwd_apply', ap['dz'], x.buf, n.scale, n.shift, n.mean, n.invstd, ap['coef'], 0,
+                   buf, acc, x.M, n.bn.C)
+
+    def _norm_backward(self, n, da, reduced=None, finalised=False, dz_amax=None):
         """Given da = dL/d relu(bn(x)), accumulate dx into n.x.grad and dgamma/dbeta.  With
         `reduced` = (partials, ntiles) the producer already masked da by the ReLU and reduced it; with `finalised` it
-        also wrote dgamma / dbeta / coef (bwd_tail)."""
+        also wrote dgamma / dbeta / coef (bwd_tail).  With dz_amax (the slot in which the producer left max|da|; the
+        caller has asked `fold_ok`) dx is NOT written: the finalise launch also leaves the bound of dx, and the backward
+        of the 1x1 convolution that produced x forms dx in registers (dsnt_conv1x1_bwd_f16x3)."""
         x, bn = n.x, n.bn
         coef = self.scratch('bncoef', 2 * bn.C)
         relu = 1 if n.relu else 0
@@ -770,6 +800,16 @@ class Tape:
             part = self.scratch('bnpart', tiles * 2 * bn.C).view(-1)
             self.b('dsnt_bn_act_bwd_reduce', da, x.buf, n.scale, n.shift, n.mean, n.invstd, relu, part,
                    x.M, bn.C)
+        if dz_amax is not None:
+            assert reduced is not None and not finalised and x.grad is None
+            acc_p = 1 if bn.uses > 0 else 0
+            bn.uses += 1
+            coef = self.empty(2 * bn.C)          # lives until the producer's backward
+            bound = self.amax_slot()
+            self.b('dsnt_bn_bwd_finalize_bound', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef, n.scale,
+                   dz_amax, bound)
+            x.pending_apply = dict(dz=da, n=n, coef=coef, bound=bound, dz_amax=dz_amax)
+            return
         fused = (not finalised) and self.fuse_finalize and bn.C <= 256 and tiles * bn.C <= self.fuse_finalize_max
         if not finalised:
             acc_p = 1 if bn.uses > 0 else 0
@@ -855,166 +895,229 @@ class Tape:
             slot_k = len(self.dgrad_slots)
             self.dgrad_slots.append((p, slot))
             self.dgrad_total += (p.w.numel() + 7) // 8 * 8
+        # the whole backward of this convolution as ONE launch (csrc/bwd1.hip): 1x1 behind a train-mode BatchNorm, both
+        # operand bounds known on the device
+        fuse1 = bool(self.bwd1 and normed and self.use_f16x3 and self.defer_reduce and slot is not None and p.R == 1 and
+                     p.S == 1 and p.post_reduce is None and self.lib.dsnt_conv1x1_bwd_ok(C.byref(g)))
+        # ... and without residual inputs (whose gradient IS dL/dy) it can also take over the BatchNorm backward of its consumer
+        y.fold_ok = fuse1 and res1 is None and res2 is None
 
         def backward():
             gy = y.grad
-            assert gy is not None, 'no gradient reached conv output ' + name
-            # parameter gradients (flat arena, overwritten every step)
-            # the weight gradient feeds nothing downstream in backward: run it on its own lane so the
-            # data-gradient chain never waits for it
-            cur = self.lane
-            wl = cur
-            if self.wgrad_lane is not None:
-                # DSNT_WGRAD_LANE_ROWS > 0: only the large main-lane convolutions whose dY nobody writes again (no
-                # residual inputs: the gradient buffer is not donated onwards) — their weight gradients then fill the
-                # chip while the main lane walks the launch-bound low-resolution levels
-                if self.wgrad_lane_rows == 0 or (cur in self.wgrad_lane_from and (self.wgrad_lane_res or (res1 is None and res2 is None)) and
-                                                 g.N * g.Ho * g.Wo >= self.wgrad_lane_rows):
-                    wl = self.wgrad_lane
-            hold = wl != cur and self._release_left > 0
-            if hold:
-                listed, self.bwd = self.bwd, self._held
-            self.sync_bwd(cur, wl)
-            self.lane = wl
-            if wl != cur:
-                # gy may be donated onwards and accumulated into by a later launch of another lane: that writer waits
-                # for the weight-gradient lane first (grad_target)
-                self._wgrad_lane_reads.add(gy.data_ptr())
-            nws = self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g))
-            # DSNT_WGRAD_SHARE_CHIP: one workgroup per CU beside the chain — except for the first convolution of the
-            # network (no data gradient: it is the LAST launch of backward and has the chip to itself)
-            share = 2 if (wl != cur and self.wgrad_share and need_input_grad) else 0
-            w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
-            if self.defer_reduce:
-                # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
-                # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
-                grouped = (w6 and normed and res1 is None and res2 is None and wl == cur and
-                           0 < g.N * g.Ho * g.Wo <= self.group_rows)
-                # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
-                w16 = w6 and self.use_f16x3 and (normed or x_amax is not None) and y.grad_amax is not None
-                ab = (self.f16_bn_bound_bwd(src) if normed else x_amax) if w16 else None
-                splits = self.lib.dsnt_conv_wgrad_splits(C.byref(g))
-                if w16 and not grouped:
-                    # dsnt_conv_wgrad_f16x3 cuts the pixels of a 3x3 convolution into its own slabs (halo kernel)
-                    nws = self.lib.dsnt_conv_wgrad_f16x3_ws_floats(C.byref(g), share)
-                    splits = self.lib.dsnt_conv_wgrad_f16x3_splits(C.byref(g), share)
-                ws = self.empty(nws)         # lives until the bucket's reduction
-                self._ws_ptrs.add(ws.data_ptr())
-                if grouped:
-                    desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
-                    if w16:
-                        nblk = self.lib.dsnt_conv_wgrad_desc_f16x3(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
-                                                                   _lib.ptr(gy), _lib.ptr(ws), _lib.ptr(ab),
-                                                                   _lib.ptr(y.grad_amax), C.byref(g), desc)
-                    else:
-                        nblk = self.lib.dsnt_conv_wgrad_desc(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
-                                                             _lib.ptr(gy), _lib.ptr(ws), C.byref(g), desc)
-                    if nblk <= 0:
-                        raise RuntimeError('dsnt_conv_wgrad_desc failed: %s' % self.lib.dsnt_last_error().decode())
-                    self._pending_group.append((desc.raw, nblk))
-                    if w16:
-                        self._pending_group_uses.append(dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu,
-                                                             a_bound=ab, g=gy, g_bound=y.grad_amax))
-                elif w16:
-                    e = self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, share, ab, y.grad_amax, g)
-                    self.f16_uses.append((e, dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
-                                                  g=gy, g_bound=y.grad_amax)))
-                else:
-                    self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
-                           None, None, share if w6 else 0, g)
-                if p.post_reduce is not None:
-                    self._post_reduce.append(p.post_reduce)
-                self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
-                                             splits, p.Cout * g.R * g.S * g.Cin, p.Cout, 0])
-            else:
-                ws = self.scratch('wgrad', nws)
-                self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
-                       p.gw, p.gb, 0, g)
-                if p.post_reduce is not None:      # the stem's space-to-depth gradient -> the parameter's 7x7 layout
-                    self.b(p.post_reduce[0], *p.post_reduce[1])
-            self.lane = cur
-            if hold:
-                self.bwd = listed
-            if need_input_grad:
+            ap = y.pending_apply
+            fused = fuse1 and self.dgrad_planes16 is not None
+            if ap is not None and (not fused or gy is not None):
+                self.materialize_apply(y)
+                ap, gy = None, y.grad
+            assert gy is not None or ap is not None, 'no gradient reached conv output ' + name
+            if fused and ap is None and y.grad_amax is None:
+                fused = False
+            cur = wl = self.lane
+            if fused:
                 nw = p.w.numel()
-                pad_d = p.dil * (p.R - 1) - p.pad
-                assert pad_d >= 0, 'data gradient needs pad <= dil * (R - 1)'
-                native = p.stride != 1 and slot is not None and self.lib.dsnt_conv_dgrad_strided_ok(C.byref(g))
-                if p.stride == 1:
-                    gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
-                elif native:
-                    # strided convolution (ResNet stage transitions): dsnt_conv_dgrad_strided computes the pixels of dX
-                    # phase by phase straight from dY (csrc/dgrad_up.hip)
-                    gd = None
+                shr = 2 if (self.lane != 0 and self.conv_share) else 0
+                nsp = self.lib.dsnt_conv1x1_bwd_splits(C.byref(g), shr)
+                ws = self.empty(self.lib.dsnt_conv1x1_bwd_ws_floats(C.byref(g), shr))      # lives until the bucket's reduction
+                self._ws_ptrs.add(ws.data_ptr())
+                wd = self.dgrad_f32[slot:slot + nw]
+                wq16 = self.dgrad_planes16[slot:slot + nw]
+                wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
+                self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total, 0, 0])
+                ab = self.f16_bn_bound_bwd(src)
+                # (the BatchNorm in front of THIS convolution may in turn be left to the 1x1 convolution before it)
+                fold = self.fold_ok(src)
+                dz = self.empty(x.M * x.C) if fold else self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
+                dz_amax = self.amax_slot() if fold else None
+                part = self.scratch('bnpart', nsp * 2 * x.C).view(-1)
+                xs = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift), _lib.ptr(src.mean),
+                                   _lib.ptr(src.invstd), 1 if src.relu else 0)
+                if ap is not None:
+                    n2 = ap['n']
+                    aps = BnBwdApply(_lib.ptr(y.buf), _lib.ptr(n2.scale), _lib.ptr(n2.mean), _lib.ptr(n2.invstd), _lib.ptr(ap['coef']))
+                    dy, gb = ap['dz'], ap['bound']
+                    y.pending_apply = None
                 else:
-                    # ... or, for the shapes that kernel refuses: the stride-1 data gradient of dY with stride-1
-                    # zeros stuffed between the pixels
-                    Hs = x.H + 2 * p.pad - p.dil * (p.R - 1)
-                    Ws = x.W + 2 * p.pad - p.dil * (p.S - 1)
-                    stuffed = self.scratch('stuffed', x.N * Hs * Ws * p.Cout).view(-1)[:x.N * Hs * Ws * p.Cout]
-                    self.b('dsnt_zero_insert', gy, stuffed, x.N, g.Ho, g.Wo, p.Cout, Hs, Ws, p.stride)
-                    gy_d = stuffed
-                    gd = ConvGeom(x.N, Hs, Ws, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
-                if slot is not None:
-                    wd = self.dgrad_f32[slot:slot + nw]
-                    wq, wq_stride = self.dgrad_planes[slot:slot + nw], self.dgrad_total
-                    d6 = gd is not None and self._use6(gd)
-                else:       # stand-alone use without a parameter arena
-                    wd = self.scratch('wdgrad', nw)
-                    self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
-                    d6 = self._use6(gd) and nw % 8 == 0
-                    if d6:
-                        wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
-                        self.b('dsnt_split_bf16x3', wd, wq, nw)
-
-                gsrc = gy if (p.stride == 1 or native) else gy_d
-
-                g_amax = y.grad_amax if (self.use_f16x3 and p.stride == 1) else None
-                d16 = d6 and g_amax is not None and slot is not None and self.dgrad_planes16 is not None
-                if d16:
-                    wq16 = self.dgrad_planes16[slot:slot + nw]
-                    wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
-                    # (the data gradient's filter is [Cin][3][3][Cout]: its "Cout" is this convolution's Cin)
-                    d_stream = self.stream_ok(p, gd, x.M, None)
-                    self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total] +
-                                             ([p.Cin, p.Cout] if d_stream else [0, 0]))
-
-                def dgrad(out, res, part=None, bnb=None, tail=None):
-                    if native:
-                        self.b('dsnt_conv_dgrad_strided', gy, wd, out, res, part, g, bnb, tail)
-                    elif d16:
-                        e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
-                                   self.dgrad_total, wbd, g_amax, None, out, None,
-                                   None, 2 if ((d_stream or p.R == 1) and self.lane != 0 and self.conv_share) else 0, res, None, part, gd, bnb, tail)
-                        self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
-                    elif d6:
-                        self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
-                               part, gd, bnb, tail)
-                    else:
-                        self.b('dsnt_conv_fwd_ex', gsrc, wd, None, out, None, None, 0, res, None, part, gd, bnb, tail)
-                if normed:
-                    # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
-                    # data-gradient epilogue; only finalise + apply remain as separate launches
-                    dz = self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
-                    if native:
-                        tiles = self.lib.dsnt_conv_dgrad_strided_tiles(C.byref(g))
-                    else:
-                        bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
-                        tiles = (x.M + bm - 1) // bm
-                    part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
-                    bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
-                                        _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
-                    tl, _ = (None, None) if native else self.bwd_tail(src, tiles)
-                    dgrad(dz, None, part, bnb, tl)
-                    self._norm_backward(src, dz, reduced=(part, tiles), finalised=tl is not None)
+                    aps, dy, gb = None, gy, y.grad_amax
+                e = self.b('dsnt_conv1x1_bwd_f16x3', xs, dy, aps, wq16, self.dgrad_total, wbd, ab, gb, dz, part, ws, dz_amax,
+                           shr, g)
+                nb = 4 * (x.buf.numel() + (y.buf.numel() if ap is not None else 0))      # (tensors named inside the structs)
+                self.bytes_bwd += nb
+                self.bytes_by_name['dsnt_conv1x1_bwd_f16x3'] = self.bytes_by_name.get('dsnt_conv1x1_bwd_f16x3', 0) + nb
+                u = dict(kind='bwd1', name=name, x=x.buf, sc=src.scale, sh=src.shift, relu=1 if src.relu else 0, a_bound=ab,
+                         w=wd, w_bound=wbd)
+                if ap is not None:
+                    u.update(g_apply=dict(dz=dy, y=y.buf, scale=n2.scale, mean=n2.mean, invstd=n2.invstd, coef=ap['coef']),
+                             g_bound=gb)
                 else:
-                    # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
-                    buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16)
-                    tl = None
-                    if x.grad_amax is not None:
-                        tl = BnTail()
-                        tl.amax = x.grad_amax.data_ptr()
-                    dgrad(buf, buf if acc else None, tail=tl)
+                    u.update(g=dy, g_bound=gb)
+                self.f16_uses.append((e, u))
+                self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
+                                             nsp, p.Cout * g.Cin, p.Cout, 0])
+                self._norm_backward(src, dz, reduced=(part, nsp), finalised=False, dz_amax=dz_amax)
+            else:
+                # parameter gradients (flat arena, overwritten every step)
+                # the weight gradient feeds nothing downstream in backward: run it on its own lane so the
+                # data-gradient chain never waits for it
+                cur = self.lane
+                wl = cur
+                if self.wgrad_lane is not None:
+                    # DSNT_WGRAD_LANE_ROWS > 0: only the large main-lane convolutions whose dY nobody writes again (no
+                    # residual inputs: the gradient buffer is not donated onwards) — their weight gradients then fill the
+                    # chip while the main lane walks the launch-bound low-resolution levels
+                    if self.wgrad_lane_rows == 0 or (cur in self.wgrad_lane_from and (self.wgrad_lane_res or (res1 is None and res2 is None)) and
+                                                     g.N * g.Ho * g.Wo >= self.wgrad_lane_rows):
+                        wl = self.wgrad_lane
+                hold = wl != cur and self._release_left > 0
+                if hold:
+                    listed, self.bwd = self.bwd, self._held
+                self.sync_bwd(cur, wl)
+                self.lane = wl
+                if wl != cur:
+                    # gy may be donated onwards and accumulated into by a later launch of another lane: that writer waits
+                    # for the weight-gradient lane first (grad_target)
+                    self._wgrad_lane_reads.add(gy.data_ptr())
+                nws = self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g))
+                # DSNT_WGRAD_SHARE_CHIP: one workgroup per CU beside the chain — except for the first convolution of the
+                # network (no data gradient: it is the LAST launch of backward and has the chip to itself)
+                share = 2 if (wl != cur and self.wgrad_share and need_input_grad) else 0
+                w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
+                if self.defer_reduce:
+                    # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
+                    # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
+                    grouped = (w6 and normed and res1 is None and res2 is None and wl == cur and
+                               0 < g.N * g.Ho * g.Wo <= self.group_rows)
+                    # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
+                    w16 = w6 and self.use_f16x3 and (normed or x_amax is not None) and y.grad_amax is not None
+                    ab = (self.f16_bn_bound_bwd(src) if normed else x_amax) if w16 else None
+                    splits = self.lib.dsnt_conv_wgrad_splits(C.byref(g))
+                    if w16 and not grouped:
+                        # dsnt_conv_wgrad_f16x3 cuts the pixels of a 3x3 convolution into its own slabs (halo kernel)
+                        nws = self.lib.dsnt_conv_wgrad_f16x3_ws_floats(C.byref(g), share)
+                        splits = self.lib.dsnt_conv_wgrad_f16x3_splits(C.byref(g), share)
+                    ws = self.empty(nws)         # lives until the bucket's reduction
+                    self._ws_ptrs.add(ws.data_ptr())
+                    if grouped:
+                        desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
+                        if w16:
+                            nblk = self.lib.dsnt_conv_wgrad_desc_f16x3(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
+                                                                       _lib.ptr(gy), _lib.ptr(ws), _lib.ptr(ab),
+                                                                       _lib.ptr(y.grad_amax), C.byref(g), desc)
+                        else:
+                            nblk = self.lib.dsnt_conv_wgrad_desc(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
+                                                                 _lib.ptr(gy), _lib.ptr(ws), C.byref(g), desc)
+                        if nblk <= 0:
+                            raise RuntimeError('dsnt_conv_wgrad_desc failed: %s' % self.lib.dsnt_last_error().decode())
+                        self._pending_group.append((desc.raw, nblk))
+                        if w16:
+                            self._pending_group_uses.append(dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu,
+                                                                 a_bound=ab, g=gy, g_bound=y.grad_amax))
+                    elif w16:
+                        e = self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, share, ab, y.grad_amax, g)
+                        self.f16_uses.append((e, dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
+                                                      g=gy, g_bound=y.grad_amax)))
+                    else:
+                        self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
+                               None, None, share if w6 else 0, g)
+                    if p.post_reduce is not None:
+                        self._post_reduce.append(p.post_reduce)
+                    self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
+                                                 splits, p.Cout * g.R * g.S * g.Cin, p.Cout, 0])
+                else:
+                    ws = self.scratch('wgrad', nws)
+                    self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
+                           p.gw, p.gb, 0, g)
+                    if p.post_reduce is not None:      # the stem's space-to-depth gradient -> the parameter's 7x7 layout
+                        self.b(p.post_reduce[0], *p.post_reduce[1])
+                self.lane = cur
+                if hold:
+                    self.bwd = listed
+                if need_input_grad:
+                    nw = p.w.numel()
+                    pad_d = p.dil * (p.R - 1) - p.pad
+                    assert pad_d >= 0, 'data gradient needs pad <= dil * (R - 1)'
+                    native = p.stride != 1 and slot is not None and self.lib.dsnt_conv_dgrad_strided_ok(C.byref(g))
+                    if p.stride == 1:
+                        gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
+                    elif native:
+                        # strided convolution (ResNet stage transitions): dsnt_conv_dgrad_strided computes the pixels of dX
+                        # phase by phase straight from dY (csrc/dgrad_up.hip)
+                        gd = None
+                    else:
+                        # ... or, for the shapes that kernel refuses: the stride-1 data gradient of dY with stride-1
+                        # zeros stuffed between the pixels
+                        Hs = x.H + 2 * p.pad - p.dil * (p.R - 1)
+                        Ws = x.W + 2 * p.pad - p.dil * (p.S - 1)
+                        stuffed = self.scratch('stuffed', x.N * Hs * Ws * p.Cout).view(-1)[:x.N * Hs * Ws * p.Cout]
+                        self.b('dsnt_zero_insert', gy, stuffed, x.N, g.Ho, g.Wo, p.Cout, Hs, Ws, p.stride)
+                        gy_d = stuffed
+                        gd = ConvGeom(x.N, Hs, Ws, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
+                    if slot is not None:
+                        wd = self.dgrad_f32[slot:slot + nw]
+                        wq, wq_stride = self.dgrad_planes[slot:slot + nw], self.dgrad_total
+                        d6 = gd is not None and self._use6(gd)
+                    else:       # stand-alone use without a parameter arena
+                        wd = self.scratch('wdgrad', nw)
+                        self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
+                        d6 = self._use6(gd) and nw % 8 == 0
+                        if d6:
+                            wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
+                            self.b('dsnt_split_bf16x3', wd, wq, nw)
+
+                    gsrc = gy if (p.stride == 1 or native) else gy_d
+
+                    g_amax = y.grad_amax if (self.use_f16x3 and p.stride == 1) else None
+                    d16 = d6 and g_amax is not None and slot is not None and self.dgrad_planes16 is not None
+                    if d16:
+                        wq16 = self.dgrad_planes16[slot:slot + nw]
+                        wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
+                        # (the data gradient's filter is [Cin][3][3][Cout]: its "Cout" is this convolution's Cin)
+                        d_stream = self.stream_ok(p, gd, x.M, None)
+                        self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total] +
+                                                 ([p.Cin, p.Cout] if d_stream else [0, 0]))
+
+                    def dgrad(out, res, part=None, bnb=None, tail=None):
+                        if native:
+                            self.b('dsnt_conv_dgrad_strided', gy, wd, out, res, part, g, bnb, tail)
+                        elif d16:
+                            e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
+                                       self.dgrad_total, wbd, g_amax, None, out, None,
+                                       None, 2 if ((d_stream or p.R == 1) and self.lane != 0 and self.conv_share) else 0, res, None, part, gd, bnb, tail)
+                            self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
+                        elif d6:
+                            self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
+                                   part, gd, bnb, tail)
+                        else:
+                            self.b('dsnt_conv_fwd_ex', gsrc, wd, None, out, None, None, 0, res, None, part, gd, bnb, tail)
+                    if normed:
+                        # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
+                        # data-gradient epilogue; only finalise + apply remain as separate launches
+                        # (fold: the 1x1 convolution that produced x forms this BatchNorm's dx in its own backward — dz then has
+                        # to outlive this op's launches, and its maximum is what the bound of dx is made from)
+                        fold = not native and self.fold_ok(src)
+                        dz = self.empty(x.M * x.C) if fold else self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
+                        if native:
+                            tiles = self.lib.dsnt_conv_dgrad_strided_tiles(C.byref(g))
+                        else:
+                            bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
+                            tiles = (x.M + bm - 1) // bm
+                        part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
+                        bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
+                                            _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
+                        tl, _ = (None, None) if native else self.bwd_tail(src, tiles)
+                        finalised, dz_amax = tl is not None, None
+                        if fold and tl is None:
+                            tl, dz_amax = BnTail(), self.amax_slot()
+                            tl.amax = dz_amax.data_ptr()
+                        dgrad(dz, None, part, bnb, tl)
+                        self._norm_backward(src, dz, reduced=(part, tiles), finalised=finalised, dz_amax=dz_amax)
+                    else:
+                        # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
+                        buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16)
+                        tl = None
+                        if x.grad_amax is not None:
+                            tl = BnTail()
+                            tl.amax = x.grad_amax.data_ptr()
+                        dgrad(buf, buf if acc else None, tail=tl)
             # identity branches last: gy is dead after the launches above (the weight-gradient lane
             # must have read it before anyone accumulates into the donated buffer)
             if res1 is not None or res2 is not None:

@@ -51,7 +51,8 @@ typedef enum {
  *         max |value| it writes to its output (atomic max on the bit patterns of non-negative floats: the caller zeroes
  *         the 64 slots once per step) — the fp16x3 operand bound of a consumer that reads the output without a
  *         BatchNorm in between (skip projections, `lin` convolutions: hourglass.py:45-48,120-135), or of a data
- *         gradient written by a convolution epilogue.  Not with a bn_bwd_epilogue.
+ *         gradient written by a convolution epilogue.  With a bn_bwd_epilogue: max |dz| (what dsnt_bn_bwd_finalize_bound
+ *         turns into the bound of a BatchNorm backward folded into dsnt_conv1x1_bwd_f16x3).
  * amax_bn (may be NULL): the same for max |relu?(value * amax_scale[c] + amax_shift[c])| — the operand a consumer with
  *         an EVAL-mode BatchNorm(+ReLU) prologue will form from this output (inference.py:38-48: the vectors come from
  *         running statistics, so they exist before the producer runs); amax_scale / amax_shift: [C], 16-byte aligned. */
@@ -376,7 +377,8 @@ int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate)
  * same registers), dy (and ap->y) once: 402 MB instead of 737 MB for 256 -> 128 channels at 64 x 64, batch 32.
  * wd_planes: the data-gradient weights [Cin][Cout] (dsnt_conv_pack_dgrad) as two fp16 planes with bound w_bound
  * (dsnt_f16_prep_weights); a_bound >= max|act(x)|, g_bound >= max|dY| (64-slot bounds; with `ap`:
- * dsnt_bn_bwd_finalize_bound leaves it); dz_amax (may be NULL): raised to max|dz_out|.
+ * dsnt_bn_bwd_finalize_bound leaves it); dz_amax (may be NULL): raised to max|dz_out|.  flags: DSNT_CONV_SHARE_CHIP = the launch
+ * runs on a stream of its own beside other work and keeps to half of the CUs (`splits` / ws size are asked with the same flags).
  * dsnt_conv1x1_bwd_ok(g) != 0: (Cout, Cin) in {(128, 256), (256, 128), (128, 128)}, N*H*W % 32 == 0 and >= 16384. */
 typedef struct {
     const float* y;            /* the convolution's own output = the BatchNorm's input, [M][Cout] */
@@ -384,12 +386,12 @@ typedef struct {
     const float* coef;         /* [2][Cout] as dsnt_bn_bwd_finalize leaves it */
 } dsnt_bn_bwd_apply;
 int dsnt_conv1x1_bwd_ok(const dsnt_conv_geom* g);
-int dsnt_conv1x1_bwd_splits(const dsnt_conv_geom* g);
-int64_t dsnt_conv1x1_bwd_ws_floats(const dsnt_conv_geom* g);
+int dsnt_conv1x1_bwd_splits(const dsnt_conv_geom* g, int flags);
+int64_t dsnt_conv1x1_bwd_ws_floats(const dsnt_conv_geom* g, int flags);
 int dsnt_conv1x1_bwd_f16x3(const dsnt_bn_bwd_epilogue* xs, const float* dy, const dsnt_bn_bwd_apply* ap,
                            const void* wd_planes, int64_t plane_stride, const float* w_bound, const float* a_bound,
                            const float* g_bound, float* dz_out, float* stats_partial, float* ws, float* dz_amax,
-                           const dsnt_conv_geom* g, void* stream);
+                           int flags, const dsnt_conv_geom* g, void* stream);
 
 /* ----------------------------------------------------- heat-map matching ("gauss" output strategy)
  * Rows = (image, joint) maps of h x w floats, target = normalised coordinates [rows][2].
@@ -448,6 +450,13 @@ int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const float* scale,
 int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M, int C,
                          float* dgamma, float* dbeta, int accumulate, float* coef,
                          void* stream);
+/* The same, and the bound of dx = scale (dz - coef0 - xhat coef1) for dsnt_conv1x1_bwd_f16x3, which forms dx in registers and
+ * needs its fp16x3 scale beforehand: max_c |scale_c| (max|dz| + |coef0_c| + |coef1_c| sqrt(M)) raised into bound_out (64 slots,
+ * zeroed by the caller once per step); scale = the BatchNorm's forward scale (gamma * invstd), dz_amax = the 64-slot max |dz| the
+ * data-gradient launch left through dsnt_bn_tail.amax.  hourglass.py:21,36-37 (bn2 of a Bottleneck, backward). */
+int dsnt_bn_bwd_finalize_bound(const float* partial, int ntiles, int64_t M, int C, float* dgamma, float* dbeta,
+                               int accumulate, float* coef, const float* scale, const float* dz_amax, float* bound_out,
+                               void* stream);
 int dsnt_bn_act_bwd_apply(const float* da, const float* x, const float* scale,
                           const float* shift, const float* mean, const float* invstd,
                           const float* coef, int relu, float* dx, int accumulate,

@@ -36,7 +36,7 @@ def _train_step_with_probe(base, reg, batch):
     uses = {}
     for entry, info in prog.tape.f16_uses:
         uses.setdefault(id(entry), []).append(info)
-    checked = {'fwd': 0, 'wgrad': 0, 'dgrad': 0}
+    checked = {'fwd': 0, 'wgrad': 0, 'dgrad': 0, 'bwd1': 0}
     worst = {'a': 0.0, 'w': 0.0, 'g': 0.0}
     bad = []
 
@@ -63,6 +63,17 @@ def _train_step_with_probe(base, reg, batch):
                 worst['w'] = max(worst['w'], got / bound)
                 if not got <= bound:
                     bad.append((u['kind'], u['name'], 'W', got, bound))
+            if 'g_apply' in u:
+                # dsnt_conv1x1_bwd_f16x3 forms dL/dy = scale (dz - coef0 - (y - mean) invstd coef1) in registers: the analytic
+                # bound dsnt_bn_bwd_finalize_bound left must dominate it
+                a = u['g_apply']
+                Cc = a['scale'].numel()
+                dy = a['scale'] * (a['dz'].view(-1, Cc) - a['coef'][:Cc] -
+                                   (a['y'].view(-1, Cc) - a['mean']) * a['invstd'] * a['coef'][Cc:])
+                got, bound = float(dy.abs().max()), float(u['g_bound'].max())
+                worst['gf'] = max(worst.get('gf', 0.0), got / max(bound, 1e-30))
+                if not got <= bound:
+                    bad.append((u['kind'], u['name'], 'dY (folded BatchNorm backward)', got, bound))
             if 'g' in u:
                 got, bound = float(u['g'].abs().max()), float(u['g_bound'].max())
                 worst['g'] = max(worst['g'], got / max(bound, 1e-30))
@@ -87,7 +98,10 @@ def _train_step_with_probe(base, reg, batch):
 def test_every_fp16x3_bound_dominates_its_operand(base, reg, batch, min_uses):
     m, loss, checked, worst, bad, prog = _train_step_with_probe(base, reg, batch)
     assert not bad, bad[:8]
-    assert checked['fwd'] >= min_uses[0] and checked['wgrad'] >= min_uses[1] and checked['dgrad'] >= min_uses[2], checked
+    assert checked['fwd'] >= min_uses[0] and checked['wgrad'] + checked['bwd1'] >= min_uses[1] and \
+        checked['dgrad'] + checked['bwd1'] >= min_uses[2] and checked['bwd1'] >= 10, checked
+    # the analytic bound of a folded BatchNorm backward is loose (|xhat| <= sqrt(M)) but not absurd: within 2^12 of the operand
+    assert 2.0 ** -12 < worst['gf'] <= 1.0, worst
     # exact bounds (weights, gradients) are tight; the analytic BatchNorm bound is loose but must not be absurd
     assert worst['w'] == 1.0 and 0.0 < worst['g'] <= 1.0 and 0.0 < worst['a'] <= 1.0, worst
     assert torch.isfinite(loss).item()

@@ -88,15 +88,15 @@ def test_conv1x1_backward_in_one_pass(case, mode, relu):
         dyd, apref = dzd, C.byref(ap)
     else:
         dyd, apref = dy.to(dev), None
-    splits = _lib.fn('dsnt_conv1x1_bwd_splits')(C.byref(g))
-    nws = _lib.fn('dsnt_conv1x1_bwd_ws_floats')(C.byref(g))
+    splits = _lib.fn('dsnt_conv1x1_bwd_splits')(C.byref(g), 0)
+    nws = _lib.fn('dsnt_conv1x1_bwd_ws_floats')(C.byref(g), 0)
     assert nws == splits * Cout * (Cin + 1) and 0 < splits <= 256
     ws = torch.full((nws,), float('nan'), device=dev)
     stats = torch.full((splits, 2, Cin), float('nan'), device=dev)
     dz_out = torch.full((M, Cin), float('nan'), device=dev)
     amax = torch.zeros(64, device=dev)
     call('dsnt_conv1x1_bwd_f16x3', C.byref(xs), ptr(dyd), apref, ptr(planes), wdt.numel(), ptr(wb), ptr(ab), ptr(gb),
-         ptr(dz_out), ptr(stats), ptr(ws), ptr(amax), C.byref(g))
+         ptr(dz_out), ptr(stats), ptr(ws), ptr(amax), 0, C.byref(g))
     torch.cuda.synchronize()
     assert bool(torch.isfinite(ws).all()) and bool(torch.isfinite(stats).all()) and bool(torch.isfinite(dz_out).all())
     # data gradient (elements whose pre-activation sits at the kink may take either side)
@@ -124,7 +124,7 @@ def test_conv1x1_backward_in_one_pass(case, mode, relu):
     # a second launch writes the same bits (fixed summation order, no atomics on the results)
     ws2, stats2, dz2 = torch.empty_like(ws), torch.empty_like(stats), torch.empty_like(dz_out)
     call('dsnt_conv1x1_bwd_f16x3', C.byref(xs), ptr(dyd), apref, ptr(planes), wdt.numel(), ptr(wb), ptr(ab), ptr(gb),
-         ptr(dz2), ptr(stats2), ptr(ws2), None, C.byref(g))
+         ptr(dz2), ptr(stats2), ptr(ws2), None, 0, C.byref(g))
     assert torch.equal(ws, ws2) and torch.equal(stats, stats2) and torch.equal(dz_out, dz2)
 
 
@@ -137,5 +137,5 @@ def test_conv1x1_backward_refusals():
     assert not ok(C.byref(ConvGeom(2, 16, 16, 256, 16, 16, 128, 1, 1, 1, 0, 1)))      # 512 rows
     g = ConvGeom(2, 16, 16, 256, 16, 16, 128, 1, 1, 1, 0, 1)
     rc = _lib.fn('dsnt_conv1x1_bwd_f16x3')(None, None, None, None, 0, None, None, None, None, None, None, None,
-                                           C.byref(g), None)
+                                           0, C.byref(g), None)
     assert rc == 3

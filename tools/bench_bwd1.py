@@ -50,8 +50,8 @@ for (H, Cin, Cout, apply) in [(64, 256, 128, True), (64, 128, 256, False), (64, 
     gb = torch.full((64,), 0.05, device=dev)
     xs = BnBwdEpilogue(ptr(x), ptr(sc), ptr(sh), ptr(mu), ptr(istd), 1)
     ap = BnBwdApply(ptr(y), ptr(ysc), ptr(ymu), ptr(yis), ptr(coef))
-    splits = _lib.fn('dsnt_conv1x1_bwd_splits')(C.byref(g))
-    ws = torch.empty(_lib.fn('dsnt_conv1x1_bwd_ws_floats')(C.byref(g)), device=dev)
+    splits = _lib.fn('dsnt_conv1x1_bwd_splits')(C.byref(g), 0)
+    ws = torch.empty(_lib.fn('dsnt_conv1x1_bwd_ws_floats')(C.byref(g), 0), device=dev)
     stats = torch.empty(splits, 2, Cin, device=dev)
     dzx = torch.empty(M, Cin, device=dev)
     st = lambda: torch.cuda.current_stream().cuda_stream
@@ -59,7 +59,7 @@ for (H, Cin, Cout, apply) in [(64, 256, 128, True), (64, 128, 256, False), (64, 
 
     def run_fused():
         assert fused(C.byref(xs), ptr(dz), C.byref(ap) if apply else None, ptr(planes), wd.numel(), ptr(wb), ptr(ab), ptr(gb),
-                     ptr(dzx), ptr(stats), ptr(ws), None, C.byref(g), st()) == 0
+                     ptr(dzx), ptr(stats), ptr(ws), None, 0, C.byref(g), st()) == 0
     t_f = timeit(run_fused)
     # the launches it replaces
     dy = torch.empty(M, Cout, device=dev)
