@@ -78,10 +78,27 @@ def dominant_kernel_roofline(batch, iters=20):
     assert _lib.fn('dsnt_split_bf16x3')(ptr(w), ptr(planes), w.numel(), stream) == 0
 
     def timed(fn, args):
+        # ISOLATED launches, a millisecond of idle between samples: 20 launches back to back measure the clock droop of the
+        # loop (DVFS: MI355X_MICROARCH.md) as kernel time — 119.9 us against 107.8 us under rocprofv3 for the same launch in
+        # round 3.  HIP events on the stream the kernel runs on; median.
         for _ in range(3):
             assert fn(*args, stream) == 0
+        torch.cuda.synchronize()
+        samples = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*args, stream)
+            e1.record()
+            torch.cuda.synchronize()
+            samples.append(e0.elapsed_time(e1))
+            time.sleep(1e-3)
+        samples.sort()
+        return samples[len(samples) // 2]
+
+    def timed_loop(fn, args):                         # the back-to-back loop of rounds 1-3, reported beside it
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()                                   # HIP events on the stream the kernel runs on
+        e0.record()
         for _ in range(iters):
             fn(*args, stream)
         e1.record()
@@ -116,8 +133,10 @@ def dominant_kernel_roofline(batch, iters=20):
                            dtype=torch.int64).to(dev)
         assert _lib.fn('dsnt_f16_prep_weights')(ptr(tab), 1, stream) == 0
         streamed = 'conv3s' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',') and bool(_lib.fn('dsnt_conv_fwd_stream_ok')(C.byref(g)))
-        ms16 = timed(_lib.fn('dsnt_conv_fwd_f16x3_stream'),
-                     (ptr(x), ptr(stream16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y)) + common + (None, None)) if streamed else ms16h
+        dom = (_lib.fn('dsnt_conv_fwd_f16x3_stream'),
+               (ptr(x), ptr(stream16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y)) + common + (None, None))
+        ms16 = timed(*dom) if streamed else ms16h
+        ms_loop = timed_loop(*dom) if streamed else None
         achieved, peak, ms = flops / (ms16 * 1e-3) / 1e12, PEAK_BF16_MFMA / 3.0, ms16
         twins['bf16x6_kernel'] = {'achieved': round(flops / (ms6 * 1e-3) / 1e12, 2), 'peak': round(PEAK_BF16_MFMA / 6.0, 1),
                                   'us_per_launch': round(ms6 * 1e3, 1)}
@@ -143,11 +162,32 @@ def dominant_kernel_roofline(batch, iters=20):
     }
     if f16 and pmc.get('matrix_pipe_busy_frac') is not None:      # PMC passes of this launch (profiles/): SQ_VALU_MFMA_BUSY_CYCLES
         out['matrix_pipe_busy_frac_pmc'] = pmc['matrix_pipe_busy_frac']
+    out['timing'] = 'median of %d isolated launches (HIP events on the launch stream, 1 ms idle between samples)' % iters
+    if f16 and ms_loop is not None:
+        out['us_per_launch_back_to_back'] = round(ms_loop * 1e3, 1)
+    if pmc.get('us_per_launch_rocprof') is not None:               # the committed kernel trace's average for the same launch
+        out['us_per_launch_rocprof'] = pmc['us_per_launch_rocprof']
+        out['us_per_launch_rocprof_source'] = pmc.get('us_per_launch_rocprof_source')
     out.update(twins)
     return out
 
 
 HBM_PEAK, HBM_COPY_PEAK = 8000.0, 6290.0      # GB/s: spec and measured float4 copy (MI355X_MICROARCH.md)
+# conv-in + conv-out activation elements per image (probed on the reference): the algorithmic HBM volume of
+# a train step is 4 B x 3 x this
+SURVEY_CONV_ELEMS = {'hg1': 36.95e6, 'hg2': 55.93e6, 'hg8': 169.87e6}
+
+
+def measured_step_traffic(workload, batch):
+    """HBM bytes per step as the TCC counters saw them: copied from the committed rocprofv3 --pmc passes of the bare train loop
+    (tools/step_traffic.sh -> profiles/r04_step_traffic*.txt), never measured by this run; None for other workloads / batches."""
+    import re
+    name = {('hg2_js', 32): 'r04_step_traffic.txt', ('hg8_js', 16): 'r04_hg8_b16_step_traffic.txt'}.get((workload, batch))
+    path = os.path.join(ROOT, 'profiles', name) if name else None
+    if not path or not os.path.exists(path):
+        return None
+    mt = re.search(r'=\s*([0-9.]+) GB per step', open(path).read())
+    return {'gbytes': float(mt.group(1)), 'source': 'profiles/%s (FETCH_SIZE x 2 + WRITE_SIZE over every kernel of a step)' % name} if mt else None
 
 
 def family_rooflines(batch, iters=20):
@@ -228,6 +268,35 @@ def family_rooflines(batch, iters=20):
                            1, ptr(g256), None, ptr(stats), C.byref(g), None, None, st))
     res.append(entry('1x1 GEMM 128->256 @64x64 B=%d (fp16x3, BN+ReLU prologue, residual add, statistics)' % batch, us,
                      2.0 * M * 128 * 256, 4.0 * (M * 128 + 2 * M * 256), 'hbm'))
+    # -- the whole backward of conv1 of a Bottleneck (256 -> 128) in one launch: data gradient + BatchNorm-backward sums +
+    #    weight gradient + the folded BatchNorm backward of bn2 (csrc/bwd1.hip); every tensor once
+    from dsnt._lib import BnBwdEpilogue, BnBwdApply
+    g = ConvGeom(batch, H, H, 256, H, H, 128, 1, 1, 1, 0, 1)
+    if _lib.fn('dsnt_conv1x1_bwd_ok')(C.byref(g)):
+        x256 = torch.randn(batch, H, H, 256, device=dev)
+        sc256, sh256 = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev) * 0.1
+        mu256, is256 = torch.randn(256, device=dev) * 0.1, torch.rand(256, device=dev) + 0.5
+        wd = torch.randn(256, 128, device=dev) * 0.05
+        wbd, = bounds(wd)
+        pl = torch.empty(2 * wd.numel(), dtype=torch.float16, device=dev)
+        assert _lib.fn('dsnt_split_f16x2')(ptr(wd), ptr(pl), wd.numel(), wd.numel(), ptr(wbd), st) == 0
+        ab256 = torch.full((64,), float(torch.relu(x256 * sc256 + sh256).max()) * 4.0, device=dev)
+        coef = torch.randn(2, 128, device=dev) * 1e-5
+        gbd = torch.full((64,), float(g128.abs().max()) * 8.0, device=dev)
+        xs = BnBwdEpilogue(ptr(x256), ptr(sc256), ptr(sh256), ptr(mu256), ptr(is256), 1)
+        apn = BnBwdApply(ptr(x128), ptr(sc128), ptr(sh128), ptr(sc128), ptr(coef))
+        nsp = _lib.fn('dsnt_conv1x1_bwd_splits')(C.byref(g), 0)
+        ws = torch.empty(_lib.fn('dsnt_conv1x1_bwd_ws_floats')(C.byref(g), 0), device=dev)
+        part, dzo = torch.empty(nsp, 2, 256, device=dev), torch.empty(batch, H, H, 256, device=dev)
+        b1 = _lib.fn('dsnt_conv1x1_bwd_f16x3')
+        us = timed(lambda: b1(C.byref(xs), ptr(g128), C.byref(apn), ptr(pl), wd.numel(), ptr(wbd), ptr(ab256), ptr(gbd),
+                              ptr(dzo), ptr(part), ptr(ws), None, 0, C.byref(g), st))
+        res.append(entry('one-pass backward of the 1x1 convolution 256->128 @64x64 B=%d (fp16x3: dX + BN-backward sums + dW + '
+                         'folded BN backward of the layer behind)' % batch, us, 2 * 2.0 * M * 128 * 256,
+                         4.0 * (2 * M * 128 + 2 * M * 256), 'hbm',
+                         'replaces bn_act_bwd_apply + the 1x1 data gradient + the 1x1 weight gradient (737 MB in three launches); '
+                         'plus %.1f MB of slabs (one per workgroup)' % (ws.numel() * 4 / 1e6)))
+        del x256, ws, dzo
     # -- BatchNorm-backward apply (hourglass.py:36-43 backward): dx = f(dz, x), 12 B per element
     dz, dx = g128, torch.empty_like(g128)
     mean, invstd, coef = torch.zeros(128, device=dev), torch.ones(128, device=dev), torch.zeros(256, device=dev)
@@ -272,7 +341,7 @@ def _host_cpus():
     return len(usable), (len(cores) or len(usable)), model
 
 
-def cpu_baseline(base, reg, batch=8, timed=5, warm=2):
+def cpu_baseline(base, reg, batch=32, timed=5, warm=2, fallback_batch=8, fallback_above_s=60.0):
     """The CPU oracle on the same workload at a bounded batch (images/sec on the host cores).  BASELINE.md §3:
     physical-core count and CPU model stated, 2 warm-up + >= 5 timed steps, median; on more than 16 logical CPUs the
     thread count is swept first (an oversubscribed intra-op pool is several times slower)."""
@@ -284,6 +353,7 @@ def cpu_baseline(base, reg, batch=8, timed=5, warm=2):
     synthetic.fill_state_dict(m, seed=0)
     m.train()
     opt = torch.optim.RMSprop(m.parameters(), lr=2.5e-4)
+    asked = batch
     x, t, k = synthetic.batch(batch, size=256, seed=1)
 
     def step():
@@ -309,7 +379,14 @@ def cpu_baseline(base, reg, batch=8, timed=5, warm=2):
             sweep[n] = step()
     best_n = min(sweep, key=sweep.get) if sweep else logical
     torch.set_num_threads(best_n)
-    for _ in range(warm):
+    # the configuration's own batch ("bs 32 if memory/time permit else bs 8"): the first warm-up step decides
+    first = step()
+    fell_back = first > fallback_above_s and batch > fallback_batch
+    if fell_back:
+        batch = fallback_batch
+        x, t, k = synthetic.batch(batch, size=256, seed=1)
+        step()
+    for _ in range(warm - 1):
         step()
     times = sorted(step() for _ in range(timed))
     torch.set_num_threads(saved)
@@ -317,9 +394,11 @@ def cpu_baseline(base, reg, batch=8, timed=5, warm=2):
     out = {'value': round(batch / med, 3), 'unit': 'images/sec', 'cores': best_n, 'kind': 'port',
            'physical_cores': physical, 'logical_cpus': logical, 'cpu_model': cpu_model,
            'spread_images_per_sec': [round(batch / times[-1], 3), round(batch / times[0], 3)],
-           'sample': '%s+dsnt reg=%s, batch %d, 256x256, RMSprop train step; %s; %d warm-up + %d timed steps at %d '
+           'batch': batch,
+           'sample': '%s+dsnt reg=%s, batch %d%s, 256x256, RMSprop train step; %s; %d warm-up + %d timed steps at %d '
                      'threads (median); torch %s CPU ops'
-                     % (base, reg, batch, ('thread sweep %s (2 warm-up + 1 timed each)' % cands) if sweep else
+                     % (base, reg, batch, (' (the configuration\'s batch %d took %.0f s per step: fell back)' % (asked, first))
+                        if fell_back else '', ('thread sweep %s (2 warm-up + 1 timed each)' % cands) if sweep else
                         'all %d logical CPUs of this process (no sweep at <= 16)' % logical, warm, timed, best_n,
                         torch.__version__)}
     if sweep:
@@ -462,6 +541,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the parity / head / dominant-kernel legs (profiling)')
     ap.add_argument('--force-dp', action='store_true', help='wire the data-parallel hooks even at world size 1 (testing)')
+    ap.add_argument('--baseline-ips', type=float, default=None,
+                    help='images/sec of the 1-GPU run of the same scaling mode: the line then carries `efficiency` = '
+                         'value / (N x this)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -506,7 +588,10 @@ def main():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29511')
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-        parallel.DataParallel(model, opt)
+        dp = parallel.DataParallel(model, opt)
+        dp.reducer.time_waits = True           # HIP events around the wait for the collectives: `exposed_comm_ms`
+    else:
+        dp = None
 
     def step():
         out = model(x)
@@ -538,6 +623,7 @@ def main():
         elapsed = t.item()
     final_loss = float(loss.item())
     guard.sync()
+    exposed = dp.reducer.exposed_comm_ms() if dp is not None else None
 
     out = None
     if rank == 0:
@@ -575,10 +661,38 @@ def main():
         hbm_ms = step_bytes / (HBM_COPY_PEAK * 1e9) * 1e3
         ms_step = 1e3 * elapsed / args.steps
         out['step_bounds'] = {'gflop_per_step': round(batch * gflop, 1), 'mfma_peak_tflops': round(PEAK_BF16_MFMA / 3.0, 1),
-                              'mfma_ms': round(mfma_ms, 3), 'algorithmic_gbytes_per_step': round(step_bytes / 1e9, 2),
+                              'mfma_ms': round(mfma_ms, 3),
+                              # bytes the launch lists name (every pass the CURRENT design makes counts as algorithmic) ...
+                              'algorithmic_gbytes_per_step': round(step_bytes / 1e9, 2),
                               'hbm_peak_gbs': HBM_COPY_PEAK, 'hbm_ms': round(hbm_ms, 3),
                               'frac_of_max_bound': round(max(mfma_ms, hbm_ms) / ms_step, 4),
                               'frac_of_sum_of_bounds': round((mfma_ms + hbm_ms) / ms_step, 4)}
+        # ... and SURVEY.md 8(d)'s floor, which no design choice moves: 4 B x 3 (forward, data gradient, weight gradient) x
+        # (conv-in + conv-out elements) with BN + ReLU folded into the operand loads and the adds into the epilogues
+        elems = SURVEY_CONV_ELEMS.get(base)
+        if elems:
+            sv = 4.0 * 3.0 * elems * batch
+            sv_ms = sv / (HBM_COPY_PEAK * 1e9) * 1e3
+            out['step_bounds'].update(survey_algorithmic_gbytes=round(sv / 1e9, 2), survey_hbm_ms=round(sv_ms, 3),
+                                      frac_of_survey_hbm_floor=round(sv_ms / ms_step, 4),
+                                      frac_of_max_survey_bound=round(max(mfma_ms, sv_ms) / ms_step, 4))
+        meas = measured_step_traffic(args.workload, batch)
+        if meas:
+            out['step_bounds'].update(measured_gbytes=meas['gbytes'], measured_gbytes_source=meas['source'],
+                                      measured_hbm_ms=round(meas['gbytes'] / HBM_COPY_PEAK * 1e3, 3),
+                                      sustained_tbs_on_measured_bytes=round(meas['gbytes'] / ms_step, 3))
+        if dp is not None:
+            # SURVEY.md 8(d) "DP all-reduce": the communication the step could not hide (device time the publishing stream
+            # waited for the bucket all-reduces after the backward list was enqueued, mean per step, rank 0), RCCL's own
+            # world size, and — against the 1-GPU throughput of the same mode — the scaling efficiency
+            out['dp'] = {'rccl_world': dist.get_world_size() if dist.is_initialized() else 1,
+                         'backend': dist.get_backend() if dist.is_initialized() else None,
+                         'exposed_comm_ms': None if exposed is None else round(exposed, 4),
+                         'gradient_mbytes': round(4e-6 * runner.arena.numel, 1), 'buckets': len(runner.arena.bucket_bounds),
+                         'guard_flag_exchanged': True}
+            if args.baseline_ips:
+                out['dp']['baseline_ips'] = args.baseline_ips
+                out['dp']['efficiency'] = round(ips / (args.baseline_ips * world), 4)      # weak and strong alike: throughput per GPU kept
         if not args.no_extras:
             out['roofline'] = dominant_kernel_roofline(batch)
             out['roofline']['by_time'] = family_rooflines(batch)

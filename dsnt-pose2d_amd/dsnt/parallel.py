@@ -34,10 +34,16 @@ import torch.distributed as dist
 class GradientAllReducer:
     """Bucketed asynchronous sum-all-reduce over contiguous ranges of one flat tensor."""
 
-    def __init__(self, flat, bounds, group=None):
+    def __init__(self, flat, bounds, group=None, flag=None):
         self.flat = flat
         self.bounds = list(bounds)          # [(start, end)] element ranges, one per bucket
         self.group = group
+        # the non-finite guard's device flag (dsnt.guard.NanGuard.flag, int32): exchanged with MAX beside the first bucket of
+        # every backward, so that EVERY rank takes the same skip decision in the optimiser kernels — a NaN loss on one rank
+        # stops the whole job's update, as the reference's single process stops itself (bin/train.py:360-371)
+        self.flag = flag
+        self.exposed_ms = []                # diagnostics (bench.py): host time spent waiting for the collectives, per backward
+        self.time_waits = False
         self.pending = []
         self.fired = set()                  # buckets enqueued since the last wait()
         self.last_late = []                 # buckets of the last backward that no marker announced (diagnostic)
@@ -46,11 +52,14 @@ class GradientAllReducer:
     def bucket_ready(self, k, late=False):
         if k in self.fired:
             return
+        first = not self.fired
         self.fired.add(k)
         if late:
             self.last_late.append(k)
         if self.world == 1:
             return
+        if first and self.flag is not None:
+            self.pending.append(dist.all_reduce(self.flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
         s, e = self.bounds[k]
         if e > s:
             self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
@@ -64,10 +73,29 @@ class GradientAllReducer:
         """Every bucket is reduced when this returns: the ones no marker announced are enqueued here."""
         self.last_late = []
         self.reduce_all(late=True)
-        for w in self.pending:
-            w.wait()
+        if self.time_waits and self.pending and self.flat.is_cuda:
+            # exposed communication: what the publishing stream still has to wait for once backward has been enqueued
+            # (device time between two events around the waits; read by `exposed_comm_ms` after a synchronisation)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for w in self.pending:
+                w.wait()
+            e1.record()
+            self.exposed_ms.append((e0, e1))
+        else:
+            for w in self.pending:
+                w.wait()
         self.pending = []
         self.fired = set()
+
+    def exposed_comm_ms(self):
+        """Mean device time per backward that the publishing stream waited for the collectives (time_waits = True)."""
+        if not self.exposed_ms:
+            return None
+        torch.cuda.synchronize()
+        v = [a.elapsed_time(b) for a, b in self.exposed_ms]
+        self.exposed_ms = []
+        return sum(v) / len(v)
 
 
 def broadcast_flat(flat, src=0, group=None):
@@ -91,7 +119,10 @@ class DataParallel:
         for b in model.buffers():
             if b.dtype.is_floating_point:
                 broadcast_flat(b.data, 0, group)
-        self.reducer = GradientAllReducer(arena.fresh, arena.bucket_bounds, group)
+        # (an optimiser built with guard= hands its flag over: the skip decision is then the same on every rank)
+        guard = getattr(optimizer, 'guard', None)
+        self.reducer = GradientAllReducer(arena.fresh, arena.bucket_bounds, group,
+                                          flag=guard.flag if guard is not None else None)
         self.runner.bucket_hook = self.reducer.bucket_ready
         self.runner.before_publish = self.reducer.wait
         # gradients are published as the MEAN over ranks (works with any optimiser)

@@ -33,6 +33,20 @@ def _worker(rank, world, port, q):
         red.wait()
         want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
         ok_sum = torch.equal(flat, want)
+        # the non-finite guard's flag travels with the first bucket of a backward (MAX): rank 1 saw a NaN loss, rank 0 did
+        # not -> both ranks end with the loss bit up and skip the same update (bin/train.py:360-371 stops its one process)
+        flag = torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32)
+        red3 = parallel.GradientAllReducer(torch.ones(8) * (rank + 1), [(0, 4), (4, 8)], flag=flag)
+        red3.bucket_ready(1)
+        red3.bucket_ready(0)
+        n_pending = len(red3.pending)          # one flag exchange + two buckets
+        red3.wait()
+        ok_sum = ok_sum and flag.tolist() == [1, 0] and n_pending == 3
+        red3.flag.zero_()                      # the next backward exchanges it again, and only once
+        red3.reduce_all()
+        ok_sum = ok_sum and len(red3.pending) == 3
+        red3.wait()
+        ok_sum = ok_sum and flag.tolist() == [0, 0]
         # broadcast rank 0's weights
         w = torch.full((17,), float(rank + 5))
         parallel.broadcast_flat(w, 0)

@@ -78,3 +78,78 @@ def test_two_ranks_average_their_gradients(base, strat, size):
         assert err <= 2e-6, (rank, err)                  # the mean of the shards' gradients (fp32 sum, then * 1/world)
         assert spread > 1e-3, spread                      # ... and the shards really differed
         assert late == [], late                           # every bucket was announced by its marker, none at the wait
+
+
+def _guard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from dsnt.model import build_mpii_pose_model
+    from dsnt import parallel, synthetic, optim
+    from dsnt.guard import NanGuard
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        m = build_mpii_pose_model(base='hg1', output_strat='dsnt', reg='js')
+        synthetic.fill_state_dict(m, seed=0)
+        m.to(dev).train()
+        x, t, k = synthetic.batch(2 * world, size=128, seed=3, mask_p=0.9)
+        sl = slice(2 * rank, 2 * rank + 2)
+        x, t, k = x[sl].to(dev), t[sl].to(dev), k[sl].to(dev)
+        m.hg._runner().ensure(dev)
+        guard = NanGuard(dev)
+        opt = optim.RMSprop(m, lr=2.5e-4, guard=guard)
+        parallel.DataParallel(m, opt)
+
+        def step(poison=None):
+            loss = m.forward_loss(m(x), t, k)
+            if poison is not None:
+                loss = loss * poison
+            guard.check(loss)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+
+        def gathered():
+            mine = m.hg.arena.params.clone()
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            return mine, bool(torch.equal(both[0], both[1]))
+
+        start = m.hg.arena.params.clone()
+        step()
+        after1, same1 = gathered()
+        step(poison=float('nan') if rank == 1 else None)       # ONE rank's loss is NaN
+        after2, same2 = gathered()
+        q.put((rank, same1, not torch.equal(start, after1), same2, bool(torch.equal(after1, after2)), guard.flag.tolist()))
+    except Exception as e:      # noqa: BLE001 — reported to the parent
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_nonfinite_loss_on_one_rank_stops_the_update_on_every_rank():
+    """train.py:360-371 under data parallelism: the guard's device flag is exchanged (MAX) beside the first gradient bucket,
+    so a NaN loss on rank 1 makes BOTH ranks skip the whole optimiser update — their parameters stay bit-identical (a
+    rank-local flag would let rank 0 apply the finite elements of the all-reduced gradient and the replicas diverge)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for r in res:
+        if len(r) == 2 and 'gloo' in r[1].lower() and ('cuda' in r[1].lower() or 'hip' in r[1].lower()):
+            pytest.skip('this torch build has no gloo collectives on device tensors: %s' % r[1])
+        assert len(r) == 6, r
+        rank, same1, moved1, same2, frozen2, flag = r
+        assert same1 and moved1                 # a finite step: both ranks move, identically
+        assert same2 and frozen2, (rank, same2, frozen2)      # the poisoned step: nobody moves
+        assert flag[0] == 1, flag               # the loss bit is up on BOTH ranks

@@ -26,7 +26,7 @@ for i, c in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
 print("HBM traffic per train step (hg2 + DSNT + JS, batch 32) from the TCC counters: FETCH_SIZE x 2 (gfx950 correction, applied to every")
 print("kernel: an upper bound for kernels whose reads are narrower than 16 bytes per lane) and WRITE_SIZE, rocprofv3 --pmc passes of")
 print("tools/train_loop.py %d (+2 warm-up) divided by %d steps; the one-off set-up launches of the first step are included (< 1 %%)." % ($steps, steps))
-print("read %.2f GB + written %.2f GB = %.2f GB per step   (algorithmic, bench.py step_bounds: 36.99 GB)" % (tot["FETCH_SIZE"] / steps / 1e9, tot["WRITE_SIZE"] / steps / 1e9, (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / steps / 1e9))
+print("read %.2f GB + written %.2f GB = %.2f GB per step   (algorithmic: SURVEY 8(d) 21.5 GB = 4 B x 3 x conv in+out elements; launch lists, bench.py step_bounds: see the bench line)" % (tot["FETCH_SIZE"] / steps / 1e9, tot["WRITE_SIZE"] / steps / 1e9, (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / steps / 1e9))
 print("%-62s %8s %8s %8s" % ("kernel", "calls", "read MB", "write MB"))
 for k, v in sorted(per.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:28]:
     print("%-62s %8.1f %8.1f %8.1f" % (k, v[2] / steps, v[0] / steps / 1e6, v[1] / steps / 1e6))
