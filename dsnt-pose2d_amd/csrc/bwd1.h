@@ -5,7 +5,8 @@
 // Plan of one launch.  ok == 0: geometry not supported (or DSNT_OFF=bwd1).
 struct Bwd1Plan {
     int ok;
-    int cfg;            // 0: Cout 128 / Cin 256, 1: Cout 256 / Cin 128, 2: Cout 128 / Cin 128
+    int cfg;            // index into the shape table of bwd1.hip
+    int chunks;         // column chunks (gridDim.y)
     int nstages;        // 32-pixel stages
     int spw;            // stages per workgroup
     int nwg;            // workgroups = slabs ws[nwg][Cout][Cin] (+ [nwg][Cout] bias partials) = rows of the statistics partials
@@ -14,5 +15,5 @@ struct Bwd1Plan {
 Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g, bool share);
 void dsnt_bwd1_launch(const Bwd1Plan& pl, const dsnt_bn_bwd_epilogue* xs, const float* dy, const dsnt_bn_bwd_apply* ap,
                       const void* wd_planes, int64_t plane_stride, const float* w_bound, const float* a_bound,
-                      const float* g_bound, float* dz_out, float* stats, float* ws, float* dz_amax,
+                      const float* g_bound, float* dz_out, float* stats, float* ws, float* dz_amax, int accumulate,
                       const dsnt_conv_geom* g, hipStream_t st);

@@ -30,6 +30,10 @@
 // v_mfma_f32_16x16x32_f16 throughout: 16-column ownership keeps W + dW at 96-128 registers per lane for both shapes
 // (n = 128, c = 256 and n = 256, c = 128).  One barrier per 32 pixels.  HBM-bound: 96 MFMAs per wave and stage are a
 // third of the stage's memory time.
+// Variants of the same body: four-wave workgroups for 64 input channels (the 128 x 128 level), two column chunks on
+// gridDim.y for 256 -> 256 (both read dY, the second from L2: workgroups x and x + gridDim.x share an XCD when gridDim.x
+// is a multiple of 8), and RAW = a convolution whose input is not seen through a BatchNorm (the projection shortcuts
+// hourglass.py:44-48 and the `fc` convolutions :146-153): act(x) = x, dX is written (or accumulated) as it is.
 #include "bwd1.h"
 #include <stdlib.h>
 
@@ -48,11 +52,12 @@ struct Bwd1P {
     int in_relu;
     const float* a_bound;       // >= max |act(x)|
     const unsigned short* wq; long wq_stride; const float* w_bound;     // data-gradient weights [c][n], two fp16 planes
-    float* dzx;                 // [M][CC]
-    float* stats;               // [workgroups][2][CC]
-    float* ws;                  // [workgroups][NN][CC] slabs, then [workgroups][NN] bias partials
+    float* dzx;                 // [M][Cin]: dz (PRO) or dL/dx (RAW; += with `accumulate`)
+    float* stats;               // [workgroups][2][Cin] (PRO)
+    float* ws;                  // [workgroups][NN][Cin] slabs, then [workgroups][NN] bias partials
     unsigned* dzx_amax;         // optional bound slot of |dzx|
-    int M, nstages, spw, nwg;   // 32-pixel stages in all / per workgroup
+    int M, Cin, nstages, spw, nwg;   // 32-pixel stages in all / per workgroup; nwg = gridDim.x = slabs
+    int accumulate;             // RAW: dzx += (the tensor already holds other gradient contributions)
 };
 
 __device__ __forceinline__ f16x8 b1_tr_frag(B1_LDS unsigned char* a0, B1_LDS unsigned char* a1) {
@@ -62,11 +67,13 @@ __device__ __forceinline__ f16x8 b1_tr_frag(B1_LDS unsigned char* a0, B1_LDS uns
     return __builtin_bit_cast(f16x8, v);
 }
 
-// NN = output channels of the convolution (n: the contraction of dX), CW = 16-column tiles per wave (Cin = 128 CW),
-// MODE 0: dY from (dz, y) through the folded BatchNorm backward, 1: dY given
-template <int NN, int CW, int MODE>
-__global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
-    constexpr int CC = 128 * CW;
+// NN = output channels of the convolution (n: the contraction of dX), CW = 16-column tiles per wave, NWV = waves per workgroup
+// (16 CW NWV columns of Cin per workgroup; blockIdx.y = column chunk), MODE 0: dY from (dz, y) through the folded BatchNorm
+// backward, 1: dY given; RAW: x is the operand itself (no BatchNorm in front of the convolution)
+template <int NN, int CW, int NWV, int MODE, bool RAW>
+__global__ __launch_bounds__(64 * NWV, 2) void bwd1_kernel(Bwd1P p) {
+    constexpr int CC = 16 * CW * NWV;           // columns of this workgroup
+    constexpr int NTHR = 64 * NWV;
     constexpr int KS = NN / 32;                 // K-steps of dX
     constexpr int NT = NN / 16;                 // n-tiles of dW
     constexpr int PITCH = NN * 2 + 32;          // bytes per pixel row of one plane (and per column row of the W image)
@@ -74,8 +81,9 @@ __global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
     constexpr int IMG = 2 * PL;
     constexpr int WLO = CC * PITCH;
     constexpr int N4 = NN / 4;                  // float4 units per pixel row
-    constexpr int U = 32 * N4 / 512;            // units per thread and stage
-    constexpr int RSTEP = 512 / N4;             // pixel rows between a thread's units
+    constexpr int U = 32 * N4 / NTHR;           // units per thread and stage
+    constexpr int RSTEP = NTHR / N4;            // pixel rows between a thread's units
+    static_assert(U >= 1 && U * NTHR == 32 * N4, "staging units per thread");
     const unsigned OOB = 0xF0000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char b1_smem[];
     unsigned char* img = b1_smem;                                   // [2 buffers][2 planes][32 pixels][PITCH]
@@ -86,6 +94,8 @@ __global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, lg = lane >> 4;
     const int wg = blockIdx.x;
+    const int col0 = blockIdx.y * CC;           // first column of this workgroup's chunk
+    const int ld = p.Cin;                       // row pitch of x / dzx / the slabs
     const int s0 = wg * p.spw;
     const int s1 = min(p.nstages, s0 + p.spw);
 
@@ -151,43 +161,49 @@ __global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
     issue(R, s0);
 
     // ---- matrix role: this wave's columns
-    const int c0 = wave * 16 * CW;
+    const int c0 = wave * 16 * CW;              // (within the chunk)
     // x in the C layout of a 16 x 16 tile: lane = column lc, register r = pixel row 4 lg + r
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x), 0, (int)((size_t)p.M * CC * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(p.dzx, 0, (int)((size_t)p.M * CC * 4u), 0x00020000);
-    const unsigned xlane = (unsigned)((4 * lg * CC + c0 + lc) * 4);
+        const_cast<float*>(p.x), 0, (int)((size_t)p.M * ld * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(p.dzx, 0, (int)((size_t)p.M * ld * 4u), 0x00020000);
+    const unsigned xlane = (unsigned)((4 * lg * ld + col0 + c0 + lc) * 4);
+    const unsigned stage_x = 32u * (unsigned)ld * 4u;
     float xv[2][CW][4];
+    float pv[RAW ? 2 : 1][CW][4];               // RAW + accumulate: what the gradient tensor holds already
     auto issue_x = [&](const int rt, const int s) {
-        const unsigned sbase = stage_off(s, 32u * CC * 4u) + (unsigned)(16 * rt * CC * 4) + xlane;
+        const unsigned sbase = stage_off(s, stage_x) + (unsigned)(16 * rt * ld * 4) + xlane;
 #pragma unroll
         for (int cw = 0; cw < CW; ++cw)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                xv[rt][cw][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, sbase + (unsigned)(cw * 64), (unsigned)(r * CC * 4), 0));
+            for (int r = 0; r < 4; ++r) {
+                xv[rt][cw][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, sbase + (unsigned)(cw * 64), (unsigned)(r * ld * 4), 0));
+                if (RAW) pv[rt][cw][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    or_, p.accumulate ? sbase + (unsigned)(cw * 64) : OOB, (unsigned)(r * ld * 4), 0));
+            }
     };
     issue_x(0, s0);
     issue_x(1, s0);
 
-    // W: hi plane of this wave's columns in registers, lo plane of all columns in LDS
+    // W: hi plane of this wave's columns in registers, lo plane of the chunk's columns in LDS
     f16x8 whi[KS][CW];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int cw = 0; cw < CW; ++cw)
-            whi[ks][cw] = *reinterpret_cast<const f16x8*>(p.wq + (size_t)(c0 + 16 * cw + lc) * NN + 32 * ks + 8 * lg);
+            whi[ks][cw] = *reinterpret_cast<const f16x8*>(p.wq + (size_t)(col0 + c0 + 16 * cw + lc) * NN + 32 * ks + 8 * lg);
     {
         constexpr int UN = CC * NN / 8;             // 16-byte units of the lo plane
+        static_assert(UN % NTHR == 0, "weight units per thread");
 #pragma unroll
-        for (int j = 0; j < UN / 512; ++j) {
-            const int u = tid + 512 * j;
+        for (int j = 0; j < UN / NTHR; ++j) {
+            const int u = tid + NTHR * j;
             const int c = u / (NN / 8), k8 = u % (NN / 8);
             *reinterpret_cast<uint4*>(wlo + c * PITCH + 16 * k8) =
-                *reinterpret_cast<const uint4*>(p.wq + (size_t)p.wq_stride + (size_t)c * NN + 8 * k8);
+                *reinterpret_cast<const uint4*>(p.wq + (size_t)p.wq_stride + (size_t)(col0 + c) * NN + 8 * k8);
         }
     }
     if (MODE == 0) {
-        for (int k = tid; k < NN; k += 512) {
+        for (int k = tid; k < NN; k += NTHR) {
             vec[k] = p.y_scale[k]; vec[NN + k] = p.y_mean[k]; vec[2 * NN + k] = p.y_invstd[k];
             vec[3 * NN + k] = p.y_coef[k]; vec[4 * NN + k] = p.y_coef[NN + k];
         }
@@ -196,10 +212,11 @@ __global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
     float xsc[CW], xsh[CW], xmu[CW], xis[CW];
 #pragma unroll
     for (int cw = 0; cw < CW; ++cw) {
-        const int c = c0 + 16 * cw + lc;
-        xsc[cw] = p.in_scale[c]; xsh[cw] = p.in_shift[c]; xmu[cw] = p.in_mean[c]; xis[cw] = p.in_invstd[c];
+        const int c = col0 + c0 + 16 * cw + lc;
+        xsc[cw] = RAW ? 1.f : p.in_scale[c]; xsh[cw] = RAW ? 0.f : p.in_shift[c];
+        xmu[cw] = RAW ? 0.f : p.in_mean[c]; xis[cw] = RAW ? 0.f : p.in_invstd[c];
     }
-    const float relu_lo = p.in_relu ? 0.f : -__builtin_inff();
+    const float relu_lo = (!RAW && p.in_relu) ? 0.f : -__builtin_inff();
     __syncthreads();                                // vec is complete
     transform(R, 0, s0 < s1 ? 1.f : 0.f);
     issue(R, s0 + 1);
@@ -253,21 +270,26 @@ __global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
                 }
             }
             // ---- its epilogue: ReLU mask of bn(x), dz out, the BatchNorm-backward sums; act(x) planes for dW
-            const unsigned obase = (unsigned)((s * 32 + 16 * rt) * CC * 4) + xlane;
+            const unsigned obase = (unsigned)(s * 32 + 16 * rt) * (unsigned)ld * 4u + xlane;
 #pragma unroll
             for (int cw = 0; cw < CW; ++cw) {
                 float av[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float xx = xv[rt][cw][r];
-                    const float z = fmaf(xx, xsc[cw], xsh[cw]);
                     float v = acc[cw][r] * osc_x;
-                    if (p.in_relu && z <= 0.f) v = 0.f;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), or_, obase + (unsigned)(cw * 64), (unsigned)(r * CC * 4), 0);
+                    if (RAW) {
+                        v += pv[rt][cw][r];               // (zeros unless accumulate)
+                        av[r] = xx * sa;
+                    } else {
+                        const float z = fmaf(xx, xsc[cw], xsh[cw]);
+                        if (p.in_relu && z <= 0.f) v = 0.f;
+                        s1a[cw] += v;
+                        s2a[cw] = fmaf(v, (xx - xmu[cw]) * xis[cw], s2a[cw]);
+                        av[r] = fmaxf(z, relu_lo) * sa;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), or_, obase + (unsigned)(cw * 64), (unsigned)(r * ld * 4), 0);
                     am = fmaxf(am, fabsf(v));
-                    s1a[cw] += v;
-                    s2a[cw] = fmaf(v, (xx - xmu[cw]) * xis[cw], s2a[cw]);
-                    av[r] = fmaxf(z, relu_lo) * sa;
                 }
                 uint2 q1, q2;
                 split4h(make_float4(av[0], av[1], av[2], av[3]), q1, q2);
@@ -299,28 +321,31 @@ __global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
     stage(s0);
     for (int s = s0 + 1; s < s1; ++s) stage(s);
 
-    // ---- slab of this workgroup: ws[wg][n][c] (D row = n: 4 lg + r of the tile, D column = c: the lane)
-    float* slab = p.ws + (size_t)wg * NN * CC;
+    // ---- slab of this workgroup's pixels: ws[wg][n][c] (D row = n: 4 lg + r of the tile, D column = c: the lane); the column
+    // chunks of one pixel range fill one slab
+    float* slab = p.ws + (size_t)wg * NN * ld;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int cw = 0; cw < CW; ++cw)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                slab[(size_t)(16 * nt + 4 * lg + r) * CC + c0 + 16 * cw + lc] = dw[nt][cw][r] * osc_w;
+                slab[(size_t)(16 * nt + 4 * lg + r) * ld + col0 + c0 + 16 * cw + lc] = dw[nt][cw][r] * osc_w;
     // BatchNorm-backward sums of bn(x): one row per workgroup
+    if (!RAW) {
 #pragma unroll
-    for (int cw = 0; cw < CW; ++cw) {
-        float a = s1a[cw], b = s2a[cw];
-        a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-        a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-        if (lg == 0) {
-            p.stats[((size_t)wg * 2 + 0) * CC + c0 + 16 * cw + lc] = a;
-            p.stats[((size_t)wg * 2 + 1) * CC + c0 + 16 * cw + lc] = b;
+        for (int cw = 0; cw < CW; ++cw) {
+            float a = s1a[cw], b = s2a[cw];
+            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            if (lg == 0) {
+                p.stats[((size_t)wg * 2 + 0) * ld + col0 + c0 + 16 * cw + lc] = a;
+                p.stats[((size_t)wg * 2 + 1) * ld + col0 + c0 + 16 * cw + lc] = b;
+            }
         }
     }
     // bias partial: the RSTEP pixel-threads of a channel group add up through LDS in pixel order (the loop ended on a barrier)
-    {
+    if (blockIdx.y == 0) {
         float4* red = reinterpret_cast<float4*>(b1_smem);
         red[prow * N4 + n4] = bs;
         __syncthreads();
@@ -330,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
                 const float4 v = red[j * N4 + tid];
                 t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
             }
-            *reinterpret_cast<float4*>(p.ws + (size_t)p.nwg * NN * CC + (size_t)wg * NN + 4 * tid) = t;
+            *reinterpret_cast<float4*>(p.ws + (size_t)p.nwg * NN * ld + (size_t)wg * NN + 4 * tid) = t;
         }
     }
     if (p.dzx_amax) amax_commit(am, p.dzx_amax);
@@ -338,6 +363,16 @@ __global__ __launch_bounds__(512, 2) void bwd1_kernel(Bwd1P p) {
 
 // ---------------------------------------------------------------- host side
 static int b1_enabled = -1;
+
+struct B1Cfg { int cout, cin, nn, cw, nwv, chunks; };
+static const B1Cfg b1_cfgs[] = {
+    {128, 256, 128, 2, 8, 1},       // conv1 of a Bottleneck
+    {256, 128, 256, 1, 8, 1},       // conv3, the 128 -> 256 projection shortcut
+    {128, 128, 128, 1, 8, 1},       // conv1 of a 128-wide Bottleneck
+    {64, 64, 64, 1, 4, 1},          // the 128 x 128 level: conv1 ...
+    {128, 64, 128, 1, 4, 1},        // ... conv3 and the projection shortcut
+    {256, 256, 256, 1, 8, 2},       // the `fc` convolutions: two column chunks
+};
 
 Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g, bool share) {
     Bwd1Plan pl;
@@ -349,10 +384,10 @@ Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g, bool share) {
     if (M % 32 != 0 || M < 16384) return pl;
     if ((size_t)M * g->Cin * 4u >= (1ull << 31) || (size_t)M * g->Cout * 4u >= (1ull << 31)) return pl;
     int cfg = -1;
-    if (g->Cout == 128 && g->Cin == 256) cfg = 0;           // conv1 of a Bottleneck
-    else if (g->Cout == 256 && g->Cin == 128) cfg = 1;      // conv3
-    else if (g->Cout == 128 && g->Cin == 128) cfg = 2;      // conv1 of a 128-wide Bottleneck
+    for (int i = 0; i < (int)(sizeof(b1_cfgs) / sizeof(b1_cfgs[0])); ++i)
+        if (g->Cout == b1_cfgs[i].cout && g->Cin == b1_cfgs[i].cin) cfg = i;
     if (cfg < 0) return pl;
+    const B1Cfg& c = b1_cfgs[cfg];
     static int cus = 0;
     if (!cus) {
         hipDeviceProp_t prop;
@@ -361,48 +396,63 @@ Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g, bool share) {
                prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     const int nstages = (int)(M / 32);
-    // share (DSNT_CONV_SHARE_CHIP): the launch runs on a lane beside the dependency chain; a workgroup holds 113-140 KB of a
+    // workgroups that fit the chip at once: one eight-wave workgroup per CU, two four-wave ones; column chunks side by side.
+    // share (DSNT_CONV_SHARE_CHIP): the launch runs on a lane beside the dependency chain; a workgroup holds up to 140 KB of a
     // CU's LDS for the whole launch, so it keeps to half of the CUs (as the streaming 1x1 kernel does: gemm1.hip)
-    int nwg = share ? (cus / 2 > 0 ? cus / 2 : 1) : cus;
+    int nwg = cus * (c.nwv == 4 ? 2 : 1) / c.chunks;
+    if (share) nwg = nwg / 2 > 0 ? nwg / 2 : 1;
+    if (c.chunks > 1) nwg = nwg / 8 * 8 > 0 ? nwg / 8 * 8 : nwg;      // chunk partners on one XCD (speed only)
     if (nwg > nstages) nwg = nstages;
     const int spw = (nstages + nwg - 1) / nwg;
     nwg = (nstages + spw - 1) / spw;                        // no workgroup without a stage
-    const int NN = g->Cout, CC = g->Cin;
-    const int pitch = NN * 2 + 32;
-    pl.ok = 1; pl.cfg = cfg; pl.nstages = nstages; pl.spw = spw; pl.nwg = nwg;
-    pl.lds = 2 * 2 * 32 * pitch + CC * pitch + 5 * NN * 4;
-    if (pl.lds < 512 * 16) pl.lds = 512 * 16;               // the bias reduction's scratch
+    const int pitch = c.nn * 2 + 32;
+    pl.ok = 1; pl.cfg = cfg; pl.nstages = nstages; pl.spw = spw; pl.nwg = nwg; pl.chunks = c.chunks;
+    pl.lds = 2 * 2 * 32 * pitch + 16 * c.cw * c.nwv * pitch + 5 * c.nn * 4;
+    if (pl.lds < 64 * c.nwv * 16) pl.lds = 64 * c.nwv * 16; // the bias reduction's scratch
     return pl;
 }
 
-template <int NN, int CW, int MODE>
+template <int NN, int CW, int NWV, int MODE, bool RAW>
 static void b1_launch_k(const Bwd1Plan& pl, const Bwd1P& p, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)bwd1_kernel<NN, CW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds);
+        hipFuncSetAttribute((const void*)bwd1_kernel<NN, CW, NWV, MODE, RAW>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds);
         attr_done = true;
     }
-    DSNT_LAUNCH((bwd1_kernel<NN, CW, MODE>), dim3(pl.nwg), dim3(512), pl.lds, st, p);
+    DSNT_LAUNCH((bwd1_kernel<NN, CW, NWV, MODE, RAW>), dim3(pl.nwg, pl.chunks), dim3(64 * NWV), pl.lds, st, p);
+}
+
+template <int NN, int CW, int NWV>
+static void b1_launch_cfg(const Bwd1Plan& pl, const Bwd1P& p, bool apply, bool raw, hipStream_t st) {
+    if (raw) b1_launch_k<NN, CW, NWV, 1, true>(pl, p, st);
+    else if (apply) b1_launch_k<NN, CW, NWV, 0, false>(pl, p, st);
+    else b1_launch_k<NN, CW, NWV, 1, false>(pl, p, st);
 }
 
 void dsnt_bwd1_launch(const Bwd1Plan& pl, const dsnt_bn_bwd_epilogue* xs, const float* dy, const dsnt_bn_bwd_apply* ap,
                       const void* wd_planes, int64_t plane_stride, const float* w_bound, const float* a_bound,
-                      const float* g_bound, float* dz_out, float* stats, float* ws, float* dz_amax,
+                      const float* g_bound, float* dz_out, float* stats, float* ws, float* dz_amax, int accumulate,
                       const dsnt_conv_geom* g, hipStream_t st) {
     Bwd1P p;
     memset(&p, 0, sizeof(p));
     p.dz = dy;
     if (ap) { p.yo = ap->y; p.y_scale = ap->scale; p.y_mean = ap->mean; p.y_invstd = ap->invstd; p.y_coef = ap->coef; }
     p.g_bound = g_bound;
+    const bool raw = xs->scale == nullptr;
     p.x = xs->x; p.in_scale = xs->scale; p.in_shift = xs->shift; p.in_mean = xs->mean; p.in_invstd = xs->invstd;
-    p.in_relu = xs->relu;
+    p.in_relu = raw ? 0 : xs->relu;
     p.a_bound = a_bound;
     p.wq = (const unsigned short*)wd_planes; p.wq_stride = plane_stride; p.w_bound = w_bound;
     p.dzx = dz_out; p.stats = stats; p.ws = ws; p.dzx_amax = (unsigned*)dz_amax;
-    p.M = g->N * g->H * g->W; p.nstages = pl.nstages; p.spw = pl.spw; p.nwg = pl.nwg;
-    if (pl.cfg == 0) { if (ap) b1_launch_k<128, 2, 0>(pl, p, st); else b1_launch_k<128, 2, 1>(pl, p, st); }
-    else if (pl.cfg == 1) { if (ap) b1_launch_k<256, 1, 0>(pl, p, st); else b1_launch_k<256, 1, 1>(pl, p, st); }
-    else { if (ap) b1_launch_k<128, 1, 0>(pl, p, st); else b1_launch_k<128, 1, 1>(pl, p, st); }
+    p.M = g->N * g->H * g->W; p.Cin = g->Cin; p.nstages = pl.nstages; p.spw = pl.spw; p.nwg = pl.nwg;
+    p.accumulate = raw ? accumulate : 0;
+    switch (pl.cfg) {
+    case 0: b1_launch_cfg<128, 2, 8>(pl, p, ap != nullptr, raw, st); break;
+    case 1: case 5: b1_launch_cfg<256, 1, 8>(pl, p, ap != nullptr, raw, st); break;
+    case 2: b1_launch_cfg<128, 1, 8>(pl, p, ap != nullptr, raw, st); break;
+    case 3: b1_launch_cfg<64, 1, 4>(pl, p, ap != nullptr, raw, st); break;
+    default: b1_launch_cfg<128, 1, 4>(pl, p, ap != nullptr, raw, st); break;
+    }
 }
 
 extern "C" int dsnt_conv1x1_bwd_ok(const dsnt_conv_geom* g) { return dsnt_bwd1_plan(g, false).ok; }
@@ -416,8 +466,13 @@ extern "C" int dsnt_conv1x1_bwd_f16x3(const dsnt_bn_bwd_epilogue* xs, const floa
                                       const void* wd_planes, int64_t plane_stride, const float* w_bound,
                                       const float* a_bound, const float* g_bound, float* dz_out, float* stats_partial,
                                       float* ws, float* dz_amax, int flags, const dsnt_conv_geom* g, void* stream) {
-    DSNT_REQUIRE(xs && xs->x && xs->scale && xs->shift && xs->mean && xs->invstd && dy && wd_planes && w_bound && a_bound &&
-                 g_bound && dz_out && stats_partial && ws && g, DSNT_ERR_ARG, "dsnt_conv1x1_bwd_f16x3: bad argument");
+    DSNT_REQUIRE(xs && xs->x && dy && wd_planes && w_bound && a_bound && g_bound && dz_out && ws && g, DSNT_ERR_ARG,
+                 "dsnt_conv1x1_bwd_f16x3: bad argument");
+    const bool raw = xs->scale == nullptr;
+    DSNT_REQUIRE(raw ? (!xs->shift && !xs->mean && !xs->invstd && !ap)
+                     : (xs->shift && xs->mean && xs->invstd && stats_partial != nullptr), DSNT_ERR_ARG,
+                 "dsnt_conv1x1_bwd_f16x3: a BatchNorm in front of the convolution needs scale/shift/mean/invstd and stats_partial; "
+                 "without one (scale == NULL) none of them, and no dsnt_bn_bwd_apply");
     DSNT_REQUIRE(!ap || (ap->y && ap->scale && ap->mean && ap->invstd && ap->coef), DSNT_ERR_ARG,
                  "dsnt_conv1x1_bwd_f16x3: incomplete dsnt_bn_bwd_apply");
     const Bwd1Plan pl = dsnt_bwd1_plan(g, (flags & DSNT_CONV_SHARE_CHIP) != 0);
@@ -426,6 +481,6 @@ extern "C" int dsnt_conv1x1_bwd_f16x3(const dsnt_bn_bwd_epilogue* xs, const floa
                  dsnt_aligned16(ws) && (!ap || dsnt_aligned16(ap->y)) && plane_stride % 8 == 0, DSNT_ERR_ALIGN,
                  "dsnt_conv1x1_bwd_f16x3: 16-byte alignment required");
     dsnt_bwd1_launch(pl, xs, dy, ap, wd_planes, plane_stride, w_bound, a_bound, g_bound, dz_out, stats_partial, ws,
-                     dz_amax, g, (hipStream_t)stream);
+                     dz_amax, (flags & 1) != 0, g, (hipStream_t)stream);
     DSNT_CHECK_LAUNCH("dsnt_conv1x1_bwd_f16x3");
 }

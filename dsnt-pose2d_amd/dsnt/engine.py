@@ -897,10 +897,11 @@ class Tape:
             self.dgrad_total += (p.w.numel() + 7) // 8 * 8
         # the whole backward of this convolution as ONE launch (csrc/bwd1.hip): 1x1 behind a train-mode BatchNorm, both
         # operand bounds known on the device
-        fuse1 = bool(self.bwd1 and normed and self.use_f16x3 and self.defer_reduce and slot is not None and p.R == 1 and
-                     p.S == 1 and p.post_reduce is None and self.lib.dsnt_conv1x1_bwd_ok(C.byref(g)))
+        fuse1 = bool(self.bwd1 and (normed or x_amax is not None) and self.use_f16x3 and self.defer_reduce and
+                     slot is not None and p.R == 1 and p.S == 1 and p.post_reduce is None and
+                     self.lib.dsnt_conv1x1_bwd_ok(C.byref(g)))
         # ... and without residual inputs (whose gradient IS dL/dy) it can also take over the BatchNorm backward of its consumer
-        y.fold_ok = fuse1 and res1 is None and res2 is None
+        y.fold_ok = fuse1 and normed and res1 is None and res2 is None
 
         def backward():
             gy = y.grad
@@ -923,14 +924,6 @@ class Tape:
                 wq16 = self.dgrad_planes16[slot:slot + nw]
                 wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
                 self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total, 0, 0])
-                ab = self.f16_bn_bound_bwd(src)
-                # (the BatchNorm in front of THIS convolution may in turn be left to the 1x1 convolution before it)
-                fold = self.fold_ok(src)
-                dz = self.empty(x.M * x.C) if fold else self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
-                dz_amax = self.amax_slot() if fold else None
-                part = self.scratch('bnpart', nsp * 2 * x.C).view(-1)
-                xs = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift), _lib.ptr(src.mean),
-                                   _lib.ptr(src.invstd), 1 if src.relu else 0)
                 if ap is not None:
                     n2 = ap['n']
                     aps = BnBwdApply(_lib.ptr(y.buf), _lib.ptr(n2.scale), _lib.ptr(n2.mean), _lib.ptr(n2.invstd), _lib.ptr(ap['coef']))
@@ -938,13 +931,31 @@ class Tape:
                     y.pending_apply = None
                 else:
                     aps, dy, gb = None, gy, y.grad_amax
-                e = self.b('dsnt_conv1x1_bwd_f16x3', xs, dy, aps, wq16, self.dgrad_total, wbd, ab, gb, dz, part, ws, dz_amax,
-                           shr, g)
+                if normed:
+                    ab = self.f16_bn_bound_bwd(src)
+                    # (the BatchNorm in front of THIS convolution may in turn be left to the 1x1 convolution before it)
+                    fold = self.fold_ok(src)
+                    dz = self.empty(x.M * x.C) if fold else self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
+                    dz_amax = self.amax_slot() if fold else None
+                    part = self.scratch('bnpart', nsp * 2 * x.C).view(-1)
+                    xs = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift), _lib.ptr(src.mean),
+                                       _lib.ptr(src.invstd), 1 if src.relu else 0)
+                    e = self.b('dsnt_conv1x1_bwd_f16x3', xs, dy, aps, wq16, self.dgrad_total, wbd, ab, gb, dz, part, ws,
+                               dz_amax, shr, g)
+                    u = dict(kind='bwd1', name=name, x=x.buf, sc=src.scale, sh=src.shift, relu=1 if src.relu else 0,
+                             a_bound=ab, w=wd, w_bound=wbd)
+                else:
+                    # no BatchNorm in front of it (projection shortcuts, the `fc` convolutions): dL/dx itself is written, or
+                    # added to what x's gradient holds already
+                    ab = x_amax
+                    buf, acc = self.grad_target(x, amax=self.raw_f16)
+                    xs = BnBwdEpilogue(_lib.ptr(x.buf), None, None, None, None, 0)
+                    e = self.b('dsnt_conv1x1_bwd_f16x3', xs, dy, None, wq16, self.dgrad_total, wbd, ab, gb, buf, None, ws,
+                               x.grad_amax, shr | acc, g)
+                    u = dict(kind='bwd1', name=name, x=x.buf, sc=None, sh=None, relu=0, a_bound=ab, w=wd, w_bound=wbd)
                 nb = 4 * (x.buf.numel() + (y.buf.numel() if ap is not None else 0))      # (tensors named inside the structs)
                 self.bytes_bwd += nb
                 self.bytes_by_name['dsnt_conv1x1_bwd_f16x3'] = self.bytes_by_name.get('dsnt_conv1x1_bwd_f16x3', 0) + nb
-                u = dict(kind='bwd1', name=name, x=x.buf, sc=src.scale, sh=src.shift, relu=1 if src.relu else 0, a_bound=ab,
-                         w=wd, w_bound=wbd)
                 if ap is not None:
                     u.update(g_apply=dict(dz=dy, y=y.buf, scale=n2.scale, mean=n2.mean, invstd=n2.invstd, coef=ap['coef']),
                              g_bound=gb)
@@ -953,7 +964,8 @@ class Tape:
                 self.f16_uses.append((e, u))
                 self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
                                              nsp, p.Cout * g.Cin, p.Cout, 0])
-                self._norm_backward(src, dz, reduced=(part, nsp), finalised=False, dz_amax=dz_amax)
+                if normed:
+                    self._norm_backward(src, dz, reduced=(part, nsp), finalised=False, dz_amax=dz_amax)
             else:
                 # parameter gradients (flat arena, overwritten every step)
                 # the weight gradient feeds nothing downstream in backward: run it on its own lane so the

@@ -379,7 +379,11 @@ int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate)
  * (dsnt_f16_prep_weights); a_bound >= max|act(x)|, g_bound >= max|dY| (64-slot bounds; with `ap`:
  * dsnt_bn_bwd_finalize_bound leaves it); dz_amax (may be NULL): raised to max|dz_out|.  flags: DSNT_CONV_SHARE_CHIP = the launch
  * runs on a stream of its own beside other work and keeps to half of the CUs (`splits` / ws size are asked with the same flags).
- * dsnt_conv1x1_bwd_ok(g) != 0: (Cout, Cin) in {(128, 256), (256, 128), (128, 128)}, N*H*W % 32 == 0 and >= 16384. */
+ * A convolution WITHOUT a BatchNorm in front of it (the projection shortcuts hourglass.py:44-48, the `fc` convolutions :146-153):
+ * xs->scale == NULL (then shift / mean / invstd NULL too, ap == NULL, stats_partial unused): act(x) = x, dz_out = dL/dx itself,
+ * added to what dz_out holds when bit 0 of `flags` is set.
+ * dsnt_conv1x1_bwd_ok(g) != 0: (Cout, Cin) in {(128, 256), (256, 128), (128, 128), (64, 64), (128, 64), (256, 256)},
+ * N*H*W % 32 == 0 and >= 16384. */
 typedef struct {
     const float* y;            /* the convolution's own output = the BatchNorm's input, [M][Cout] */
     const float* scale; const float* mean; const float* invstd;   /* [Cout] */

@@ -17,6 +17,9 @@ CASES = [
     (4, 64, 64, 128, 128),     # conv1 of a 128-wide Bottleneck
     (5, 64, 64, 256, 128),     # 640 stages over 214 workgroups: the last one is short
     (16, 32, 32, 128, 256),
+    (2, 128, 128, 64, 64),     # the 128 x 128 level: four-wave workgroups, two per CU
+    (2, 128, 128, 64, 128),
+    (4, 64, 64, 256, 256),     # the `fc` convolutions: two column chunks (gridDim.y) filling one slab
 ]
 
 
@@ -36,7 +39,7 @@ def _reference(x, sc, sh, mu, istd, relu, dy, w):
 
 
 @pytest.mark.parametrize('case', CASES)
-@pytest.mark.parametrize('mode,relu', [('apply', 1), ('given', 1), ('apply', 0)])
+@pytest.mark.parametrize('mode,relu', [('apply', 1), ('given', 1), ('apply', 0), ('raw', 0), ('raw_acc', 0)])
 def test_conv1x1_backward_in_one_pass(case, mode, relu):
     from dsnt import _lib
     from dsnt._lib import ptr, call, ConvGeom, BnBwdEpilogue, BnBwdApply
@@ -53,6 +56,9 @@ def test_conv1x1_backward_in_one_pass(case, mode, relu):
     istd = (1.0 / (x.double().var(0, unbiased=False) + 1e-5).sqrt()).float()
     sc = gamma * istd
     sh = beta - mu * sc
+    raw = mode.startswith('raw')           # no BatchNorm in front of the convolution: act(x) = x, dL/dx written as it is
+    if raw:
+        sc, sh, mu, istd = torch.ones(Cin), torch.zeros(Cin), torch.zeros(Cin), torch.zeros(Cin)
     w = synthetic.tensor(tag + 'w', (Cout, Cin), seed=2) * 0.05
     if mode == 'apply':
         # dY = y_scale (dz - c0 - (y - y_mean) y_invstd c1): the BatchNorm backward of the layer behind, folded in
@@ -80,7 +86,9 @@ def test_conv1x1_backward_in_one_pass(case, mode, relu):
     act_max = (torch.relu(z64) if relu else z64).abs().max().item()
     ab = _bound(act_max * 3.0, dev)
     gb = _bound(dy64.abs().max().item() * 5.0, dev)                  # loose, as the analytic bound of the engine is
-    xs = BnBwdEpilogue(ptr(xd), ptr(scd), ptr(shd), ptr(mud), ptr(isd), relu)
+    xs = BnBwdEpilogue(ptr(xd), None, None, None, None, 0) if raw else BnBwdEpilogue(ptr(xd), ptr(scd), ptr(shd), ptr(mud), ptr(isd), relu)
+    flags = 1 if mode == 'raw_acc' else 0
+    prev = synthetic.tensor(tag + 'pv', (M, Cin), seed=7) * 1e-3 if flags else None
     if mode == 'apply':
         yd, dzd = y.to(dev), dz.to(dev)
         ysd, ymd, yid, cfd = y_scale.to(dev), y_mean.to(dev), y_istd.to(dev), coef.contiguous().to(dev)
@@ -90,15 +98,18 @@ def test_conv1x1_backward_in_one_pass(case, mode, relu):
         dyd, apref = dy.to(dev), None
     splits = _lib.fn('dsnt_conv1x1_bwd_splits')(C.byref(g), 0)
     nws = _lib.fn('dsnt_conv1x1_bwd_ws_floats')(C.byref(g), 0)
-    assert nws == splits * Cout * (Cin + 1) and 0 < splits <= 256
+    assert nws == splits * Cout * (Cin + 1) and 0 < splits <= 512
     ws = torch.full((nws,), float('nan'), device=dev)
     stats = torch.full((splits, 2, Cin), float('nan'), device=dev)
-    dz_out = torch.full((M, Cin), float('nan'), device=dev)
+    dz_out = prev.to(dev) if flags else torch.full((M, Cin), float('nan'), device=dev)
+    if flags:
+        ref_dz = ref_dz + prev.double()
     amax = torch.zeros(64, device=dev)
     call('dsnt_conv1x1_bwd_f16x3', C.byref(xs), ptr(dyd), apref, ptr(planes), wdt.numel(), ptr(wb), ptr(ab), ptr(gb),
-         ptr(dz_out), ptr(stats), ptr(ws), ptr(amax), 0, C.byref(g))
+         ptr(dz_out), None if raw else ptr(stats), ptr(ws), ptr(amax), flags, C.byref(g))
     torch.cuda.synchronize()
-    assert bool(torch.isfinite(ws).all()) and bool(torch.isfinite(stats).all()) and bool(torch.isfinite(dz_out).all())
+    assert bool(torch.isfinite(ws).all()) and bool(torch.isfinite(dz_out).all())
+    assert raw or bool(torch.isfinite(stats).all())
     # data gradient (elements whose pre-activation sits at the kink may take either side)
     got = dz_out.cpu().double()
     sure = (z64.abs() > 1e-5) if relu else torch.ones_like(z64, dtype=torch.bool)
@@ -107,11 +118,12 @@ def test_conv1x1_backward_in_one_pass(case, mode, relu):
     assert e <= 2e-6 * scale, (e, scale)
     assert abs(amax.max().item() - dz_out.abs().max().item()) == 0.0
     # the BatchNorm-backward sums: one partial row per workgroup
-    s = stats.cpu().double().sum(0)
-    unsure1 = ((got.abs() + ref_dz.abs()) * ~sure).sum(0)
-    assert ((s[0] - ref_s1).abs() <= 1e-5 * ref_dz.abs().sum(0) + unsure1 + 1e-12).all()
-    xhat = ((x.double() - mu.double()) * istd.double()).abs()
-    assert ((s[1] - ref_s2).abs() <= 1e-5 * (ref_dz.abs() * xhat).sum(0) + unsure1 * xhat.max() + 1e-12).all()
+    if not raw:
+        s = stats.cpu().double().sum(0)
+        unsure1 = ((got.abs() + ref_dz.abs()) * ~sure).sum(0)
+        assert ((s[0] - ref_s1).abs() <= 1e-5 * ref_dz.abs().sum(0) + unsure1 + 1e-12).all()
+        xhat = ((x.double() - mu.double()) * istd.double()).abs()
+        assert ((s[1] - ref_s2).abs() <= 1e-5 * (ref_dz.abs() * xhat).sum(0) + unsure1 * xhat.max() + 1e-12).all()
     # weight and bias gradient through the table-driven slab reduction
     dw, db = torch.zeros(Cout, Cin, device=dev), torch.zeros(Cout, device=dev)
     table = torch.tensor([[ws.data_ptr(), dw.data_ptr(), db.data_ptr(), splits, Cout * Cin, Cout, 0]],
@@ -122,17 +134,18 @@ def test_conv1x1_backward_in_one_pass(case, mode, relu):
     eb = (db.cpu().double() - ref_db).abs().max().item()
     assert eb <= 3e-6 * max(ref_db.abs().max().item(), dy64.abs().sum(0).max().item() * 1e-2), eb
     # a second launch writes the same bits (fixed summation order, no atomics on the results)
-    ws2, stats2, dz2 = torch.empty_like(ws), torch.empty_like(stats), torch.empty_like(dz_out)
+    ws2, stats2 = torch.empty_like(ws), torch.empty_like(stats)
+    dz2 = prev.to(dev) if flags else torch.empty_like(dz_out)
     call('dsnt_conv1x1_bwd_f16x3', C.byref(xs), ptr(dyd), apref, ptr(planes), wdt.numel(), ptr(wb), ptr(ab), ptr(gb),
-         ptr(dz2), ptr(stats2), ptr(ws2), None, 0, C.byref(g))
-    assert torch.equal(ws, ws2) and torch.equal(stats, stats2) and torch.equal(dz_out, dz2)
+         ptr(dz2), None if raw else ptr(stats2), ptr(ws2), None, flags, C.byref(g))
+    assert torch.equal(ws, ws2) and (raw or torch.equal(stats, stats2)) and torch.equal(dz_out, dz2)
 
 
 def test_conv1x1_backward_refusals():
     from dsnt import _lib
     from dsnt._lib import ConvGeom
     ok = _lib.fn('dsnt_conv1x1_bwd_ok')
-    assert not ok(C.byref(ConvGeom(4, 64, 64, 256, 64, 64, 256, 1, 1, 1, 0, 1)))      # 256 -> 256: not built
+    assert not ok(C.byref(ConvGeom(4, 64, 64, 256, 64, 64, 16, 1, 1, 1, 0, 1)))       # 256 -> 16 (score): not built
     assert not ok(C.byref(ConvGeom(4, 64, 64, 128, 64, 64, 128, 3, 3, 1, 1, 1)))      # 3x3
     assert not ok(C.byref(ConvGeom(2, 16, 16, 256, 16, 16, 128, 1, 1, 1, 0, 1)))      # 512 rows
     g = ConvGeom(2, 16, 16, 256, 16, 16, 128, 1, 1, 1, 0, 1)

@@ -60,7 +60,7 @@ def test_backward_list_lanes_and_fusions(tape):
     on_lane2 = [x for x in wg if x[1] == 2]
     # DSNT_WGRAD_SHARE_CHIP in `accumulate` — except on the network's first convolution: no data gradient follows it, its
     # weight gradient is the LAST launch of backward and has the chip to itself
-    assert len(on_lane2) >= 20 and all(x[2][8] == 2 for x in on_lane2[:-1]) and on_lane2[-1][2][8] == 0
+    assert len(on_lane2) >= 14 and all(x[2][8] == 2 for x in on_lane2[:-1]) and on_lane2[-1][2][8] == 0
     assert wg[-1] is on_lane2[-1]
     assert all(x[2][8] == 0 for x in wg if x[1] != 2)
     # slab reductions, grouped small weight gradients and the gradient-bucket markers live on the weight-gradient lane
@@ -83,9 +83,11 @@ def test_one_pass_backward_of_the_1x1_convolutions(tape):
     bwd = _launches(tape.bwd)
     fused = [(lane, a) for n, lane, a in bwd if n == 'dsnt_conv1x1_bwd_f16x3']
     folded = [a for _, a in fused if a[2] is not None]
-    assert len(fused) == 24 and len(folded) == 12
+    assert len(fused) == 31 and len(folded) == 13
+    # ... four of them without a BatchNorm in front (two projection shortcuts, two `fc`): dL/dx written as it is, no statistics
+    assert sum(1 for _, a in fused if a[9] is None) == 4
     assert sum(1 for n, _, _ in bwd if n == 'dsnt_bn_bwd_finalize_bound') == len(folded)
-    assert all((a[12] == 2) == (lane != 0) for lane, a in fused)
+    assert all(((a[12] & 2) == 2) == (lane != 0) for lane, a in fused)
     assert {lane for lane, _ in fused} == {0, 1, 3}
     # the dz a folded launch reads is private (it outlives the launches of the op that wrote it) and its bound slot differs per layer
     assert len({a[1].value for a in folded}) == len(folded) and len({a[7].value for a in folded}) == len(folded)
