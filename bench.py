@@ -131,7 +131,7 @@ def dominant_kernel_roofline(batch, iters=20):
         stream16 = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
         tab = torch.tensor([[w.data_ptr(), stream16.data_ptr(), wb.data_ptr(), w.numel(), w.numel(), 128, 128]],
                            dtype=torch.int64).to(dev)
-        assert _lib.fn('dsnt_f16_prep_weights')(ptr(tab), 1, stream) == 0
+        assert _lib.fn('dsnt_f16_prep_weights')(ptr(tab), 1, 7, stream) == 0
         streamed = 'conv3s' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',') and bool(_lib.fn('dsnt_conv_fwd_stream_ok')(C.byref(g)))
         dom = (_lib.fn('dsnt_conv_fwd_f16x3_stream'),
                (ptr(x), ptr(stream16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y)) + common + (None, None))

@@ -1634,14 +1634,15 @@ extern "C" int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t 
 // long as its largest row — 130 us for a 3x3 128->128 filter with 256 threads and one load in flight, and proportionally longer
 // on hg8, where the stem convolution no longer covers it.)
 #define PREP_T 1024
-__global__ __launch_bounds__(PREP_T) void f16_prep_weights_kernel(const long long* __restrict__ table) {
+__global__ __launch_bounds__(PREP_T) void f16_prep_weights_kernel(const long long* __restrict__ table, int row_ints) {
     __shared__ float red[PREP_T / 64];
-    const long long* t = table + (size_t)blockIdx.x * 7;
+    const long long* t = table + (size_t)blockIdx.x * row_ints;
     const float4* src = reinterpret_cast<const float4*>(t[0]);
     uint2* dst = reinterpret_cast<uint2*>(t[1]);
     float* bound = reinterpret_cast<float*>(t[2]);
     const long n4 = (long)t[3] / 4, stride4 = (long)t[4] / 4;
-    const int s_cout = (int)t[5], s_cin = (int)t[6];       // > 0: OHWI [Cout][9][Cin] -> stream order [Cin/16][9][Cout][16]
+    // > 0: OHWI [Cout][9][Cin] -> stream order [Cin/16][9][Cout][16] (rows of 5 values: always the plain layout)
+    const int s_cout = row_ints >= 7 ? (int)t[5] : 0, s_cin = row_ints >= 7 ? (int)t[6] : 0;
     const int s_k4 = 9 * s_cin / 4, s_cin4 = s_cin / 4;
     float m = 0.f;
     long i = threadIdx.x;
@@ -1678,9 +1679,12 @@ __global__ __launch_bounds__(PREP_T) void f16_prep_weights_kernel(const long lon
     for (; i < n4; i += PREP_T) put(i, src[i]);
 }
 
-extern "C" int dsnt_f16_prep_weights(const int64_t* table, int rows, void* stream) {
-    DSNT_REQUIRE(table && rows > 0, DSNT_ERR_ARG, "dsnt_f16_prep_weights: bad argument");
-    DSNT_LAUNCH(f16_prep_weights_kernel, dim3(rows), dim3(PREP_T), 0, (hipStream_t)stream, (const long long*)table);
+// (the table's row width is an argument: the first form of this entry point read five values per row, and a caller's
+// five-wide table must not be walked with a stride of seven)
+extern "C" int dsnt_f16_prep_weights(const int64_t* table, int rows, int row_ints, void* stream) {
+    DSNT_REQUIRE(table && rows > 0 && (row_ints == 5 || row_ints == 7), DSNT_ERR_ARG,
+                 "dsnt_f16_prep_weights: bad argument (row_ints is 5: plain layout only, or 7: with the stream-layout columns)");
+    DSNT_LAUNCH(f16_prep_weights_kernel, dim3(rows), dim3(PREP_T), 0, (hipStream_t)stream, (const long long*)table, row_ints);
     DSNT_CHECK_LAUNCH("dsnt_f16_prep_weights");
 }
 

@@ -106,7 +106,7 @@ SIGNATURES = {
     'dsnt_conv_fwd_f16x3_stream': [P, P, L, P, P, P, P, P, P, I, P, P, P, GP, BP, TP, P],
     'dsnt_amax': [P, L, P, P],
     'dsnt_split_f16x2': [P, P, L, L, P, P],
-    'dsnt_f16_prep_weights': [P, I, P],
+    'dsnt_f16_prep_weights': [P, I, I, P],
     'dsnt_f16_prep_bn_bounds': [P, I, P],
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_bf16x6': [P, P, P, I, P, P, P, P, I, GP, P],

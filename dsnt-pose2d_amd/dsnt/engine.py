@@ -79,7 +79,7 @@ class BnParams:
 
 class Normed:
     """x seen through a BatchNorm(+ReLU): what a fused conv prologue needs."""
-    __slots__ = ('x', 'bn', 'mean', 'invstd', 'scale', 'shift', 'relu', 'abound', 'pending')
+    __slots__ = ('x', 'bn', 'mean', 'invstd', 'scale', 'shift', 'relu', 'abound', 'pending', 'lane')
 
 
 class Tape:
@@ -319,7 +319,7 @@ class Tape:
         return n.abound
 
     # launches that read weight planes or operand bounds: the preparation must have finished before the first of them
-    _PREP_CONSUMERS = ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_bf16x6_ex', 'dsnt_conv_fwd_bf16x6')
+    _PREP_CONSUMERS = ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_f16x3_stream', 'dsnt_conv_fwd_bf16x6_ex', 'dsnt_conv_fwd_bf16x6')
 
     def emit_f16_prep(self, pos, head=()):
         """Insert the per-step preparation launches at position `pos` of the forward list: fp16x3 weight planes and BN
@@ -336,7 +336,7 @@ class Tape:
         if self._f16_w_rows:
             t = torch.tensor(self._f16_w_rows, dtype=torch.int64).to(self.device)
             self._keep.append(t)
-            self.f('dsnt_f16_prep_weights', t, len(self._f16_w_rows))
+            self.f('dsnt_f16_prep_weights', t, len(self._f16_w_rows), 7)
         if self._f16_bn_rows:
             t = torch.tensor(self._f16_bn_rows, dtype=torch.int64).to(self.device)
             self._keep.append(t)
@@ -350,7 +350,7 @@ class Tape:
         if self._f16_dw_rows:
             t = torch.tensor(self._f16_dw_rows, dtype=torch.int64).to(self.device)
             self._keep.append(t)
-            self.f('dsnt_f16_prep_weights', t, len(self._f16_dw_rows))
+            self.f('dsnt_f16_prep_weights', t, len(self._f16_dw_rows), 7)
         self.lane = 0
         if self._famax_used:
             self.f('dsnt_fill_zero', self._famax_buf, self._famax_used)
@@ -719,6 +719,7 @@ class Tape:
         n.abound = None
         n.mean, n.invstd, n.scale, n.shift = (self.empty(bn.C) for _ in range(4))
         n.pending = None
+        n.lane = self.lane      # the lane whose launches write scale / shift: every consumer must run there (`check_lane`)
         if self.training:
             part, tiles = self.ensure_stats(x)
             tl = x.stats_tail
@@ -743,8 +744,19 @@ class Tape:
                                        bn.C, bits])
         return n
 
+    def check_lane(self, n):
+        """A consumer of Normed n is about to be emitted on the current lane.  The vectors of n are written by launches of ONE
+        lane (the finalise launch at `norm` time, or — deferred — the first consumer's prologue / `materialize`), and nothing
+        orders another lane's reader behind them: a second consumer elsewhere would race silently."""
+        if n.pending is not None:
+            n.lane = self.lane              # this consumer finalises it, here
+        elif n.lane != self.lane:
+            raise RuntimeError('dsnt: BatchNorm vectors finalised on lane %d are read on lane %d without a synchronisation '
+                               '(trace norm() and its consumers on one lane, or sync the lanes)' % (n.lane, self.lane))
+
     def materialize(self, n):
         """The separate finalise launch of a BatchNorm whose finalisation was left to its consumer (`norm`)."""
+        self.check_lane(n)
         if n.pending is not None:
             part, tiles = n.pending
             n.pending = None
@@ -838,6 +850,8 @@ class Tape:
         sc = src.scale if normed else None
         sh = src.shift if normed else None
         relu = 1 if (normed and src.relu) else 0
+        if normed:
+            self.check_lane(src)
         part, tail = None, None
         use6 = self._use6(g) and p.wq is not None
         if want_stats and self.training:

@@ -84,6 +84,10 @@ class _FlatOptimizer(torch.optim.Optimizer):
         for g in self.param_groups:
             pg = {k: v for k, v in g.items() if k != 'params'}
             pg['params'] = list(range(len(g['params'])))
+            # which order the indices follow: 'model' = model.parameters() (torch.optim's own numbering).  Revisions before
+            # round 3 numbered them in the arena's slot order (bucket by bucket) and wrote no marker: such a checkpoint is
+            # refused on load, because a permutation of equal-shaped parameters (hg stack 0 / stack 1) cannot be detected
+            pg['dsnt_order'] = 'model'
             groups.append(pg)
         return {'state': state, 'param_groups': groups}
 
@@ -91,8 +95,26 @@ class _FlatOptimizer(torch.optim.Optimizer):
         groups = state_dict['param_groups']
         if len(groups) != 1 or len(groups[0]['params']) != len(self._where):
             raise ValueError('dsnt.optim: loaded state dict has a different number of parameters')
+        # Index order.  'model' (what this class writes) and NO marker (what torch.optim writes: bin/train.py:364,492 checkpoints
+        # optimizer.state_dict()) both mean model.parameters() order.  A checkpoint of a dsnt.optim revision before round 3
+        # numbered the parameters in ARENA order and carries no marker either — it cannot be told from torch's, so it has to be
+        # re-tagged by hand (param_groups[0]['dsnt_order'] = 'arena') and is then re-numbered here; anything else is refused.
+        order = groups[0].get('dsnt_order', 'model')
+        if order == 'arena':
+            pos = {name: i for i, (name, _, _, _) in enumerate(self.runner.arena.slots)}
+            st, remap = state_dict['state'], {}
+            n_arena = len(pos)
+            extra_seen = 0
+            for i, (kind, key) in enumerate(self._where):
+                j = pos[key] if kind == 'arena' else n_arena + key      # (arena order listed the out-of-arena parameters last)
+                e = st.get(j, st.get(str(j)))
+                if e is not None:
+                    remap[i] = e
+            state_dict = {'state': remap, 'param_groups': groups}
+        elif order != 'model':
+            raise ValueError("dsnt.optim: unknown parameter order %r in the loaded state (expected 'model' or 'arena')" % (order,))
         for k, v in groups[0].items():
-            if k != 'params':
+            if k not in ('params', 'dsnt_order'):
                 self.param_groups[0][k] = v
         st = state_dict['state']
         steps = 0

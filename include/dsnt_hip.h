@@ -280,13 +280,13 @@ int dsnt_conv_fwd_stream_ok(const dsnt_conv_geom* g);
 int dsnt_amax(const float* src, int64_t n, float* out, void* stream);
 int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t plane_stride, const float* bound, void* stream);
 /* The same for many tensors per launch (device tables of int64 rows):
- * dsnt_f16_prep_weights: row {src float*, dst fp16 plane-0*, bound float*, count (% 4 == 0), plane stride (elements),
- *   stream Cout, stream Cin}: bound = max|src|, dst = the two fp16 planes of src * pow2(bound) — every conv's weights once
+ * dsnt_f16_prep_weights: row of `row_ints` values {src float*, dst fp16 plane-0*, bound float*, count (% 4 == 0), plane stride
+ *   (elements), stream Cout, stream Cin} (row_ints == 5: the last two are absent and read as 0; dsnt_version() >= 110): bound = max|src|, dst = the two fp16 planes of src * pow2(bound) — every conv's weights once
  *   per step; stream Cout > 0: src is an OHWI 3x3 filter [Cout][3][3][Cin] (Cin % 16 == 0) and each plane is written in
  *   STREAM order [Cin / 16][9 taps][Cout][16] for dsnt_conv_fwd_f16x3_stream (0, 0: element order kept);
  * dsnt_f16_prep_bn_bounds: row {gamma float*, beta float*, out float*, C, bits of float sqrt(M)}:
  *   out = max_c(|gamma_c| sqrt(M) + |beta_c|), an upper bound of |relu?(bn(x))| for a TRAIN-mode BatchNorm over M samples. */
-int dsnt_f16_prep_weights(const int64_t* table, int rows, void* stream);
+int dsnt_f16_prep_weights(const int64_t* table, int rows, int row_ints, void* stream);   /* row_ints: 7, or 5 (no stream columns) */
 int dsnt_f16_prep_bn_bounds(const int64_t* table, int rows, void* stream);
 
 /* Re-pack OHWI weights for the data-gradient pass: wd[Cin][R][S][Cout] with taps flipped,

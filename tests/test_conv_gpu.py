@@ -694,7 +694,7 @@ def test_f16x3_preparation_launches():
         rows.append([w.data_ptr(), planes.data_ptr(), bound.data_ptr(), w.numel(), w.numel(), 0, 0])
         outs.append(planes); bounds.append(bound)
     table = torch.tensor(rows, dtype=torch.int64).to(dev)
-    call('dsnt_f16_prep_weights', ptr(table), len(rows))
+    call('dsnt_f16_prep_weights', ptr(table), len(rows), 7)
     for w, planes, bound in zip(ws, outs, bounds):
         assert bool((bound == w.abs().max()).all())
         ref_b = torch.zeros(64, device=dev)
@@ -774,7 +774,7 @@ def test_conv3_stream_kernel(case, mode):
     wb, wb2 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
     table = torch.tensor([[wd.data_ptr(), plain.data_ptr(), wb.data_ptr(), n, n, 0, 0],
                           [wd.data_ptr(), strm.data_ptr(), wb2.data_ptr(), n, n, Cout, Cin]], dtype=torch.int64).to(dev)
-    call('dsnt_f16_prep_weights', ptr(table), 2)
+    call('dsnt_f16_prep_weights', ptr(table), 2, 7)
     assert torch.equal(wb, wb2)
     want = plain.view(2, Cout, 9, Cin // 16, 16).permute(0, 3, 2, 1, 4).contiguous().view(-1)
     assert torch.equal(want.view(torch.int16), strm.view(torch.int16))

@@ -489,6 +489,20 @@ def test_optimiser_state_interoperates_with_torch_optim_on_hg2():
     bad = {'state': {0: {'step': torch.tensor(1.0), 'square_avg': torch.zeros(3)}}, 'param_groups': sd['param_groups']}
     with pytest.raises(ValueError):
         opt2.load_state_dict(bad)
+    # the order marker: what this class writes says so; a checkpoint re-tagged as ARENA order (what revisions before the
+    # model-order numbering wrote, without a marker) is re-numbered on load — the permutation swaps equal-shaped parameters
+    # of stack 0 and stack 1, which no shape check could catch; an unknown marker is refused
+    assert sd['param_groups'][0]['dsnt_order'] == 'model' and 'dsnt_order' not in opt.param_groups[0]
+    name_of = {id(p): name for name, p, _, _ in arena.slots}
+    slot_pos = {name: i for i, (name, _, _, _) in enumerate(arena.slots)}
+    old = {'state': {slot_pos[name_of[id(p)]]: sd['state'][i] for i, p in enumerate(params)},
+           'param_groups': [dict(sd['param_groups'][0], dsnt_order='arena')]}
+    opt3 = optim.RMSprop(m, lr=1.0)
+    opt3.load_state_dict(old)
+    assert torch.equal(opt3.flat_state, opt.flat_state) or all(
+        torch.equal(arena.logical(opt3.flat_state, by_id[id(p)]), sd['state'][i]['square_avg']) for i, p in enumerate(params))
+    with pytest.raises(ValueError, match='unknown parameter order'):
+        opt3.load_state_dict({'state': sd['state'], 'param_groups': [dict(sd['param_groups'][0], dsnt_order='bucket')]})
 
 
 def test_data_parallel_world1_nccl():

@@ -48,6 +48,12 @@ def test_forward_list_preparation_runs_beside_the_stem(tape):
     before = [e[2] for e in fwd[:first_sync] if e[3] == 0 and e[0] is not None]
     assert before[:5] == ['dsnt_fill_zero', 'dsnt_s2d_input', 'dsnt_s2d_weights_prep', 'dsnt_conv_fwd_f16x3_ex', 'dsnt_bn_finalize']
     assert 'dsnt_bn_act_fwd_stats' in before and before.count('dsnt_conv_fwd_f16x3_ex') == 1
+    # ... and that wait comes before the first launch that reads ANY prepared plane or bound, the stream-layout 3x3 kernel included
+    readers = ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_f16x3_stream', 'dsnt_conv_fwd_bf16x6_ex', 'dsnt_conv_fwd_bf16x6')
+    first_reader = next(i for i, e in enumerate(fwd) if e[2] in readers and id(e) not in tape._prep_exempt)
+    assert first_sync < first_reader
+    first_stream = next(i for i, e in enumerate(fwd) if e[2] == 'dsnt_conv_fwd_f16x3_stream')
+    assert first_sync < first_stream and 'dsnt_conv_fwd_f16x3_stream' in tape._PREP_CONSUMERS
     assert 'dsnt_nchw_to_nhwc' not in [e[2] for e in fwd]         # the NHWC copy of the image is gone
     assert {e[3] for e in fwd if e[0] is not None} == {0, 1, 3}     # two side lanes for the skip branches
 

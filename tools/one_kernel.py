@@ -28,7 +28,7 @@ ab.fill_(float(torch.relu(x * sc + sh).max()) * 4.0)
 planes16s = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
 if k == 3 and _lib.fn('dsnt_conv_fwd_stream_ok')(C.byref(g)):
     tab = torch.tensor([[w.data_ptr(), planes16s.data_ptr(), wb.data_ptr(), w.numel(), w.numel(), Cout, Cin]], dtype=torch.int64).to(dev)
-    _lib.fn('dsnt_f16_prep_weights')(ptr(tab), 1, st)
+    _lib.fn('dsnt_f16_prep_weights')(ptr(tab), 1, 7, st)
 reps = int(os.environ.get('ONE_KERNEL_REPS', '5'))
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
 for it in range(reps):
