@@ -310,22 +310,37 @@ def test_gradient_with_respect_to_the_input_image(base):
 
 def test_hg8_every_gradient_vs_oracle_on_the_smooth_network():
     """hg8 + DSNT + JS (BASELINE config 5's model; batch 2, 128 px) against the CPU oracle: coordinates of all eight
-    stacks within 1e-4, the loss, and — with the ReLUs taken out on both sides, so that no mask bit can flip — every
-    one of its parameter gradients to 5e-3 relative L2 and the flat gradient's cosine >= 1 - 1e-7.
-    (The smooth eight-stack network is an un-clipped amplifier: against the oracle in fp64 the fp32 oracle itself sits at
-    1.5e-4 .. 2.5e-4 depending on its thread count, this path at 1.3e-4 .. 2.7e-3 — adding the four per-wave partial sums of
-    ONE layer's BatchNorm statistic in the opposite order, a one-ulp change, moves the worst parameter, a BatchNorm bias whose
-    gradient norm sits at the floor, from one end of that range to the other: tools/diag_hg8_oracle.py, DESIGN.md "round 3".)"""
+    stacks within 1e-4, the loss, and — with the ReLUs taken out on both sides — every one of its 1464 parameter gradients
+    against the oracle IN FP64, held to an envelope the oracle draws itself (the fp32 oracle's own distance from the fp64
+    oracle, parameter by parameter) instead of one constant:
+      * the bulk: the MEDIAN of (this path's distance / the fp32 oracle's distance) <= 2.5 (measured 1.2 - 1.3 on all three
+        matrix-core paths) — a 2x loss of accuracy anywhere in the common path fails here, which a constant bar set by the
+        worst parameter (5e-3 in round 3) would hide;
+      * >= 80 % of the parameters within max(2e-4, 16 x the fp32 oracle's distance);
+      * every parameter <= 5e-3 and the flat gradient's cosine >= 1 - 1e-7.
+    Why not the envelope for ALL parameters: the network is not smooth even without its ReLUs.  Its max-pools route the
+    gradient by arg-max, and the fp64 forward of this input has 2x2 windows whose two largest values differ by 2.5e-7 ..
+    4.5e-7 of the tensor's scale in stack 2 (pools 9 and 11: tools/diag_hg8_envelope.py prints them) — any fp32 evaluation
+    whose rounding differs from torch-CPU's may take the other pixel.  The parameters behind such a window then sit at
+    1e-3 .. 2.7e-3 on the fp32-MFMA and fp16x3 paths ALIKE (same quantiles to three digits, whatever the switches:
+    finalisation, lanes, reduction order) and at <= 4.2e-4 on the bf16x6 path, whose products carry 6e-9 instead of 1e-7
+    and stay on the oracle's side of every tie.  (Round 3 read this as a "chaotic amplifier"; it is an arg-max flip.)"""
     from dsnt.model import build_mpii_pose_model
     from dsnt_oracle import model as omodel
+    K, FLOOR = 16.0, 2e-4
     with _NoRelu():
         m = build_mpii_pose_model(base='hg8', output_strat='dsnt', reg='js')
         o = omodel.build_mpii_pose_model(base='hg8', output_strat='dsnt', reg='js')
+        o64 = omodel.build_mpii_pose_model(base='hg8', output_strat='dsnt', reg='js')
         _NoRelu.strip(o)
+        _NoRelu.strip(o64)
         synthetic.fill_state_dict(m, seed=3)
         synthetic.fill_state_dict(o, seed=3)
+        synthetic.fill_state_dict(o64, seed=3)
+        o64.double()
         m.cuda().train()
         o.train()
+        o64.train()
         x, target, mask = synthetic.batch(2, size=128, seed=2, mask_p=0.8)
         outs = m(x.to(DEV))
         loss = m.forward_loss(outs, target.to(DEV), mask.to(DEV))
@@ -333,17 +348,30 @@ def test_hg8_every_gradient_vs_oracle_on_the_smooth_network():
         outs_o = o(x)
         loss_o = o.forward_loss(outs_o, target, mask)
         loss_o.backward()
+        o64.forward_loss(o64(x.double()), target.double(), mask.double()).backward()
     assert len(outs) == 8 and len(outs_o) == 8
     for a, b in zip(outs, outs_o):
         assert (a.detach().cpu() - b.detach()).abs().max().item() <= 1e-4
     assert abs(loss.item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
-    pm, po = dict(m.named_parameters()), dict(o.named_parameters())
-    assert list(pm) == list(po)
-    worst = _grads_close(m, o, 5e-3, 'hg8')
+    pm, po, p64 = dict(m.named_parameters()), dict(o.named_parameters()), dict(o64.named_parameters())
+    assert list(pm) == list(po) == list(p64)
+    floor = 1e-3 * max(q.grad.norm().item() for q in p64.values())
+    ratios, inside, worst_abs = [], 0, 0.0
+    for n in pm:
+        e_hip = _rel_l2(pm[n].grad.cpu(), p64[n].grad, floor)
+        e_o32 = _rel_l2(po[n].grad, p64[n].grad, floor)
+        ratios.append(e_hip / max(e_o32, 1e-9))
+        inside += e_hip <= max(FLOOR, K * e_o32)
+        worst_abs = max(worst_abs, e_hip)
+    ratios.sort()
+    worst_ratio = ratios[-1]
+    assert ratios[len(ratios) // 2] <= 2.5, ratios[len(ratios) // 2]
+    assert inside >= 0.8 * len(pm), (inside, len(pm))
+    assert worst_abs <= 5e-3, worst_abs
     flat_m = torch.cat([p.grad.cpu().reshape(-1) for p in pm.values()]).double()
-    flat_o = torch.cat([p.grad.reshape(-1) for p in po.values()]).double()
+    flat_o = torch.cat([p.grad.reshape(-1) for p in p64.values()]).double()
     cos = (flat_m @ flat_o / (flat_m.norm() * flat_o.norm())).item()
-    assert cos >= 1 - 1e-7, (cos, worst)
+    assert cos >= 1 - 1e-7, (cos, worst_abs, worst_ratio)
 
 
 @pytest.mark.parametrize('kind', ['rmsprop', 'sgd'])
