@@ -164,6 +164,7 @@ class Program:
     def __init__(self, root, arena, in_shape, training, input_grad):
         self.training = training
         self.token = 0
+        self.in_flight = False      # a forward of this program is waiting for its backward (hourglass._Run)
         dev = arena.device
         tape = Tape(dev, training)
         tape.want_input_grad = bool(input_grad and training)     # the stem then keeps its data gradient (no space-to-depth form)
@@ -236,10 +237,20 @@ class Program:
 class _Run(Function):
     @staticmethod
     def forward(ctx, runner, prog, x, *params):
+        import weakref
         prog.in_nchw.copy_(x)
         prog.token += 1
         prog.tape.run(prog.tape.fwd, probe=runner.probe)
         ctx.runner, ctx.prog, ctx.token, ctx.nparams = runner, prog, prog.token, len(params)
+        # this program's saved activations belong to this forward until its backward has run — or until autograd drops the
+        # graph (the caller let go of the outputs): a second forward of the same shape meanwhile takes another program
+        prog.in_flight = True
+        token = prog.token
+
+        def release(p=prog, t=token):
+            if p.token == t:
+                p.in_flight = False
+        weakref.finalize(ctx, release)
         return tuple(o.clone() for o in prog.outs)
 
     @staticmethod
@@ -260,12 +271,14 @@ class _Run(Function):
         if runner.before_publish is not None:
             runner.before_publish()
         runner.arena.publish_grads(runner.params)
+        prog.in_flight = False                 # (a second backward through the same graph re-reads the same activations: allowed)
         gx = prog.gx.clone() if prog.input_grad else None
         return (None, None, gx) + (None,) * ctx.nparams
 
 
 class Runner:
     """Owns the arena and the traced programs of one root module."""
+    MAX_IN_FLIGHT = 4       # forwards of one shape that may wait for their backward at the same time
 
     def __init__(self, root):
         self.root = root
@@ -300,6 +313,18 @@ class Runner:
         grad_mode = torch.is_grad_enabled()
         key = (tuple(x.shape), training, bool(x.requires_grad), self._bn_signature())
         prog = self.programs.get(key)
+        if prog is not None and prog.in_flight and training and grad_mode:
+            # the reference's autograd lets a caller run several forwards before the first backward (model.py:273-307 has no
+            # restriction): each such forward needs its own set of saved activations, i.e. a further traced program of the same
+            # shape (static buffers: ~190 MB per image for hg2) — created on demand, kept, at most MAX_IN_FLIGHT of them
+            k = 1
+            while (key, k) in self.programs and self.programs[(key, k)].in_flight:
+                k += 1
+            if k >= self.MAX_IN_FLIGHT:
+                raise RuntimeError('dsnt: %d forward passes of this shape are waiting for their backward; run backward (or drop the '
+                                   'outputs) before forwarding again' % k)
+            key = (key, k)
+            prog = self.programs.get(key)
         if prog is None:
             if x.requires_grad and not self.root.supports_input_grad:
                 raise NotImplementedError('dsnt: gradient with respect to the input image is not '

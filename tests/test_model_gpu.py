@@ -677,6 +677,52 @@ def test_optimizer_kernels():
         assert (pd.cpu() - pt.detach()).abs().max().item() <= 2e-6, kind
 
 
+def test_several_forwards_before_the_first_backward():
+    """The reference's autograd has no 'one forward in flight' rule (model.py:273-307): two forward passes of the same
+    shape, then one backward through the sum of their losses, must give the gradient of that sum.  Each waiting forward gets
+    its own traced program (its own saved activations); a dropped graph hands its program back; beyond the cap it raises."""
+    import gc
+    from dsnt.model import build_mpii_pose_model
+    m = build_mpii_pose_model(base='hg1', output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(m, seed=5)
+    m.cuda().train()
+    xa, ta, ka = (v.to(DEV) for v in synthetic.batch(2, size=64, seed=6, mask_p=0.9))
+    xb, tb, kb = (v.to(DEV) for v in synthetic.batch(2, size=64, seed=7, mask_p=0.9))
+    runner = m.hg._runner()
+
+    def grads():
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+
+    for p in m.parameters():
+        p.grad = None
+    m.forward_loss(m(xa), ta, ka).backward()            # one after the other, accumulated into p.grad
+    m.forward_loss(m(xb), tb, kb).backward()
+    want = grads()
+    assert sum(1 for p in runner.programs.values() if p.training) == 1
+    for p in m.parameters():
+        p.grad = None
+    la = m.forward_loss(m(xa), ta, ka)                  # both forwards first
+    lb = m.forward_loss(m(xb), tb, kb)
+    assert sum(1 for p in runner.programs.values() if p.training) == 2
+    (la + lb).backward()
+    got = grads()
+    assert (got - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+    assert not any(p.in_flight for p in runner.programs.values())
+    # a graph that is dropped without a backward frees its program: no third one is traced
+    lc = m.forward_loss(m(xa), ta, ka)
+    del lc
+    gc.collect()
+    ld = m.forward_loss(m(xb), tb, kb)
+    ld.backward()
+    assert sum(1 for p in runner.programs.values() if p.training) == 2
+    # and there is a cap
+    keep = []
+    with pytest.raises(RuntimeError, match='waiting for their backward'):
+        for _ in range(runner.MAX_IN_FLIGHT + 1):
+            keep.append(m(xa))
+
+
 def test_surface_and_errors():
     from dsnt.model import build_mpii_pose_model
     m = build_mpii_pose_model(base='hg', dilate=2, truncate=1)       # resnet kwargs filtered out
