@@ -31,7 +31,7 @@ def _newer(a, b):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'bn_tail.h'), os.path.join(CSRC, 'conv_split.h'),
+    deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'bn_pro.h'), os.path.join(CSRC, 'conv_split.h'),
             os.path.join(CSRC, 'wgrad3.h'), os.path.join(CSRC, 'gemm1.h'), os.path.join(CSRC, 'conv3s.h'), os.path.join(CSRC, 'bwd1.h'),
             os.path.join(HERE, '..', 'include', 'dsnt_hip.h'), os.path.join(HERE, '..', 'include', 'dsnt_hip_debug.h')]
     objs, jobs = [], []

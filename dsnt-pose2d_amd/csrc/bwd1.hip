@@ -381,7 +381,9 @@ Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g, bool share) {
     if (!b1_enabled || !g) return pl;
     if (!(g->R == 1 && g->S == 1 && g->stride == 1 && g->pad == 0 && g->Ho == g->H && g->Wo == g->W)) return pl;
     const long M = (long)g->N * g->H * g->W;
-    if (M % 32 != 0 || M < 16384) return pl;
+    static long min_rows = -1;
+    if (min_rows < 0) { const char* e = getenv("DSNT_X_BWD1_MIN_ROWS"); min_rows = e ? atol(e) : 16384; }      // A/B only
+    if (M % 32 != 0 || M < min_rows) return pl;
     if ((size_t)M * g->Cin * 4u >= (1ull << 31) || (size_t)M * g->Cout * 4u >= (1ull << 31)) return pl;
     int cfg = -1;
     for (int i = 0; i < (int)(sizeof(b1_cfgs) / sizeof(b1_cfgs[0])); ++i)

@@ -17,7 +17,7 @@
 // bank-conflict free.  One barrier per K-step, global loads for step s+1 in flight during the
 // MFMAs of step s (register staging: the A operand needs per-element BN/ReLU/padding).
 #include "common.h"
-#include "bn_tail.h"
+#include "bn_pro.h"
 #include "conv_split.h"
 #include "wgrad3.h"
 #include "gemm1.h"
@@ -187,11 +187,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[TM][
                     a0 += red[((size_t)w * BN + tid) * 2 + 0];
                     a1 += red[((size_t)w * BN + tid) * 2 + 1];
                 }
-                tail_store(p.stats + ((size_t)mtile * 2 + 0) * p.Cout + n, a0);      // write-through: see bn_tail.h
+                tail_store(p.stats + ((size_t)mtile * 2 + 0) * p.Cout + n, a0);
                 tail_store(p.stats + ((size_t)mtile * 2 + 1) * p.Cout + n, a1);
             }
         }
-        if (p.tail.counters) bn_tail_run<NT>(p.tail, p.stats, p.mtiles, p.Cout, p.M, mtile, p.ntiles, smem);
     }
 }
 
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(512, 4) void conv_fwd_kernel(ConvP p) {
     const int wm = cw / WN, wn = cw % WN;
     DBG_INIT();
     DBG_STAMP(0);
-    if (PRO && p.pro.partial) {          // the A operand's BatchNorm is finalised here (bn_tail.h: bn_pro_forward)
+    if (PRO && p.pro.partial) {          // the A operand's BatchNorm is finalised here (bn_pro.h: bn_pro_forward)
         bn_pro_forward<512>(p.pro, reinterpret_cast<double*>(smem), blockIdx.x == 0);
         __syncthreads();                 // this workgroup's stores to in_scale / in_shift are visible to its loads
     }
@@ -842,7 +841,6 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_bf16x6_kernel(ConvP p) {
     DBG_STAMP(125);
 }
 
-extern "C" int dsnt_bn_tail_group(void) { return BN_TAIL_GROUP; }
 
 extern "C" int dsnt_conv_bf16x6_ok(const dsnt_conv_geom* g) {
     if (!g) return 0;
@@ -947,7 +945,7 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const unsigned OOB = 0xF0000000u;
-    if (PRO && p.pro.partial) {          // the A operand's BatchNorm is finalised here (bn_tail.h: bn_pro_forward)
+    if (PRO && p.pro.partial) {          // the A operand's BatchNorm is finalised here (bn_pro.h: bn_pro_forward)
         bn_pro_forward<512>(p.pro, reinterpret_cast<double*>(&part[0][0][0]), blockIdx.x == 0);
         __syncthreads();                 // this workgroup's stores to in_scale / in_shift are visible to its loads
     }
@@ -1085,14 +1083,16 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
             tail_store(p.stats + ((size_t)mtile * 2 + 0) * p.Cout + n, a0);
             tail_store(p.stats + ((size_t)mtile * 2 + 1) * p.Cout + n, a1);
         }
-        if (p.tail.counters) bn_tail_run<512>(p.tail, p.stats, p.mtiles, p.Cout, p.M, mtile, nt32, &part[0][0][0]);
     }
 }
 
 // rows up to which the K-split kernel replaces the 32 x 128 tiling (measured crossover: 2048)
 static long ksplit_rows() {
     static long v = -1;
-    if (v < 0) v = 2048;
+    if (v < 0) {
+        const char* e = getenv("DSNT_X_KSPLIT_ROWS");        // A/B only (tools/ab_env.sh)
+        v = e ? atol(e) : 2048;
+    }
     return v;
 }
 
@@ -1105,7 +1105,7 @@ extern "C" int dsnt_conv_fwd_pro_ok(const dsnt_conv_geom* g, int tiles, int C) {
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, float* y,
                          const float* in_scale, const float* in_shift, int in_relu,
                          const float* res1, const float* res2, float* stats_partial,
-                         const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, const dsnt_bn_tail* g_tail,
+                         const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, const dsnt_out_bounds* g_tail,
                          void* stream, const dsnt_bn_prologue* g_pro = nullptr) {
     if (int e = check_geom(g, "dsnt_conv_fwd")) return e;
     DSNT_REQUIRE(!g_bnb || (g_bnb->x && g_bnb->scale && g_bnb->shift && g_bnb->mean && g_bnb->invstd &&
@@ -1127,9 +1127,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
         p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
         p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
     }
-    if (int e = bn_tail_fill(p.tail, g_tail, "dsnt_conv_fwd_ex")) return e;
-    DSNT_REQUIRE(!p.tail.counters || (stats_partial && p.tail.mode == (g_bnb ? 1 : 0)), DSNT_ERR_ARG,
-                 "dsnt_conv_fwd_ex: a dsnt_bn_tail needs stats_partial; mode 1 goes with the batch-norm-backward epilogue");
+    if (int e = out_bounds_fill(p.tail, g_tail, "dsnt_conv_fwd_ex")) return e;
     memset(&p.pro, 0, sizeof(p.pro));
     if (g_pro) {
         DSNT_REQUIRE(g_pro->partial && g_pro->mean && g_pro->invstd && g_pro->scale && g_pro->shift && g_pro->M > 0 &&
@@ -1153,7 +1151,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
     p.mtiles = (p.M + BM - 1) / BM; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
     const bool pro = in_scale != nullptr;
-    DSNT_REQUIRE(!(p.tail.amax_bn && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_ex: dsnt_bn_tail.amax_bn excludes the batch-norm-backward epilogue");
+    DSNT_REQUIRE(!(p.tail.amax_bn && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_ex: dsnt_out_bounds.amax_bn excludes the batch-norm-backward epilogue");
     if (BM == 32 && p.M <= ksplit_rows() && p.Cin % 8 == 0 && (size_t)p.N * p.H * p.W * p.Cin * 4u < (1ull << 31) &&
         (size_t)p.Cout * p.K * 4u < (1ull << 31) && !p.tail.amax && !p.tail.amax_bn &&        // (the K-split epilogue has no amax)
         (!pro || p.Cin <= 4096)) {
@@ -1184,14 +1182,14 @@ extern "C" int dsnt_conv_fwd(const float* x, const float* w, const float* bias, 
 extern "C" int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y,
                                 const float* in_scale, const float* in_shift, int in_relu,
                                 const float* res1, const float* res2, float* stats_partial,
-                                const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail,
+                                const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_out_bounds* tail,
                                 void* stream) {
     return conv_fwd_impl(x, w, bias, y, in_scale, in_shift, in_relu, res1, res2, stats_partial, g, bnb, tail, stream);
 }
 
 extern "C" int dsnt_conv_fwd_pro(const float* x, const float* w, const float* bias, float* y, const dsnt_bn_prologue* pro,
                                  int in_relu, const float* res1, const float* res2, float* stats_partial,
-                                 const dsnt_conv_geom* g, const dsnt_bn_tail* tail, void* stream) {
+                                 const dsnt_conv_geom* g, const dsnt_out_bounds* tail, void* stream) {
     DSNT_REQUIRE(pro, DSNT_ERR_ARG, "dsnt_conv_fwd_pro: null dsnt_bn_prologue");
     return conv_fwd_impl(x, w, bias, y, pro->scale, pro->shift, in_relu, res1, res2, stats_partial, g, nullptr, tail, stream, pro);
 }
@@ -1466,7 +1464,7 @@ extern "C" int dsnt_debug_force_gemm6(int on) { g_force_gemm6 = on != 0; return 
 static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_stride, const float* bias, float* y,
                           const float* in_scale, const float* in_shift, int in_relu,
                           const float* res1, const float* res2, float* stats_partial,
-                          const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, const dsnt_bn_tail* g_tail,
+                          const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, const dsnt_out_bounds* g_tail,
                           void* stream, const float* a_bound = nullptr, const float* w_bound = nullptr,
                           bool stream_w = false) {
     if (int e = check_geom(g, "dsnt_conv_fwd_bf16x6")) return e;
@@ -1495,22 +1493,20 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
         p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
         p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
     }
-    if (int e = bn_tail_fill(p.tail, g_tail, "dsnt_conv_fwd_bf16x6_ex")) return e;
-    DSNT_REQUIRE(!p.tail.counters || (stats_partial && p.tail.mode == (g_bnb ? 1 : 0)), DSNT_ERR_ARG,
-                 "dsnt_conv_fwd_bf16x6_ex: a dsnt_bn_tail needs stats_partial; mode 1 goes with the batch-norm-backward epilogue");
+    if (int e = out_bounds_fill(p.tail, g_tail, "dsnt_conv_fwd_bf16x6_ex")) return e;
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
     const int BN = g->Cout <= 64 ? 64 : 128;
     p.mtiles = (p.M + 127) / 128; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
-    DSNT_REQUIRE(!(p.tail.amax_bn && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_bn_tail.amax_bn excludes the batch-norm-backward epilogue");
+    DSNT_REQUIRE(!(p.tail.amax_bn && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_out_bounds.amax_bn excludes the batch-norm-backward epilogue");
     p.a_bound = a_bound; p.w_bound = w_bound;
     const bool share_chip = a_bound && (in_relu & DSNT_CONV_SHARE_CHIP) != 0;       // (fp16x3 entry points) leave room beside this launch
     if (a_bound) p.in_relu = in_relu & 1;
     if (stream_w) {                  // 3x3, weights in the stream layout: the symmetric kernel (conv3s.hip)
         DSNT_REQUIRE(dsnt_conv3s_ok(p), DSNT_ERR_SHAPE, "dsnt_conv_fwd_f16x3_stream: launch not supported (dsnt_conv_fwd_stream_ok; "
-                     "no second residual, no BatchNorm tail counters)");
+                     "no second residual)");
         dsnt_conv3s_launch(p, in_scale != nullptr, st, share_chip);
         DSNT_CHECK_LAUNCH("dsnt_conv_fwd_f16x3_stream");
     }
@@ -1544,7 +1540,7 @@ extern "C" int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_
 extern "C" int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* bias,
                                        float* y, const float* in_scale, const float* in_shift, int in_relu,
                                        const float* res1, const float* res2, float* stats_partial,
-                                       const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail,
+                                       const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_out_bounds* tail,
                                        void* stream) {
     return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
                           stats_partial, g, bnb, tail, stream);
@@ -1554,7 +1550,7 @@ extern "C" int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int6
                                       const float* a_bound, const float* bias, float* y, const float* in_scale,
                                       const float* in_shift, int in_relu, const float* res1, const float* res2,
                                       float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
-                                      const dsnt_bn_tail* tail, void* stream) {
+                                      const dsnt_out_bounds* tail, void* stream) {
     DSNT_REQUIRE(a_bound && w_bound, DSNT_ERR_ARG, "dsnt_conv_fwd_f16x3_ex: the operand bounds (device scalars) are required");
     return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
                           stats_partial, g, bnb, tail, stream, a_bound, w_bound);
@@ -1566,7 +1562,7 @@ extern "C" int dsnt_conv_fwd_f16x3_stream(const float* x, const void* w_planes, 
                                           const float* a_bound, const float* bias, float* y, const float* in_scale,
                                           const float* in_shift, int in_relu, const float* res1, const float* res2,
                                           float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
-                                          const dsnt_bn_tail* tail, void* stream) {
+                                          const dsnt_out_bounds* tail, void* stream) {
     DSNT_REQUIRE(a_bound && w_bound, DSNT_ERR_ARG, "dsnt_conv_fwd_f16x3_stream: the operand bounds (device scalars) are required");
     return conv_fwd6_impl(x, w_planes, plane_stride, bias, y, in_scale, in_shift, in_relu, res1, res2,
                           stats_partial, g, bnb, tail, stream, a_bound, w_bound, true);

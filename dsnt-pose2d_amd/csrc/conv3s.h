@@ -4,7 +4,7 @@
 
 // true: conv3s runs this launch (fp16x3 with the weights in the STREAM layout of dsnt_f16_prep_weights, 3x3 / stride 1 /
 // pad 1, H % 4 == 0 and W % 32 == 0 or H % 8 == 0 and W % 16 == 0, Cin % 32 == 0 and <= 128, Cout 64 or 128, at most one
-// residual, no BatchNorm tail counters)
+// residual)
 bool dsnt_conv3s_ok(const ConvP& p);
 // geometry part of the same test (the engine asks before it chooses the weight layout)
 bool dsnt_conv3s_geom_ok(const dsnt_conv_geom* g);

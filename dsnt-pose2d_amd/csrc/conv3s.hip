@@ -19,7 +19,7 @@
 //     software-pipelined over the wave's tiles (as gemm1.hip).
 // Same K order (16-channel chunk, tap) and MFMA order as conv3x3_bf16x6_kernel<.., F16>: the convolution sums are
 // bit-identical to that kernel's; the per-tile column statistics are summed in another order.
-// Contract: conv_fwd_bf16x6_kernel<..., F16> minus the second residual and the BatchNorm tail counters (dsnt_conv3s_ok).
+// Contract: conv_fwd_bf16x6_kernel<..., F16> minus the second residual (dsnt_conv3s_ok).
 // Measured (DESIGN.md "round 3", profiles/r03_pmc_issue_accounting.txt): 3x3 128->128 @64x64, batch 32: 129 -> 104 us on one box
 // (matrix pipe 53 %, 1.15 PFLOP/s of fp16 MFMA at the ~1.9 GHz this load holds), -0.42 ms per hg2 step.  Built on the same pieces,
 // bit-identical, and dropped: an 8-wave ping-pong form (two groups one phase apart, 101-110 us, but one 124 KB workgroup per CU
@@ -412,7 +412,7 @@ bool dsnt_conv3s_ok(const ConvP& p) {
     g.R = p.R; g.S = p.S; g.stride = p.stride; g.pad = p.pad; g.dil = p.dil;
     if (!dsnt_conv3s_geom_ok(&g)) return false;
     if (!p.a_bound || !p.w_bound || !p.wq) return false;
-    if (p.tail.counters || p.res2) return false;
+    if (p.res2) return false;
     if (p.bnb_scale && p.in_scale) return false;
     return true;
 }

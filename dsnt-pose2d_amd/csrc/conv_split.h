@@ -2,7 +2,7 @@
 // fp16x3 operand scale / 64-slot bounds and the exact two-plane fp16 split.  Device code only (gfx950).
 #pragma once
 #include "common.h"
-#include "bn_tail.h"
+#include "bn_pro.h"
 #include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -69,9 +69,9 @@ struct ConvP {
     const float* a_bound; const float* w_bound;
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil;
     int M, K, mtiles, ntiles;
-    // optional: the launch's last workgroup finishes the BatchNorm bookkeeping over `stats` (bn_tail.h)
-    BnTailP tail;
+    // optional: the operand bounds this launch leaves for the consumers of its output (bn_pro.h)
+    OutBoundsP tail;
     // optional (pro.partial != null): the BatchNorm of the A operand is finalised in this launch's prologue — every
-    // workgroup writes in_scale / in_shift (= pro.scale / pro.shift) itself before it reads them (bn_tail.h)
+    // workgroup writes in_scale / in_shift (= pro.scale / pro.shift) itself before it reads them (bn_pro.h)
     BnProP pro;
 };

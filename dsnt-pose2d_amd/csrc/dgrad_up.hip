@@ -21,7 +21,7 @@
 // Replaces cuDNN's strided backward-data of /root/reference/src/dsnt/model.py:103-121 (torchvision ResNet conv1,
 // layerN[0].conv1 / conv2 and downsample[0]).
 #include "common.h"
-#include "bn_tail.h"
+#include "bn_pro.h"
 #include "conv_split.h"
 
 #define UP_MAX_STRIDE 4
@@ -196,7 +196,7 @@ extern "C" int dsnt_conv_dgrad_strided_tiles(const dsnt_conv_geom* g) {
 }
 
 extern "C" int dsnt_conv_dgrad_strided(const float* dy, const float* wd, float* dx, const float* res1, float* stats_partial,
-                                       const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail,
+                                       const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_out_bounds* tail,
                                        void* stream) {
     DSNT_REQUIRE(g && dy && wd && dx, DSNT_ERR_ARG, "dsnt_conv_dgrad_strided: null argument");
     const int ho = (g->H + 2 * g->pad - g->dil * (g->R - 1) - 1) / g->stride + 1;
@@ -210,8 +210,8 @@ extern "C" int dsnt_conv_dgrad_strided(const float* dy, const float* wd, float* 
                  "dsnt_conv_dgrad_strided: the batch-norm-backward epilogue needs x/scale/shift/mean/invstd and stats_partial, "
                  "and excludes res1");
     DSNT_REQUIRE(bnb || !stats_partial, DSNT_ERR_ARG, "dsnt_conv_dgrad_strided: stats_partial goes with the batch-norm-backward epilogue");
-    DSNT_REQUIRE(!tail || (!tail->counters && !tail->amax_bn), DSNT_ERR_ARG, "dsnt_conv_dgrad_strided: of dsnt_bn_tail only amax is supported");
-    DSNT_REQUIRE(!(tail && tail->amax && bnb), DSNT_ERR_ARG, "dsnt_conv_dgrad_strided: dsnt_bn_tail.amax excludes the batch-norm-backward epilogue");
+    DSNT_REQUIRE(!tail || !tail->amax_bn, DSNT_ERR_ARG, "dsnt_conv_dgrad_strided: of dsnt_out_bounds only amax is supported");
+    DSNT_REQUIRE(!(tail && tail->amax && bnb), DSNT_ERR_ARG, "dsnt_conv_dgrad_strided: dsnt_out_bounds.amax excludes the batch-norm-backward epilogue");
     UpP p;
     memset(&p, 0, sizeof(p));
     p.dy = dy; p.wd = wd; p.dx = dx; p.res1 = res1; p.stats = stats_partial;

@@ -6,7 +6,7 @@
 // no atomics).
 #include "common.h"
 #include <string.h>
-#include "bn_tail.h"
+#include "bn_pro.h"
 #include "conv_split.h"
 
 #define TILE_ROWS 128
@@ -106,7 +106,7 @@ template <int OP>
 __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                             float* __restrict__ y, unsigned char* __restrict__ idx,
                                                             float* partial, int N, int Ho, int Wo, int C, int cgs,
-                                                            BnTailP tail, const float* __restrict__ bn_scale = nullptr,
+                                                            OutBoundsP tail, const float* __restrict__ bn_scale = nullptr,
                                                             const float* __restrict__ bn_shift = nullptr, int bn_relu = 0) {
     __shared__ __attribute__((aligned(16))) float red[256 * 8];
     const int tid = threadIdx.x;
@@ -212,23 +212,20 @@ __global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restr
                 for (int e = 0; e < 8; ++e) acc[e] += red[(j * cgs + tid) * 8 + e];
             float* p0 = partial + ((size_t)blockIdx.x * 2 + 0) * C + (size_t)(cg0 + tid) * 4;
             float* p1 = partial + ((size_t)blockIdx.x * 2 + 1) * C + (size_t)(cg0 + tid) * 4;
-            tail_store4(p0, make_float4(acc[0], acc[1], acc[2], acc[3]));      // write-through: see bn_tail.h
-            tail_store4(p1, make_float4(acc[4], acc[5], acc[6], acc[7]));
+            *reinterpret_cast<float4*>(p0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(p1) = make_float4(acc[4], acc[5], acc[6], acc[7]);
         }
     }
     if (tail.amax) amax_commit(am, tail.amax);
     if (tail.amax_bn) amax_commit(am2, tail.amax_bn, 1);
-    if (tail.counters) bn_tail_run<256>(tail, partial, (int)((M + TILE_ROWS - 1) / TILE_ROWS), C, M, blockIdx.x, (int)gridDim.y, red);
 }
 
 extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* partial, int N, int H, int W,
-                                       int C, const dsnt_bn_tail* g_tail, void* stream) {
-    BnTailP tail;
-    if (int e = bn_tail_fill(tail, g_tail, "dsnt_maxpool2_fwd_stats")) return e;
-    DSNT_REQUIRE(!tail.counters || tail.mode == 0, DSNT_ERR_ARG, "dsnt_maxpool2_fwd_stats: dsnt_bn_tail must be mode 0");
+                                       int C, const dsnt_out_bounds* g_tail, void* stream) {
+    OutBoundsP tail;
+    if (int e = out_bounds_fill(tail, g_tail, "dsnt_maxpool2_fwd_stats")) return e;
     DSNT_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
                  "dsnt_maxpool2_fwd_stats: bad argument");
-    DSNT_REQUIRE(partial || !tail.counters, DSNT_ERR_ARG, "dsnt_maxpool2_fwd_stats: a dsnt_bn_tail needs the partial sums");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_fwd_stats: H and W must be even (got %dx%d)", H, W);
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(partial) &&
                  (((uintptr_t)idx) & 3) == 0, DSNT_ERR_ALIGN, "dsnt_maxpool2_fwd_stats: alignment");
@@ -240,13 +237,11 @@ extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, f
 }
 
 extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, float* out, float* partial, int N,
-                                            int H, int W, int C, const dsnt_bn_tail* g_tail, void* stream) {
-    BnTailP tail;
-    if (int e = bn_tail_fill(tail, g_tail, "dsnt_upsample2_add_fwd_stats")) return e;
-    DSNT_REQUIRE(!tail.counters || tail.mode == 0, DSNT_ERR_ARG, "dsnt_upsample2_add_fwd_stats: dsnt_bn_tail must be mode 0");
+                                            int H, int W, int C, const dsnt_out_bounds* g_tail, void* stream) {
+    OutBoundsP tail;
+    if (int e = out_bounds_fill(tail, g_tail, "dsnt_upsample2_add_fwd_stats")) return e;
     DSNT_REQUIRE(up && low && out && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG,
                  "dsnt_upsample2_add_fwd_stats: bad argument");
-    DSNT_REQUIRE(partial || !tail.counters, DSNT_ERR_ARG, "dsnt_upsample2_add_fwd_stats: a dsnt_bn_tail needs the partial sums");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_upsample2_add_fwd_stats: H and W must be even");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(up) && dsnt_aligned16(low) && dsnt_aligned16(out) &&
                  dsnt_aligned16(partial), DSNT_ERR_ALIGN, "dsnt_upsample2_add_fwd_stats: alignment");
@@ -258,12 +253,10 @@ extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, f
 }
 
 extern "C" int dsnt_bn_act_fwd_stats(const float* x, const float* scale, const float* shift, int relu, float* y,
-                                     float* partial, int64_t M, int C, const dsnt_bn_tail* g_tail, void* stream) {
-    BnTailP tail;
-    if (int e = bn_tail_fill(tail, g_tail, "dsnt_bn_act_fwd_stats")) return e;
-    DSNT_REQUIRE(!tail.counters || tail.mode == 0, DSNT_ERR_ARG, "dsnt_bn_act_fwd_stats: dsnt_bn_tail must be mode 0");
+                                     float* partial, int64_t M, int C, const dsnt_out_bounds* g_tail, void* stream) {
+    OutBoundsP tail;
+    if (int e = out_bounds_fill(tail, g_tail, "dsnt_bn_act_fwd_stats")) return e;
     DSNT_REQUIRE(x && scale && shift && y && M > 0 && C > 0, DSNT_ERR_ARG, "dsnt_bn_act_fwd_stats: bad argument");
-    DSNT_REQUIRE(partial || !tail.counters, DSNT_ERR_ARG, "dsnt_bn_act_fwd_stats: a dsnt_bn_tail needs the partial sums");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(y) && dsnt_aligned16(scale) && dsnt_aligned16(shift) &&
                  dsnt_aligned16(partial), DSNT_ERR_ALIGN, "dsnt_bn_act_fwd_stats: alignment");
     const long tiles = ((long)M + TILE_ROWS - 1) / TILE_ROWS;
@@ -428,7 +421,7 @@ extern "C" int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M,
 
 // dsnt_bn_bwd_finalize that also leaves the bound of the BatchNorm's dx for a consumer that never sees dx in memory
 // (dsnt_conv1x1_bwd_f16x3 with a dsnt_bn_bwd_apply): scale = the BatchNorm's forward scale vector (gamma * invstd), dz_amax = the
-// 64-slot max |dz| its data-gradient producer left (dsnt_bn_tail.amax), bound_out = 64 slots, zeroed by the caller once per step.
+// 64-slot max |dz| its data-gradient producer left (dsnt_out_bounds.amax), bound_out = 64 slots, zeroed by the caller once per step.
 extern "C" int dsnt_bn_bwd_finalize_bound(const float* partial, int ntiles, int64_t M, int C, float* dgamma, float* dbeta,
                                           int accumulate, float* coef, const float* scale, const float* dz_amax,
                                           float* bound_out, void* stream) {
@@ -883,7 +876,7 @@ __global__ void s2d_input_kernel(const float* __restrict__ src, float4* __restri
     if (amax) amax_commit(am, amax);
 }
 
-extern "C" int dsnt_s2d_input(const float* src_nchw, float* dst, int N, int C, int H, int W, const dsnt_bn_tail* tail,
+extern "C" int dsnt_s2d_input(const float* src_nchw, float* dst, int N, int C, int H, int W, const dsnt_out_bounds* tail,
                               void* stream) {
     DSNT_REQUIRE(src_nchw && dst && N > 0 && C > 0 && C <= 4 && H > 0 && W > 0, DSNT_ERR_ARG, "dsnt_s2d_input: bad argument");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_s2d_input: H and W must be even (got %dx%d)", H, W);

@@ -17,7 +17,7 @@
 //     two 128-byte runs — residuals are loaded and results stored as full lines by dword accesses, bias / BatchNorm
 //     vectors are per-lane scalars (lane = column), column sums need no transposition.
 // Same contract as conv_fwd_bf16x6_kernel<..., F16> (conv.hip): BN+ReLU prologue, bias, two residuals, per-128-row
-// column statistics, the BatchNorm-backward epilogue of data-gradient launches, the bounds of dsnt_bn_tail.
+// column statistics, the BatchNorm-backward epilogue of data-gradient launches, the bounds of dsnt_out_bounds.
 #include "gemm1.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -289,7 +289,6 @@ int dsnt_gemm1_cfg(const ConvP& p) {
     }
     if (!g1_enabled || !p.a_bound || !p.w_bound || !p.wq) return -1;
     if (!(p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.Ho == p.H && p.Wo == p.W)) return -1;
-    if (p.tail.counters) return -1;                             // BatchNorm tails: the tiled kernel only
     if (p.res2) return -1;                                      // two residuals (score_ joins): the tiled kernel
     if (p.bnb_scale && (p.in_scale || p.res2)) return -1;
     if (p.M < g1_min_rows) return -1;

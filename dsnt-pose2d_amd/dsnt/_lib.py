@@ -47,12 +47,9 @@ PP = C.POINTER(BnPrologue)
 
 
 class BnTail(C.Structure):
-    """dsnt_bn_tail: the BatchNorm bookkeeping a statistics-producing launch finishes in its last workgroup."""
-    _fields_ = [('mode', C.c_int), ('accumulate', C.c_int), ('counters', C.c_void_p), ('level2', C.c_void_p),
-                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
-                ('momentum', C.c_float), ('eps', C.c_float),
-                ('out0', C.c_void_p), ('out1', C.c_void_p), ('out2', C.c_void_p), ('out3', C.c_void_p),
-                ('amax', C.c_void_p), ('amax_bn', C.c_void_p), ('amax_scale', C.c_void_p), ('amax_shift', C.c_void_p),
+    """dsnt_out_bounds: the fp16x3 operand bounds a launch leaves behind for the consumers of its output.  (The class keeps the
+    name it had while the struct also described a BatchNorm finalisation in the producer's last workgroup.)"""
+    _fields_ = [('amax', C.c_void_p), ('amax_bn', C.c_void_p), ('amax_scale', C.c_void_p), ('amax_shift', C.c_void_p),
                 ('amax_relu', C.c_int), ('reserved', C.c_int)]
 
 
@@ -168,7 +165,6 @@ PLAIN = {
     'dsnt_version': (I, []),
     'dsnt_last_error': (C.c_char_p, []),
     'dsnt_conv_fwd_bm': (I, [GP]),
-    'dsnt_bn_tail_group': (I, []),
     'dsnt_list_create': (P, []),
     'dsnt_list_destroy': (None, [P]),
     'dsnt_list_begin': (I, [P]),

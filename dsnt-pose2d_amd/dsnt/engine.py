@@ -32,7 +32,7 @@ BN_MOMENTUM = 0.1
 
 class Act:
     """An activation on the tape: NHWC buffer + lazily created gradient / batch statistics."""
-    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'stats_tail', 'amax_tail', 'fold_ok',
+    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'amax_tail', 'fold_ok',
                  'pending_apply')
 
     def __init__(self, buf, name=''):
@@ -40,8 +40,7 @@ class Act:
         self.N, self.H, self.W, self.C = buf.shape
         self.grad = None        # torch tensor once some backward op has written it
         self.stats = None       # (partial tensor, ntiles)
-        self.stats_tail = None  # BnTail of the launch that writes `stats`: the first BatchNorm over this tensor claims it
-        self.amax_tail = None   # fp16x3: the dsnt_bn_tail of the producing launch if it can leave max|buf| (operand_amax)
+        self.amax_tail = None   # fp16x3: the dsnt_out_bounds of the producing launch if it can leave max|buf| (operand_amax)
         self.grad_amax = None   # fp16x3: device scalar max|grad| when ONE bn-backward apply wrote the whole gradient
         self.fold_ok = False    # the producing 1x1 convolution can take the BatchNorm backward of its consumer into its own backward
         self.pending_apply = None   # ... and this is that BatchNorm backward, reduced but not applied (Tape._norm_backward)
@@ -116,7 +115,7 @@ class Tape:
         # DSNT_WGRAD_LANE_RES=1 also moves convolutions with residual inputs, whose dY buffer is donated onwards and
         # written again — the writer then has to wait for the lane (measured: +0.45 ms, off).
         self.wgrad_lane = 2 if (self.use_lanes and os.environ.get('DSNT_WGRAD_LANE', '1') != '0') else None
-        self.wgrad_lane_rows = 16000
+        self.wgrad_lane_rows = int(os.environ.get('DSNT_X_WGRAD_LANE_ROWS', '16000'))
         self.wgrad_lane_res = False
         self.wgrad_lane_from = self.chain_lanes
         # 3x3 forward / data gradient: the symmetric persistent kernel of csrc/conv3s.hip (stream-ordered weight planes)
@@ -135,7 +134,7 @@ class Tape:
         # DSNT_WGRAD_RELEASE_ROWS rows.  Issued as they come, the weight gradients share the chip with the large
         # data-gradient kernels and are gone by the time the small levels start; held back, they run beside them.
         # Only while a release point is still ahead in the backward order (a ResNet has none: nothing is held back).
-        self.release_rows = 8192
+        self.release_rows = int(os.environ.get('DSNT_X_RELEASE_ROWS', '8192'))
         self._release_total, self._release_left = 0, 0
         self._held = []
         self.acts = []          # every activation in creation order (debugging / introspection)
@@ -151,7 +150,7 @@ class Tape:
         # weight gradients of the low-resolution levels (few workgroups each, nothing downstream in backward
         # needs them) wait for the end of their parameter bucket and run side by side in one grouped launch;
         # DSNT_WGRAD_GROUP_ROWS = largest N*Ho*Wo that is deferred (0 disables)
-        self.group_rows = 8192 if self.defer_reduce else 0
+        self.group_rows = int(os.environ.get('DSNT_X_GROUP_ROWS', '8192')) if self.defer_reduce else 0
         self._pending_group = []    # (descriptor bytes, workgroups) since the last flush
         # max-pool / upsample+add write the BatchNorm statistics of their output themselves (DSNT_FUSE_OP_STATS=0:
         # a separate dsnt_bn_stats pass when a BatchNorm asks for them)
@@ -161,7 +160,7 @@ class Tape:
         # ... up to this many (tiles x channels) of partial sums.  Measured (tools/bench_bn_prologue.py, MI355X): a finalise
         # launch costs the chain 4-5 us; the prologue costs every workgroup of the consumer 2.8 us at 16 KB of partials,
         # 3.2 us at 32 KB, 4.5 us at 64 KB (no gain), 9 us at 128 KB (a loss): fused up to 32 KB
-        self.fuse_finalize_max = 4096
+        self.fuse_finalize_max = int(os.environ.get('DSNT_X_FUSE_FINALIZE_MAX', '4096'))
         # fp16x3 (default; DSNT_SPLIT=bf16x6 turns it off): two fp16 planes + three MFMAs instead of three bf16 planes + six, where an operand
         # bound is available without a host round-trip: train-mode BN+ReLU operands (bound from the BN parameters) and
         # weights (amax in the per-step prep launch)
@@ -185,18 +184,6 @@ class Tape:
         # step launch by launch and hold each bound against the operand it must dominate (tests/test_bounds_gpu.py)
         self.f16_uses = []
         self._pending_group_uses = []
-        # BatchNorm finalisation folded into the producers' last workgroup (csrc/bn_tail.h); DSNT_BN_TAIL=0: separate
-        # dsnt_bn_finalize / dsnt_bn_bwd_finalize launches as before (A/B switch)
-        self.use_tail = True
-        # ... for producers of up to DSNT_BN_TAIL_ROWS rows.  Default 0 = off: measured on MI355X (hg2, batch 32) the
-        # 193 finalise launches are NOT on the critical path of an untraced step — 16.53 ms without tails, 16.69 ms with
-        # tails on every launch of <= 32768 rows (507 launches/step instead of 651), 16.80 ms with tails everywhere (460)
-        # — although under rocprofv3's kernel trace, which stretches every launch boundary, tails win 1.1 ms/step.
-        # Every workgroup of a tailed launch drains its stores and draws a ticket before it retires (~3 us).
-        self.tail_rows = int(os.environ.get('DSNT_BN_TAIL_ROWS', '0'))
-        self._tail_group = self.lib.dsnt_bn_tail_group()
-        self._tail_counters = torch.zeros(1 << 16, dtype=torch.int32, device=device)   # arrival tickets, self-resetting
-        self._tail_used = 0
         # replay from C (dsnt_list_*): a launch list is recorded once into the library and then issued by ONE call per
         # segment instead of one ctypes call per launch (DSNT_C_REPLAY=0: the Python loop below)
         self.c_replay = True
@@ -251,9 +238,8 @@ class Tape:
         assert self._f16_w_stream.get(key, False) == stream, 'one weight tensor, two plane layouts'
 
     def stream_ok(self, p, g, rows, res2):
-        """A 3x3 convolution the symmetric persistent kernel runs (weights in stream order): large enough that no BatchNorm
-        tail is ever attached to it, at most one residual."""
-        return (self.conv3s and p.R == 3 and p.S == 3 and res2 is None and rows > self.tail_rows and
+        """A 3x3 convolution the symmetric persistent kernel runs (weights in stream order): at most one residual."""
+        return (self.conv3s and p.R == 3 and p.S == 3 and res2 is None and
                 bool(self.lib.dsnt_conv_fwd_stream_ok(C.byref(g))))
 
     def f16_bn_bound(self, n):
@@ -274,7 +260,7 @@ class Tape:
 
     def operand_amax(self, x):
         """Bound slot for activation x used as a RAW fp16x3 operand (no BatchNorm in between: skip projections, `lin`
-        convolutions): the launch that produced x is asked — through its dsnt_bn_tail, read at launch time — to leave
+        convolutions): the launch that produced x is asked — through its dsnt_out_bounds, read at launch time — to leave
         max|x| there.  None if the producer cannot."""
         t = x.amax_tail
         if t is None or not self.use_f16x3 or not self.raw_f16:
@@ -297,7 +283,7 @@ class Tape:
     def operand_amax_bn(self, n):
         """Eval mode: bound slot for relu?(bn(x)) as an fp16x3 operand.  The BatchNorm vectors come from running
         statistics (one dsnt_bn_eval_prep launch at the head of the forward), so the launch that produces x can form
-        the operand itself and leave its exact maximum (dsnt_bn_tail.amax_bn).  One BatchNorm per producer; None if
+        the operand itself and leave its exact maximum (dsnt_out_bounds.amax_bn).  One BatchNorm per producer; None if
         the producer cannot or is already taken by another BatchNorm."""
         t = n.x.amax_tail
         if t is None or not self.use_f16x3 or not self.raw_f16 or self.training:
@@ -364,24 +350,6 @@ class Tape:
                           if self.fwd[i][0] is not None and self.fwd[i][2] in self._PREP_CONSUMERS
                           and id(self.fwd[i]) not in self._prep_exempt), len(self.fwd))
             self.fwd.insert(first, (None, (side, 0, torch.cuda.Event()), 'sync', 0))
-
-    def new_tail(self):
-        """A disabled dsnt_bn_tail to hand to a statistics-producing launch; `claim_tail` switches it on."""
-        return BnTail() if (self.use_tail and self.training) else None
-
-    def claim_tail(self, tail, mode, tiles, Cc, rows):
-        """Give `tail` its tickets and scratch (launch arguments are read at launch time, so this may happen after the
-        producer was put on the list).  Returns False if it is already taken, tails are off or the launch is too large."""
-        if tail is None or tail.counters or rows > self.tail_rows:
-            return False
-        groups = (tiles + self._tail_group - 1) // self._tail_group
-        assert self._tail_used + 1 + groups <= self._tail_counters.numel()
-        cnt = self._tail_counters[self._tail_used:self._tail_used + 1 + groups]
-        self._tail_used += 1 + groups
-        level2 = self.empty(groups * 2 * Cc, dtype=torch.float64)
-        tail.mode = mode
-        tail.counters, tail.level2 = cnt.data_ptr(), level2.data_ptr()
-        return True
 
     def _use6(self, g):
         return (self.use_bf16x6 and g.N * g.Ho * g.Wo >= self.bf16x6_min_rows and
@@ -457,7 +425,7 @@ class Tape:
         if not self.use_lanes:
             return x
         xb = Act(x.buf, x.name + '/branch')
-        xb.stats, xb.stats_tail, xb.amax_tail = x.stats, x.stats_tail, x.amax_tail
+        xb.stats, xb.amax_tail = x.stats, x.amax_tail
         if self.training and join:
             def join_grad():
                 if xb.grad is not None:
@@ -619,7 +587,6 @@ class Tape:
                 rc = self.lib.dsnt_list_replay(h, seg, arr, len(ptrs))
                 if rc != 0:
                     torch.cuda.synchronize()
-                    self._tail_counters.zero_()
                     self._rc(rc, 'dsnt_list_replay')
                 if seg < len(marks) and bucket_hook is not None:
                     k, lane = marks[seg]
@@ -647,7 +614,6 @@ class Tape:
             rc = fn(*args, ptrs[lane])
             if rc != 0:
                 torch.cuda.synchronize()
-                self._tail_counters.zero_()      # a list cut short may leave arrival tickets half-counted
                 raise RuntimeError('%s failed (%d): %s' % (
                     name, rc, _lib.load().dsnt_last_error().decode()))
         if self.use_lanes:
@@ -722,14 +688,7 @@ class Tape:
         n.lane = self.lane      # the lane whose launches write scale / shift: every consumer must run there (`check_lane`)
         if self.training:
             part, tiles = self.ensure_stats(x)
-            tl = x.stats_tail
-            if self.claim_tail(tl, 0, tiles, bn.C, x.M):
-                # the launch that writes `part` finishes this BatchNorm itself (its last workgroup): no finalise launch
-                tl.gamma, tl.beta = _lib.ptr(bn.gamma), _lib.ptr(bn.beta)
-                tl.running_mean, tl.running_var = _lib.ptr(bn.rmean), _lib.ptr(bn.rvar)
-                tl.momentum, tl.eps = bn.momentum, bn.eps
-                tl.out0, tl.out1, tl.out2, tl.out3 = (_lib.ptr(v) for v in (n.mean, n.invstd, n.scale, n.shift))
-            elif self.fuse_finalize and bn.C <= 256 and tiles * bn.C <= self.fuse_finalize_max:
+            if self.fuse_finalize and bn.C <= 256 and tiles * bn.C <= self.fuse_finalize_max:
                 # few tiles (the 8x8 / 4x4 levels): the launch that CONSUMES this BatchNorm finalises it in its prologue
                 # (`conv`); any other first reader materialises it with the usual launch (`materialize`)
                 n.pending = (part, tiles)
@@ -764,19 +723,6 @@ class Tape:
             self.f('dsnt_bn_finalize', part, tiles, n.x.M, bn.C, bn.gamma, bn.beta, bn.rmean, bn.rvar,
                    bn.momentum, bn.eps, 1, n.mean, n.invstd, n.scale, n.shift)
 
-    def bwd_tail(self, n, tiles):
-        """dsnt_bn_tail (mode 1) for a data-gradient launch with the BatchNorm-backward epilogue of Normed n: its last
-        workgroup writes dgamma / dbeta / coef; None if tails are off.  Returns (tail, coef)."""
-        bn = n.bn
-        coef = self.scratch('bncoef', 2 * bn.C)
-        tl = self.new_tail()
-        if not self.claim_tail(tl, 1, tiles, bn.C, n.x.M):
-            return None, coef
-        tl.accumulate = 1 if bn.uses > 0 else 0
-        bn.uses += 1
-        tl.out0, tl.out1, tl.out2 = _lib.ptr(bn.ggamma), _lib.ptr(bn.gbeta), _lib.ptr(coef)
-        return tl, coef
-
     def fold_ok(self, n):
         """The BatchNorm backward of Normed n can be left to the backward of the convolution that produced n.x."""
         x = n.x
@@ -798,7 +744,7 @@ class Tape:
     def _norm_backward(self, n, da, reduced=None, finalised=False, dz_amax=None):
         """Given da = dL/d relu(bn(x)), accumulate dx into n.x.grad and dgamma/dbeta.  With
         `reduced` = (partials, ntiles) the producer already masked da by the ReLU and reduced it; with `finalised` it
-        also wrote dgamma / dbeta / coef (bwd_tail).  With dz_amax (the slot in which the producer left max|da|; the
+        also wrote dgamma / dbeta / coef.  With dz_amax (the slot in which the producer left max|da|; the
         caller has asked `fold_ok`) dx is NOT written: the finalise launch also leaves the bound of dx, and the backward
         of the 1x1 convolution that produced x forms dx in registers (dsnt_conv1x1_bwd_f16x3)."""
         x, bn = n.x, n.bn
@@ -859,10 +805,9 @@ class Tape:
             tiles = (y.M + bm - 1) // bm
             part = self.empty(tiles, 2, p.Cout)
             y.stats = (part, tiles)
-            y.stats_tail = tail = self.new_tail()
         if use6 and self.use_f16x3:
             # the large-tile kernels can leave max|y| behind: a later consumer of the raw y claims it (operand_amax)
-            y.amax_tail = tail = tail if tail is not None else BnTail()
+            y.amax_tail = tail = BnTail()
         r1 = res1.buf if res1 is not None else None
         r2 = res2.buf if res2 is not None else None
         if self.use_f16x3 and self.training and normed:
@@ -1129,13 +1074,12 @@ class Tape:
                         part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
                         bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
                                             _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
-                        tl, _ = (None, None) if native else self.bwd_tail(src, tiles)
-                        finalised, dz_amax = tl is not None, None
-                        if fold and tl is None:
+                        tl, dz_amax = None, None
+                        if fold:
                             tl, dz_amax = BnTail(), self.amax_slot()
                             tl.amax = dz_amax.data_ptr()
                         dgrad(dz, None, part, bnb, tl)
-                        self._norm_backward(src, dz, reduced=(part, tiles), finalised=finalised, dz_amax=dz_amax)
+                        self._norm_backward(src, dz, reduced=(part, tiles), dz_amax=dz_amax)
                     else:
                         # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
                         buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16)
@@ -1167,10 +1111,8 @@ class Tape:
             # (that Bottleneck's skip projection) ride in the same pass
             tiles = (y.M + 127) // 128
             part = self.empty(tiles, 2, x.C)
-            y.stats_tail = self.new_tail()
-            if big:
-                y.amax_tail = y.stats_tail = y.stats_tail if y.stats_tail is not None else BnTail()
-            self.f('dsnt_bn_act_fwd_stats', x.buf, n.scale, n.shift, 1 if n.relu else 0, y.buf, part, x.M, x.C, y.stats_tail)
+            y.amax_tail = BnTail() if big else None
+            self.f('dsnt_bn_act_fwd_stats', x.buf, n.scale, n.shift, 1 if n.relu else 0, y.buf, part, x.M, x.C, y.amax_tail)
             y.stats = (part, tiles)
         elif not self.training and big:
             y.amax_tail = BnTail()
@@ -1190,10 +1132,8 @@ class Tape:
             # the consumer is a BatchNorm (hourglass.py:33): its batch statistics ride in the same pass
             tiles = (y.M + 127) // 128
             part = self.empty(tiles, 2, x.C)
-            y.stats_tail = self.new_tail()
-            if self.use_f16x3 and y.M >= self.bf16x6_min_rows:
-                y.amax_tail = y.stats_tail = y.stats_tail if y.stats_tail is not None else BnTail()
-            self.f('dsnt_maxpool2_fwd_stats', x.buf, y.buf, idx, part, x.N, x.H, x.W, x.C, y.stats_tail)
+            y.amax_tail = BnTail() if (self.use_f16x3 and y.M >= self.bf16x6_min_rows) else None
+            self.f('dsnt_maxpool2_fwd_stats', x.buf, y.buf, idx, part, x.N, x.H, x.W, x.C, y.amax_tail)
             y.stats = (part, tiles)
         elif not self.training and self.use_f16x3 and y.M >= self.bf16x6_min_rows:
             y.amax_tail = BnTail()        # no statistics in eval mode, but the next convolution's operand bound
@@ -1248,10 +1188,8 @@ class Tape:
         if self.training and self.fuse_op_stats:
             tiles = (out.M + 127) // 128
             part = self.empty(tiles, 2, up.C)
-            out.stats_tail = self.new_tail()
-            if self.use_f16x3 and out.M >= self.bf16x6_min_rows:
-                out.amax_tail = out.stats_tail = out.stats_tail if out.stats_tail is not None else BnTail()
-            self.f('dsnt_upsample2_add_fwd_stats', up.buf, low.buf, out.buf, part, up.N, up.H, up.W, up.C, out.stats_tail)
+            out.amax_tail = BnTail() if (self.use_f16x3 and out.M >= self.bf16x6_min_rows) else None
+            self.f('dsnt_upsample2_add_fwd_stats', up.buf, low.buf, out.buf, part, up.N, up.H, up.W, up.C, out.amax_tail)
             out.stats = (part, tiles)
         elif not self.training and self.use_f16x3 and out.M >= self.bf16x6_min_rows:
             out.amax_tail = BnTail()

@@ -38,36 +38,22 @@ typedef enum {
     DSNT_ERR_HIP = 4          /* hipGetLastError() after launch */
 } dsnt_status;
 
-/* Optional tail of a launch that leaves per-tile partial sums for a BatchNorm: the LAST workgroup to arrive
- * (agent-scope release/acquire ticket, csrc/bn_tail.h) adds the partials — in tile order, fp64, whatever the arrival
- * order — and does what dsnt_bn_finalize (mode 0) / dsnt_bn_bwd_finalize (mode 1) would do in a launch of their own
- * (hourglass.py:33-43: every conv is preceded by BN -> ReLU; 193 such launches per hg2 train step otherwise).
- * counters: [1 + (mtiles + 31) / 32] uint32, zero before the first launch (the tail re-zeroes them);
- * level2:   [(mtiles + 31) / 32][2][C] doubles of scratch;
- * mode 0: gamma/beta (may be NULL), running_mean/var (both or neither), momentum, eps -> out0..3 = mean, invstd,
- *         scale, shift [C];  mode 1: out0 = dgamma, out1 = dbeta (either may be NULL; += if accumulate),
- *         out2 = coef [2][C] (sum dz / M, sum dz*xhat / M).  counters == NULL (or a NULL struct): no tail.
- * amax (independent of the tail, may be NULL): a 64-float bound as dsnt_amax leaves it; the launch RAISES it to the
- *         max |value| it writes to its output (atomic max on the bit patterns of non-negative floats: the caller zeroes
- *         the 64 slots once per step) — the fp16x3 operand bound of a consumer that reads the output without a
- *         BatchNorm in between (skip projections, `lin` convolutions: hourglass.py:45-48,120-135), or of a data
- *         gradient written by a convolution epilogue.  With a bn_bwd_epilogue: max |dz| (what dsnt_bn_bwd_finalize_bound
- *         turns into the bound of a BatchNorm backward folded into dsnt_conv1x1_bwd_f16x3).
+/* What a launch leaves behind for the CONSUMERS of its output besides the output itself: fp16x3 operand bounds.
+ * amax (may be NULL): a 64-float bound as dsnt_amax leaves it; the launch RAISES it to the max |value| it writes to its
+ *         output (atomic max on the bit patterns of non-negative floats: the caller zeroes the 64 slots once per step) — the
+ *         fp16x3 operand bound of a consumer that reads the output without a BatchNorm in between (skip projections, `lin`
+ *         convolutions: hourglass.py:45-48,120-135), or of a data gradient written by a convolution epilogue.  With a
+ *         bn_bwd_epilogue: max |dz| (what dsnt_bn_bwd_finalize_bound turns into the bound of a BatchNorm backward folded
+ *         into dsnt_conv1x1_bwd_f16x3).
  * amax_bn (may be NULL): the same for max |relu?(value * amax_scale[c] + amax_shift[c])| — the operand a consumer with
  *         an EVAL-mode BatchNorm(+ReLU) prologue will form from this output (inference.py:38-48: the vectors come from
- *         running statistics, so they exist before the producer runs); amax_scale / amax_shift: [C], 16-byte aligned. */
+ *         running statistics, so they exist before the producer runs); amax_scale / amax_shift: [C], 16-byte aligned.
+ * (Until round 3 this struct — then dsnt_out_bounds — also described a BatchNorm finalisation run by the launch's last
+ * workgroup; slower than the separate dsnt_bn_finalize launches in every measurement of three rounds, removed in round 4.) */
 typedef struct {
-    int mode, accumulate;
-    unsigned* counters;
-    double* level2;
-    const float* gamma; const float* beta; float* running_mean; float* running_var;
-    float momentum, eps;
-    float* out0; float* out1; float* out2; float* out3;
     float* amax;
     float* amax_bn; const float* amax_scale; const float* amax_shift; int amax_relu, reserved;
-} dsnt_bn_tail;
-/* m-tiles whose partial rows one first-level reduction covers (32) */
-int dsnt_bn_tail_group(void);
+} dsnt_out_bounds;
 
 /* BatchNorm finalisation folded into the prologue of the launch that CONSUMES the BatchNorm (the low-resolution
  * hourglass levels, /root/reference/src/dsnt/hourglass.py:33-43 between two 10-us convolutions: a separate
@@ -213,9 +199,8 @@ typedef struct {
 int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y,
                      const float* in_scale, const float* in_shift, int in_relu,
                      const float* res1, const float* res2, float* stats_partial,
-                     const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail, void* stream);
-/* (`tail`, here and in the other _ex variants: the BatchNorm bookkeeping over stats_partial done by the launch's last
- * workgroup — forward statistics of the consumer BatchNorm, or with `bnb` the dgamma / dbeta / coef of the backward.) */
+                     const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_out_bounds* tail, void* stream);
+/* (`tail`, here and in the other _ex variants: the operand bounds the launch leaves behind — dsnt_out_bounds.) */
 
 /* dsnt_conv_fwd_ex with the BatchNorm of its A operand finalised in the launch's prologue (fp32-MFMA path: the
  * small-M kernels); in_scale / in_shift are pro->scale / pro->shift.  dsnt_conv_fwd_pro_ok(g, tiles, C) != 0 if the
@@ -223,7 +208,7 @@ int dsnt_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y
 int dsnt_conv_fwd_pro_ok(const dsnt_conv_geom* g, int tiles, int C);
 int dsnt_conv_fwd_pro(const float* x, const float* w, const float* bias, float* y, const dsnt_bn_prologue* pro,
                       int in_relu, const float* res1, const float* res2, float* stats_partial,
-                      const dsnt_conv_geom* g, const dsnt_bn_tail* tail, void* stream);
+                      const dsnt_conv_geom* g, const dsnt_out_bounds* tail, void* stream);
 
 /* Rows per stats_partial tile that dsnt_conv_fwd uses for this geometry (128 or 32): the
  * caller sizes stats_partial as [ceil(M/bm)][2][Cout] and hands ceil(M/bm) to dsnt_bn_finalize. */
@@ -245,7 +230,7 @@ int dsnt_conv_fwd_bf16x6(const float* x, const void* w_planes, int64_t plane_str
 int dsnt_conv_fwd_bf16x6_ex(const float* x, const void* w_planes, int64_t plane_stride, const float* bias,
                             float* y, const float* in_scale, const float* in_shift, int in_relu,
                             const float* res1, const float* res2, float* stats_partial,
-                            const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail,
+                            const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_out_bounds* tail,
                             void* stream);
 
 /* fp16x3 variant: x * s = h1 + h2 on TWO fp16 planes after a power-of-two scale, three MFMAs per product (error vs
@@ -260,11 +245,11 @@ int dsnt_conv_fwd_f16x3_ex(const float* x, const void* w_planes, int64_t plane_s
                            const float* a_bound, const float* bias, float* y, const float* in_scale,
                            const float* in_shift, int in_relu, const float* res1, const float* res2,
                            float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
-                           const dsnt_bn_tail* tail, void* stream);
+                           const dsnt_out_bounds* tail, void* stream);
 /* The same call for a 3x3 / stride 1 / pad 1 convolution whose weight planes are in the STREAM layout of
  * dsnt_f16_prep_weights (row flag): the symmetric persistent kernel of csrc/conv3s.hip (cuDNN's 3x3 forward / data gradient of
  * /root/reference/src/dsnt/hourglass.py:22-23).  Needs dsnt_conv_fwd_stream_ok(g) (H % 4 == 0 and W % 32 == 0, or H % 8 == 0 and
- * W % 16 == 0; Cin % 32 == 0 and <= 128, Cout 64 or 128, tensors < 2 GiB), res2 == NULL and no ticket counters in `tail`; DSNT_ERR_SHAPE otherwise.  The
+ * W % 16 == 0; Cin % 32 == 0 and <= 128, Cout 64 or 128, tensors < 2 GiB) and res2 == NULL; DSNT_ERR_SHAPE otherwise.  The
  * convolution sums are bit-identical to dsnt_conv_fwd_f16x3_ex's; stats_partial rows are one per 128-pixel patch (4 x 32, or 8 x 16 when W % 32 != 0): [N * H * W / 128][2][Cout].
  * in_relu (this entry point and dsnt_conv_fwd_f16x3_ex): bit 0 = ReLU in the prologue; bit 1 (DSNT_CONV_SHARE_CHIP): the launch runs on
  * a stream of its own beside other work — the persistent kernels (3x3 stream kernel, streaming 1x1 kernel) then start fewer
@@ -274,7 +259,7 @@ int dsnt_conv_fwd_f16x3_stream(const float* x, const void* w_planes, int64_t pla
                                const float* a_bound, const float* bias, float* y, const float* in_scale,
                                const float* in_shift, int in_relu, const float* res1, const float* res2,
                                float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
-                               const dsnt_bn_tail* tail, void* stream);
+                               const dsnt_out_bounds* tail, void* stream);
 int dsnt_conv_fwd_stream_ok(const dsnt_conv_geom* g);
 /* out[0..63] = bound slots whose maximum is max |src[i]|; dst = two fp16 planes (plane_stride elements apart) of src * pow2(bound). */
 int dsnt_amax(const float* src, int64_t n, float* out, void* stream);
@@ -457,7 +442,7 @@ int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M, int C,
 /* The same, and the bound of dx = scale (dz - coef0 - xhat coef1) for dsnt_conv1x1_bwd_f16x3, which forms dx in registers and
  * needs its fp16x3 scale beforehand: max_c |scale_c| (max|dz| + |coef0_c| + |coef1_c| sqrt(M)) raised into bound_out (64 slots,
  * zeroed by the caller once per step); scale = the BatchNorm's forward scale (gamma * invstd), dz_amax = the 64-slot max |dz| the
- * data-gradient launch left through dsnt_bn_tail.amax.  hourglass.py:21,36-37 (bn2 of a Bottleneck, backward). */
+ * data-gradient launch left through dsnt_out_bounds.amax.  hourglass.py:21,36-37 (bn2 of a Bottleneck, backward). */
 int dsnt_bn_bwd_finalize_bound(const float* partial, int ntiles, int64_t M, int C, float* dgamma, float* dbeta,
                                int accumulate, float* coef, const float* scale, const float* dz_amax, float* bound_out,
                                void* stream);
@@ -515,10 +500,10 @@ int dsnt_zero_insert(const float* dy, float* out, int N, int Ho, int Wo, int C, 
  * copy of dy nor the multiplications by its zeros exist: 1 / stride^2 of the work of dsnt_zero_insert + dsnt_conv_fwd,
  * which it replaces in the engine.  Exact fp32 (v_mfma_f32_32x32x2_f32).  Optional epilogues, as dsnt_conv_fwd_ex:
  * res1 (may alias dx), or bnb + stats_partial ([dsnt_conv_dgrad_strided_tiles(g)][2][Cin], every row written),
- * or tail->amax (the other dsnt_bn_tail fields must be unset).  Replaces cuDNN's backward-data of the torchvision ResNet
+ * or tail->amax (the other dsnt_out_bounds fields must be unset).  Replaces cuDNN's backward-data of the torchvision ResNet
  * stride-2 convolutions (conv1, layerN[0].conv1 / .conv2, downsample[0]) consumed by /root/reference/src/dsnt/model.py:103-121. */
 int dsnt_conv_dgrad_strided(const float* dy, const float* wd, float* dx, const float* res1, float* stats_partial,
-                            const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_bn_tail* tail, void* stream);
+                            const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_out_bounds* tail, void* stream);
 int dsnt_conv_dgrad_strided_ok(const dsnt_conv_geom* g);
 int dsnt_conv_dgrad_strided_tiles(const dsnt_conv_geom* g);
 
@@ -534,21 +519,21 @@ int dsnt_upsample2_bwd(const float* dout, float* dlow, int accumulate,
  * stored result would give (bit-identical), M = output pixels.  partial may be NULL (eval mode: no statistics;
  * tail->amax / amax_bn can still ask for the next convolution's fp16x3 operand bound). */
 int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* partial, int N, int H, int W, int C,
-                            const dsnt_bn_tail* tail, void* stream);
+                            const dsnt_out_bounds* tail, void* stream);
 int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, float* out, float* partial, int N, int H, int W,
-                                 int C, const dsnt_bn_tail* tail, void* stream);
+                                 int C, const dsnt_out_bounds* tail, void* stream);
 /* y = relu?(x * scale + shift) (dsnt_bn_act_fwd: the stem's materialised BatchNorm + ReLU, hourglass.py:157-159) with the
  * statistics of y in the same pass — the first Bottleneck's BatchNorm reads y next — and, through tail->amax / amax_bn, the
  * fp16x3 bound of the skip projection that reads y raw.  partial: [ceil(M/128)][2][C], may be NULL. */
 int dsnt_bn_act_fwd_stats(const float* x, const float* scale, const float* shift, int relu, float* y, float* partial,
-                          int64_t M, int C, const dsnt_bn_tail* tail, void* stream);
+                          int64_t M, int C, const dsnt_out_bounds* tail, void* stream);
 
 /* The 7x7 / stride 2 / pad 3 stem convolution on a C <= 4 channel image (hourglass.py:106; torchvision resnet conv1) as a
  * 4x4 / stride 1 / pad 1 convolution: dsnt_s2d_input writes the image as [N][H/2+1][W/2+1][16] (2x2 pixel blocks -> 16 channels,
  * one zero block row / column in front; tail->amax, if given, receives max|image| as the fp16x3 operand bound);
  * dsnt_s2d_weights re-packs OHWI [Cout][7][7][4] weights into [Cout][4][4][16] (back = 0) or gathers a [Cout][4][4][16] weight
  * gradient back into [Cout][7][7][4] (back = 1).  Any convolution entry point then runs the stem with K = 256. */
-int dsnt_s2d_input(const float* src_nchw, float* dst, int N, int C, int H, int W, const dsnt_bn_tail* tail, void* stream);
+int dsnt_s2d_input(const float* src_nchw, float* dst, int N, int C, int H, int W, const dsnt_out_bounds* tail, void* stream);
 int dsnt_s2d_weights(const float* w, float* w2, int Cout, int back, void* stream);
 /* dsnt_s2d_weights (back = 0) + the filter's maximum (bound[64]) + its two fp16 planes (scaled as dsnt_split_f16x2 does,
  * plane stride Cout*256) + its three bf16 planes (dsnt_split_bf16x3 layout) in one launch; w2 (fp32 copy) may be NULL. */

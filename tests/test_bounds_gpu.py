@@ -166,7 +166,7 @@ def test_nonfinite_guard_blocks_the_update_and_reports_asynchronously():
 
 def test_eval_mode_fp16x3_bounds_come_from_the_producers():
     """Eval mode has no batch statistics to bound relu(bn(x)) analytically: the launch that produces x forms the
-    consumer's operand from the (running-statistics) BatchNorm vectors and leaves its maximum (dsnt_bn_tail.amax_bn).
+    consumer's operand from the (running-statistics) BatchNorm vectors and leaves its maximum (dsnt_out_bounds.amax_bn).
     Walk a batch-8 eval forward of hg2: every fp16x3 launch's A bound equals max|operand| at that moment (to fp32
     rounding) and most large convolutions are on fp16x3."""
     from dsnt.model import build_mpii_pose_model

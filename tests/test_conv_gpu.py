@@ -910,29 +910,16 @@ BNB_CASES = [
 ]
 
 
-def _make_tail(mode, tiles, Cc, dev, **fields):
-    """A dsnt_bn_tail with its tickets and scratch; returns (struct, keep-alive tensors)."""
-    from dsnt import _lib
-    grp = _lib.fn('dsnt_bn_tail_group')()
-    groups = (tiles + grp - 1) // grp
-    counters = torch.zeros(1 + groups, dtype=torch.int32, device=dev)
-    level2 = torch.empty(groups * 2 * Cc, dtype=torch.float64, device=dev)
-    t = _lib.BnTail()
-    t.mode, t.counters, t.level2 = mode, counters.data_ptr(), level2.data_ptr()
-    for k, v in fields.items():
-        setattr(t, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
-    return t, (counters, level2)
-
-
 @pytest.mark.parametrize('case', BNB_CASES)
 @pytest.mark.parametrize('path', ['f32', 'bf16x6', 'f16x3'])
-@pytest.mark.parametrize('use_tail', [False, True])
-def test_bn_backward_epilogue_with_relu_vs_autograd(case, path, use_tail):
+@pytest.mark.parametrize('with_amax', [False, True])
+def test_bn_backward_epilogue_with_relu_vs_autograd(case, path, with_amax):
     """ONE layer x -> BatchNorm(train) -> ReLU -> conv, backward through the production chain with the ReLU ON:
     data-gradient launch with the BN-backward epilogue (ReLU mask + the two per-channel sums) -> finalise ->
     apply, against torch autograd (fp64).  A single layer has no flip amplification, so the bars are tight
     (2e-5 of the scale, as for the plain convolutions): inputs are nudged so that no pre-activation sits within
-    5e-4 of the ReLU kink, where two fp32 evaluations may legitimately disagree."""
+    5e-4 of the ReLU kink, where two fp32 evaluations may legitimately disagree.  with_amax: the launch also leaves max|dz|
+    (dsnt_out_bounds.amax beside the epilogue: what dsnt_bn_bwd_finalize_bound makes the bound of a folded BatchNorm backward from)."""
     from dsnt import _lib
     from dsnt._lib import ptr, call, BnBwdEpilogue
     N, H, W, Cin, Cout, k = case
@@ -979,9 +966,10 @@ def test_bn_backward_epilogue_with_relu_vs_autograd(case, path, use_tail):
     dgamma, dbeta = torch.empty(Cin, device=dev), torch.empty(Cin, device=dev)
     coef = torch.empty(2, Cin, device=dev)
     bm = _lib.fn('dsnt_conv_fwd_bm')(C.byref(g)) if path == 'f32' else 128
-    tail, keep = None, None
-    if use_tail:        # the launch's last workgroup writes dgamma / dbeta / coef itself (csrc/bn_tail.h)
-        tail_s, keep = _make_tail(1, (M + bm - 1) // bm, Cin, dev, out0=dgamma, out1=dbeta, out2=coef)
+    tail, dz_amax = None, torch.zeros(64, device=dev)
+    if with_amax:
+        tail_s = _lib.BnTail()
+        tail_s.amax = dz_amax.data_ptr()
         tail = C.byref(tail_s)
     if path == 'f32':
         tiles_d = (M + bm - 1) // bm
@@ -1013,12 +1001,16 @@ def test_bn_backward_epilogue_with_relu_vs_autograd(case, path, use_tail):
     s_dz = dz_ref.abs().max().item()
     assert (dz.cpu().permute(0, 3, 1, 2).double() - dz_ref).abs().max().item() <= tol * s_dz
     assert float((dz == 0).float().mean()) > 0.2          # the mask really is on
-    if use_tail:
-        assert int(keep[0].abs().max()) == 0               # every ticket counter is back at zero
+    if with_amax:
+        # max|dz| exactly, and the finalise launch that also leaves the bound of dx = scale (dz - c0 - xhat c1): it dominates dx
+        assert float(dz_amax.max()) == float(dz.abs().max())
+        bound = torch.zeros(64, device=dev)
+        call('dsnt_bn_bwd_finalize_bound', ptr(part_d), tiles_d, M, Cin, ptr(dgamma), ptr(dbeta), 0, ptr(coef), ptr(scale),
+             ptr(dz_amax), ptr(bound))
         ref = [torch.empty_like(dgamma), torch.empty_like(dbeta), torch.empty_like(coef)]
         call('dsnt_bn_bwd_finalize', ptr(part_d), tiles_d, M, Cin, ptr(ref[0]), ptr(ref[1]), 0, ptr(ref[2]))
-        for got_, want_ in zip((dgamma, dbeta, coef), ref):      # same sums as the stand-alone launch (fp64, other order)
-            assert (got_ - want_).abs().max().item() <= 1e-6 * max(1.0, want_.abs().max().item())
+        for got_, want_ in zip((dgamma, dbeta, coef), ref):
+            assert torch.equal(got_, want_)
     else:
         call('dsnt_bn_bwd_finalize', ptr(part_d), tiles_d, M, Cin, ptr(dgamma), ptr(dbeta), 0, ptr(coef))
     dx = torch.empty(N, H, W, Cin, device=dev)
@@ -1028,6 +1020,8 @@ def test_bn_backward_epilogue_with_relu_vs_autograd(case, path, use_tail):
     assert (dbeta.cpu().double() - br.grad).abs().max().item() <= tol * max(1.0, br.grad.abs().max().item())
     s_dx = xr.grad.abs().max().item()
     assert (dx.cpu().permute(0, 3, 1, 2).double() - xr.grad).abs().max().item() <= tol * s_dx
+    if with_amax:
+        assert float(dx.abs().max()) <= float(bound.max()) <= 4096.0 * float(dx.abs().max())
 
 
 @pytest.mark.parametrize('shape', [(2, 8, 8, 128, 128, 3), (2, 8, 8, 256, 128, 1), (4, 16, 16, 128, 256, 1), (2, 4, 4, 128, 128, 3)],
@@ -1100,98 +1094,11 @@ def test_batchnorm_finalised_in_the_consumers_prologue(shape):
             assert (a_ - b_).abs().max().item() <= 2e-6 * max(1.0, b_.abs().max().item())
 
 
-@pytest.mark.parametrize('kind', ['conv_f32_128', 'conv_f32_32x128', 'conv_ksplit', 'conv_bf16x6', 'conv_halo_f16x3',
-                                  'maxpool', 'upsample'])
-def test_bn_tail_forward_matches_the_finalize_launch(kind):
-    """Forward statistics finished by the producer's last workgroup (dsnt_bn_tail mode 0) == dsnt_bn_finalize over the
-    same partial sums: mean / invstd / scale / shift and the running statistics, for every kind of producer; a second
-    launch (tickets must have re-armed themselves) gives bit-identical vectors and moves the running statistics on."""
-    from dsnt import _lib
-    from dsnt._lib import ptr, call
-    dev = torch.device('cuda:0')
-    shapes = {'conv_f32_128': (4, 32, 32, 64, 128, 3), 'conv_f32_32x128': (2, 16, 16, 128, 256, 1),
-              'conv_ksplit': (2, 8, 8, 128, 128, 3), 'conv_bf16x6': (4, 64, 64, 128, 256, 1),
-              'conv_halo_f16x3': (8, 64, 64, 128, 128, 3), 'maxpool': (6, 32, 32, 0, 256, 0), 'upsample': (6, 32, 32, 0, 256, 0)}
-    N, H, W, Cin, Cout, k = shapes[kind]
-    gamma = (synthetic.tensor('bt.g', (Cout,), seed=50, kind='uniform') + 1.5).to(dev)
-    beta = (synthetic.tensor('bt.b', (Cout,), seed=50) * 0.2).to(dev)
-
-    def run(tail):
-        """launch the producer with `tail` (or None); returns (partials, tiles, M)"""
-        if kind.startswith('conv'):
-            g = _geom(N, H, W, Cin, Cout, k, k, 1, k // 2, 1)
-            x = synthetic.tensor('bt.x', (N, H, W, Cin), seed=51).to(dev)
-            w = (synthetic.tensor('bt.w', (Cout, k, k, Cin), seed=51) * 0.05).to(dev)
-            b = (synthetic.tensor('bt.bias', (Cout,), seed=51) * 0.1).to(dev)
-            y = torch.empty(N, H, W, Cout, device=dev)
-            M = N * H * W
-            bm = _lib.fn('dsnt_conv_fwd_bm')(C.byref(g)) if 'f32' in kind or kind == 'conv_ksplit' else 128
-            tiles = (M + bm - 1) // bm
-            part = torch.zeros(tiles, 2, Cout, device=dev)
-            if kind in ('conv_f32_128', 'conv_f32_32x128', 'conv_ksplit'):
-                call('dsnt_conv_fwd_ex', ptr(x), ptr(w), ptr(b), ptr(y), None, None, 0, None, None, ptr(part), C.byref(g),
-                     None, tail)
-            elif kind == 'conv_bf16x6':
-                planes = torch.empty(3 * w.numel(), dtype=torch.bfloat16, device=dev)
-                call('dsnt_split_bf16x3', ptr(w), ptr(planes), w.numel())
-                call('dsnt_conv_fwd_bf16x6_ex', ptr(x), ptr(planes), w.numel(), ptr(b), ptr(y), None, None, 0, None, None,
-                     ptr(part), C.byref(g), None, tail)
-            else:
-                wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
-                call('dsnt_amax', ptr(w), w.numel(), ptr(wb))
-                call('dsnt_amax', ptr(x), x.numel(), ptr(ab))
-                planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
-                call('dsnt_split_f16x2', ptr(w), ptr(planes), w.numel(), w.numel(), ptr(wb))
-                call('dsnt_conv_fwd_f16x3_ex', ptr(x), ptr(planes), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), None, None,
-                     0, None, None, ptr(part), C.byref(g), None, tail)
-            torch.cuda.synchronize()
-            return part, tiles, M
-        x = synthetic.tensor('bt.px', (N, H, W, Cout), seed=52).to(dev)
-        if kind == 'maxpool':
-            M = N * (H // 2) * (W // 2)
-            tiles = (M + 127) // 128
-            part = torch.zeros(tiles, 2, Cout, device=dev)
-            y = torch.empty(N, H // 2, W // 2, Cout, device=dev)
-            idx = torch.empty(N, H // 2, W // 2, Cout, dtype=torch.uint8, device=dev)
-            call('dsnt_maxpool2_fwd_stats', ptr(x), ptr(y), ptr(idx), ptr(part), N, H, W, Cout, tail)
-        else:
-            M = N * H * W
-            tiles = (M + 127) // 128
-            part = torch.zeros(tiles, 2, Cout, device=dev)
-            low = synthetic.tensor('bt.low', (N, H // 2, W // 2, Cout), seed=53).to(dev)
-            y = torch.empty(N, H, W, Cout, device=dev)
-            call('dsnt_upsample2_add_fwd_stats', ptr(x), ptr(low), ptr(y), ptr(part), N, H, W, Cout, tail)
-        torch.cuda.synchronize()
-        return part, tiles, M
-
-    part0, tiles, M = run(None)
-    want = [torch.empty(Cout, device=dev) for _ in range(4)]
-    rm_w, rv_w = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-    call('dsnt_bn_finalize', ptr(part0), tiles, M, Cout, ptr(gamma), ptr(beta), ptr(rm_w), ptr(rv_w), 0.1, 1e-5, 1,
-         *(ptr(v) for v in want))
-    got = [torch.full((Cout,), float('nan'), device=dev) for _ in range(4)]
-    rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-    tail_s, keep = _make_tail(0, tiles, Cout, dev, gamma=gamma, beta=beta, running_mean=rm, running_var=rv,
-                              momentum=0.1, eps=1e-5, out0=got[0], out1=got[1], out2=got[2], out3=got[3])
-    part1, _, _ = run(C.byref(tail_s))
-    assert torch.equal(part0, part1) and int(keep[0].abs().max()) == 0
-    for a, b, nm in zip(got, want, ('mean', 'invstd', 'scale', 'shift')):
-        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), (kind, nm)
-    assert (rm - rm_w).abs().max().item() <= 1e-6 and (rv - rv_w).abs().max().item() <= 1e-6 * max(1.0, float(rv_w.max()))
-    first = [g_.clone() for g_ in got]
-    rm1 = rm.clone()
-    for g_ in got:
-        g_.fill_(float('nan'))
-    run(C.byref(tail_s))                                   # tickets re-armed themselves
-    assert all(torch.equal(a, b) for a, b in zip(got, first)) and int(keep[0].abs().max()) == 0
-    assert (rm - (0.9 * rm1 + 0.1 * first[0])).abs().max().item() <= 1e-6
-
-
 @pytest.mark.parametrize('path', ['f32', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('k,with_res,N', [(1, True, 2), (3, False, 2), (1, True, 64)],
                          ids=['k1_res', 'k3', 'k1_res_65536rows'])
 def test_epilogue_leaves_the_bound_of_its_output(path, k, with_res, N):
-    """dsnt_bn_tail.amax: the launch raises a 64-slot bound to max|y| of what it wrote (bias and residual included) —
+    """dsnt_out_bounds.amax: the launch raises a 64-slot bound to max|y| of what it wrote (bias and residual included) —
     the fp16x3 operand bound of a consumer that reads y raw (skip projections / `lin` convolutions,
     hourglass.py:45-48,120-135).  Exactly the maximum (a max is order-independent), never lowered, and a second
     launch into the same slots keeps the larger value."""

@@ -100,7 +100,7 @@ def test_eval_forward_shards_like_replicas(setup):
             half = x.shape[0] // 2
             halves = torch.cat([m(x[:half])[-1].clone(), m(x[half:])[-1].clone()])
         # not bit-identical: eval-mode fp16x3 scales its operands by a power of two taken from the batch's own maximum
-        # (dsnt_bn_tail.amax_bn), and the 16x16 level of a 16-image shard (4096 rows) falls below the split-precision row
+        # (dsnt_out_bounds.amax_bn), and the 16x16 level of a 16-image shard (4096 rows) falls below the split-precision row
         # threshold (8192) that the whole batch passes; both are fp32-rounding-level effects on coordinates in [-1, 1]
         # (measured: 2e-6 .. 6e-6 at batch 32; 6e-6 .. 1.4e-5 at batch 256, where the shards also differ in which 1x1 kernel
         # the 32x32 level runs on)

@@ -583,46 +583,9 @@ def test_data_parallel_world1_nccl():
         dist.destroy_process_group()
 
 
-def test_bn_tails_give_the_same_step(monkeypatch):
-    """BatchNorm finalisation folded into the producers' last workgroup (DSNT_BN_TAIL_ROWS, csrc/bn_tail.h) against the
-    stand-alone finalise launches: same loss / coordinates / gradients to fp32 rounding (the fp64 partial sums are added
-    in another order), ~190 launches fewer, bit-reproducible."""
-    from dsnt.model import build_mpii_pose_model
-
-    monkeypatch.setenv('DSNT_FUSE_FINALIZE', '0')          # the baseline: every BatchNorm finalised by its own launch
-    monkeypatch.setenv('DSNT_OFF', 'conv3s')                # (the persistent 3x3 kernel carries no tail: same kernels on both sides)
-
-    def step(rows):
-        monkeypatch.setenv('DSNT_BN_TAIL_ROWS', str(rows))
-        m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
-        synthetic.fill_state_dict(m, seed=0)
-        m.cuda().train()
-        x, t, k = synthetic.batch(4, size=128, seed=1, mask_p=0.9)
-        res = []
-        for _ in range(2):
-            for p in m.parameters():
-                p.grad = None
-            out = m(x.to(DEV))
-            loss = m.forward_loss(out, t.to(DEV), k.to(DEV))
-            loss.backward()
-            res.append((loss.item(), out[-1].detach().clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()))
-        prog = [p for p in m.hg._runner().programs.values() if p.training][0]
-        rs = {n: b.clone() for n, b in m.named_buffers() if 'running' in n}
-        return res, prog.n_fwd + prog.n_bwd, rs
-    (a0, a1), n_a, rs_a = step(0)
-    (b0, b1), n_b, rs_b = step(10 ** 9)
-    assert n_a - n_b >= 150, (n_a, n_b)
-    assert abs(a0[0] - b0[0]) <= 1e-6 * abs(a0[0]) and (a0[1] - b0[1]).abs().max().item() <= 2e-6
-    assert (a0[2] - b0[2]).norm().item() <= 1e-4 * a0[2].norm().item()
-    for n in rs_a:
-        assert (rs_a[n] - rs_b[n]).abs().max().item() <= 1e-5 * max(1.0, rs_a[n].abs().max().item()), n
-    # the two forward/backward passes of each model differ only through the running statistics (not used in train mode)
-    assert b0[0] == b1[0] and torch.equal(b0[1], b1[1]) and torch.equal(b0[2], b1[2])
-
-
 def test_finalisation_in_the_consumers_prologue_gives_the_same_step(monkeypatch):
     """BatchNorm finalisation of few-tile statistics folded into the prologue of the consuming launch (the default:
-    dsnt_conv_fwd_pro / dsnt_bn_act_bwd_apply_pro, csrc/bn_tail.h) against the stand-alone finalise launches
+    dsnt_conv_fwd_pro / dsnt_bn_act_bwd_apply_pro, csrc/bn_pro.h) against the stand-alone finalise launches
     (DSNT_FUSE_FINALIZE=0): same loss / coordinates / gradients / running statistics to fp32 rounding (the fp64 sums are
     added in another order), fewer launches, bit-reproducible."""
     from dsnt.model import build_mpii_pose_model

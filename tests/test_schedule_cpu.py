@@ -146,7 +146,7 @@ def _trace(monkeypatch_module, base, training, shape, **kw):
 def test_eval_mode_schedule_of_hg2(monkeypatch_module):
     """Inference (inference.py:33-48): no backward list, every BatchNorm's vectors from ONE table-driven launch, no
     finalise launches, no statistics passes, the side lane still carries the skip branches; the large convolutions run
-    fp16x3 with bounds their producers leave (dsnt_bn_tail.amax_bn), so the forward list starts by zeroing them."""
+    fp16x3 with bounds their producers leave (dsnt_out_bounds.amax_bn), so the forward list starts by zeroing them."""
     tape = _trace(monkeypatch_module, 'hg2', False, (32, 3, 256, 256), reg='none')
     fwd = _launches(tape.fwd)
     names = [n for n, _, _ in fwd]

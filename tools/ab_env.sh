@@ -5,6 +5,6 @@ for spec in "$@"; do
   label=${spec%%:*}; vars=${spec#*:}
   for rep in 1 2; do
     ( IFS=','; for kv in $vars; do [ -n "$kv" ] && export "$kv"; done
-      printf '%-28s ' "$label"; timeout -k 10 200 python3 tools/train_loop.py 30 | tail -1 ) || exit 1
+      printf '%-28s ' "$label"; timeout -k 10 200 python3 tools/train_loop.py ${AB_STEPS:-30} ${AB_BATCH:-32} ${AB_BASE:-hg2} | tail -1 ) || exit 1
   done
 done

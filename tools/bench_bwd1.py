@@ -25,7 +25,7 @@ def timeit(fn, iters=20):
 
 
 for (H, Cin, Cout, apply) in [(64, 256, 128, True), (64, 128, 256, False), (64, 128, 128, True), (32, 256, 128, True),
-                              (32, 128, 256, False), (128, 64, 64, True), (128, 64, 128, False), (64, 256, 256, False)]:
+                              (32, 128, 256, False), (128, 64, 64, True), (128, 64, 128, False), (64, 256, 256, False), (16, 256, 128, True), (16, 128, 256, False)]:
     M = B * H * H
     g = ConvGeom(B, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1)
     gd = ConvGeom(B, H, H, Cout, H, H, Cin, 1, 1, 1, 0, 1)

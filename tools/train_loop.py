@@ -1,4 +1,4 @@
-"""Bare train loop (no bench extras) for rocprofv3: python3 tools/train_loop.py [steps] [batch]"""
+"""Bare train loop (no bench extras) for rocprofv3: python3 tools/train_loop.py [steps] [batch] [base: hg2 | hg8 | hg1]"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +8,8 @@ from dsnt import synthetic, optim
 dev = torch.device('cuda:0')
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-model = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+base = sys.argv[3] if len(sys.argv) > 3 else 'hg2'
+model = build_mpii_pose_model(base=base, output_strat='dsnt', reg='js')
 synthetic.fill_state_dict(model, seed=0)
 model.cuda().train()
 x, target, mask = synthetic.batch(batch, size=256, seed=1, mask_p=1.0)
@@ -29,4 +30,4 @@ t0 = time.perf_counter()
 for _ in range(steps):
     step()
 torch.cuda.synchronize()
-print('%.3f ms/step over %d steps (+2 warm-up), batch %d' % (1e3 * (time.perf_counter() - t0) / steps, steps, batch))
+print('%.3f ms/step over %d steps (+2 warm-up), batch %d, %s' % (1e3 * (time.perf_counter() - t0) / steps, steps, batch, base))
