@@ -2378,12 +2378,16 @@ static int64_t wgrad_ws_floats_plain(const dsnt_conv_geom* g) {
 }
 // Enough for ANY of the weight-gradient entry points on this geometry (the fp16x3 kernels of wgrad3.hip / wgrad1.hip cut
 // the pixels into their own, sometimes more, slabs: dsnt_conv_wgrad_f16x3_ws_floats is the exact size of that call)
+// `accumulate` flags -> the halo kernel's plan: 0 whole chip, 1 DSNT_WGRAD_SHARE_CHIP, 2 with DSNT_WGRAD_NARROW on top
+static inline int wg3_share(int accumulate) {
+    return (accumulate & DSNT_WGRAD_SHARE_CHIP) ? ((accumulate & DSNT_WGRAD_NARROW) ? 2 : 1) : 0;
+}
 extern "C" int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g) {
     if (!g) return 0;
     int64_t n = wgrad_ws_floats_plain(g);
     const int64_t per = (int64_t)g->Cout * (g->R * g->S * g->Cin) + g->Cout;
     for (int share = 0; share < 2; ++share) {
-        const Wg3Plan p3 = dsnt_wg3_plan(g, share != 0);
+        const Wg3Plan p3 = dsnt_wg3_plan(g, share);
         if (p3.ok && p3.nslabs * per > n) n = p3.nslabs * per;
         const Wg1Plan p1 = dsnt_wg1_plan(g, share != 0);
         if (p1.ok && p1.nsplits * per > n) n = p1.nsplits * per;
@@ -2488,7 +2492,7 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
                  "dsnt_conv_wgrad_f16x3: geometry not supported (need Wo %% 4 == 0, tensors < 2 GiB)");
     DSNT_REQUIRE(a_bound && g_bound, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: both operand bounds are required");
     // 3x3 / stride 1 convolutions: the halo kernel (wgrad3.hip) — every operand element staged once for all nine taps
-    const Wg3Plan pl = dsnt_wg3_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
+    const Wg3Plan pl = dsnt_wg3_plan(g, wg3_share(accumulate));
     if (pl.ok) {
         if (int e = check_geom(g, "dsnt_conv_wgrad_f16x3")) return e;
         DSNT_REQUIRE(x && dy && ws, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: null tensor");
@@ -2499,7 +2503,7 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
                      DSNT_ERR_ALIGN, "dsnt_conv_wgrad_f16x3: tensors must be 16-byte aligned");
         hipStream_t st = (hipStream_t)stream;
         dsnt_wg3_launch(pl, x, in_scale, in_shift, in_relu, dy, ws, a_bound, g_bound, g, st,
-                        (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
+                        wg3_share(accumulate));
         if (dw) {
             const int CK = g->Cout * 9 * g->Cin;
             const int total = CK / 4 + (g->Cout + 3) / 4;
@@ -2536,20 +2540,20 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
 // equal to dsnt_conv_wgrad_splits / _ws_floats where the implicit-GEMM kernel runs.
 extern "C" int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g, int accumulate) {
     if (!g) return 0;
-    const Wg3Plan pl = dsnt_wg3_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
+    const Wg3Plan pl = dsnt_wg3_plan(g, wg3_share(accumulate));
     if (pl.ok) return pl.nslabs;
     const Wg1Plan p1 = dsnt_wg1_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
     return p1.ok ? p1.nsplits : dsnt_conv_wgrad_splits(g);
 }
 extern "C" int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate) {
     if (!g) return 0;
-    const Wg3Plan pl = dsnt_wg3_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
+    const Wg3Plan pl = dsnt_wg3_plan(g, wg3_share(accumulate));
     if (pl.ok) return (int64_t)pl.nslabs * g->Cout * (9 * g->Cin) + (int64_t)pl.nslabs * g->Cout;
     const Wg1Plan p1 = dsnt_wg1_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
     if (p1.ok) return (int64_t)p1.nsplits * g->Cout * g->Cin + (int64_t)p1.nsplits * g->Cout;
     return wgrad_ws_floats_plain(g);
 }
-extern "C" int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g) { return g ? dsnt_wg3_plan(g, false).ok : 0; }
+extern "C" int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g) { return g ? dsnt_wg3_plan(g, 0).ok : 0; }
 
 static int conv_wgrad_impl(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                            const float* dy, float* ws, float* dw, float* dbias, int accumulate,

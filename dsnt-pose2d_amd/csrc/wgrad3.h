@@ -19,12 +19,12 @@ struct Wg3Plan {
     int lds;            // dynamic LDS bytes
 };
 // share = DSNT_WGRAD_SHARE_CHIP: the plan of a launch that runs beside a dependency chain (fewer, longer slabs)
-Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, bool share);
+Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, int share);      // share: 0 whole chip, 1 beside a chain, 2 the same, narrower
 // enqueue (or record) the launch; tensors as dsnt_conv_wgrad_f16x3 (in_scale / in_shift may be null); share =
 // DSNT_WGRAD_SHARE_CHIP: the launch runs beside a dependency chain on another stream
 void dsnt_wg3_launch(const Wg3Plan& pl, const float* x, const float* in_scale, const float* in_shift, int in_relu,
                      const float* dy, float* ws, const float* a_bound, const float* g_bound, const dsnt_conv_geom* g,
-                     hipStream_t st, bool share);
+                     hipStream_t st, int share);
 
 // ---- 1x1 weight gradients (wgrad1.hip): a four-wave workgroup owns ck x cn channels of the weight matrix for its pixels
 struct Wg1Plan {

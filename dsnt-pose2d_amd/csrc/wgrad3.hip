@@ -301,7 +301,7 @@ __global__ __launch_bounds__(CFG == 2 ? 256 : 512, 2) void wgrad3_kernel(Wg3P p)
 
 static int enabled = -1, min_steps = 0, small_wg = 1;
 
-Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, bool share) {
+Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, int share) {
     Wg3Plan pl;
     memset(&pl, 0, sizeof(pl));
     // tuning constants (measured on MI355X, hg2 batch 32): 256 workgroups = one per CU; at least 32 16-pixel steps per
@@ -332,7 +332,13 @@ Wg3Plan dsnt_wg3_plan(const dsnt_conv_geom* g, bool share) {
     const long per = (long)pl.kchunks * pl.nchunks * pl.strips * g->N;
     // (a launch that shares the chip runs as four-wave workgroups of 32 channels, ONE per CU: twice the workgroups per
     // slab, so half as many slabs fill the chip — and half the slab bytes are written and reduced)
-    const long want = (share && small_wg && pl.cfg == 0) ? target / 2 : target;
+    // share == 2 (DSNT_WGRAD_NARROW): half as many slabs again — 128 four-wave workgroups.  In the middle of backward the
+    // weight-gradient lane has slack since the 1x1 weight gradients left it (bwd1.hip), and a 3x3 weight gradient on half of
+    // the CUs takes less from the dependency chain's kernels beside it (same box, hg2 batch 32: 12.53 -> 12.27 ms/step,
+    // 12.09 -> 11.93 on a second one; and half the slab bytes); NOT at the end of backward, where nothing runs beside the
+    // stem's weight gradients and their duration is the step's (hg8 batch 16 with every launch narrow: +0.4 ms)
+    long want = (share && small_wg && pl.cfg == 0) ? target / 2 : target;
+    if (share == 2) want /= 2;
     while (per * (g->H / rps) < want && rps % 2 == 0 && (rps / 2) * (WS / 16) >= min_steps) rps /= 2;
     pl.rps = rps;
     pl.hsplits = g->H / rps;
@@ -360,7 +366,7 @@ static void wg3_launch_cfg(const Wg3Plan& pl, const Wg3P& p, hipStream_t st) {
 
 void dsnt_wg3_launch(const Wg3Plan& pl, const float* x, const float* in_scale, const float* in_shift, int in_relu,
                      const float* dy, float* ws, const float* a_bound, const float* g_bound, const dsnt_conv_geom* g,
-                     hipStream_t st, bool share) {
+                     hipStream_t st, int share) {
     Wg3P p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.dy = dy; p.ws = ws;

@@ -128,6 +128,10 @@ class Tape:
         # the CUs): both hold most of a CU's LDS for the whole launch, and the chain's kernels need LDS too (-0.2 ms)
         self.conv_share = True
         self.wgrad_share = True    # DSNT_WGRAD_SHARE_CHIP on every launch of that lane (-0.2 ms)
+        # DSNT_X=<name>=<value>,...: A/B overrides of scheduling constants (tools/ab_env.sh); not product switches
+        self._x = dict(kv.split('=') for kv in os.environ.get('DSNT_X', '').split(',') if '=' in kv)
+        self.wgrad_narrow = self._x.get('wgrad_narrow', '1')      # DSNT_WGRAD_NARROW: 0 never, 1 always, 2 stem bucket only, 3 stacks only
+        self.cur_bucket = 0         # parameter bucket of the layers being traced (mark_bucket)
         self._wgrad_lane_reads = set()
         # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
         # phase: a `release point` is the backward of an up-sampling whose low-resolution operand has at most
@@ -510,6 +514,7 @@ class Tape:
     def mark_bucket(self, k):
         """Forward position where parameter bucket k starts being used: in the (reversed) backward
         list the marker lands right after the last launch that writes bucket k's gradients."""
+        self.cur_bucket = k
         if self.training:
             def mark():
                 lane, self.lane = self.lane, self._flush_lane()
@@ -856,6 +861,7 @@ class Tape:
             self.dgrad_total += (p.w.numel() + 7) // 8 * 8
         # the whole backward of this convolution as ONE launch (csrc/bwd1.hip): 1x1 behind a train-mode BatchNorm, both
         # operand bounds known on the device
+        bucket = self.cur_bucket
         fuse1 = bool(self.bwd1 and (normed or x_amax is not None) and self.use_f16x3 and self.defer_reduce and
                      slot is not None and p.R == 1 and p.S == 1 and p.post_reduce is None and
                      self.lib.dsnt_conv1x1_bwd_ok(C.byref(g)))
@@ -951,6 +957,10 @@ class Tape:
                 # DSNT_WGRAD_SHARE_CHIP: one workgroup per CU beside the chain — except for the first convolution of the
                 # network (no data gradient: it is the LAST launch of backward and has the chip to itself)
                 share = 2 if (wl != cur and self.wgrad_share and need_input_grad) else 0
+                # DSNT_WGRAD_NARROW for the hourglass stacks' 3x3 weight gradients: the lane has slack there (the 1x1 weight
+                # gradients left it), the stem's bucket is the tail of backward and keeps the wider plan
+                if share and self.wgrad_narrow in ('1', {0: '2'}.get(bucket, '3')):
+                    share |= 4
                 w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
                 if self.defer_reduce:
                     # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per

@@ -295,6 +295,9 @@ int dsnt_conv_pack_dgrad_all(const int* table, int nconv, const float* params, f
  * dw == NULL (and dbias == NULL): only the split-M partial slabs are written to `ws`; the caller keeps `ws`
  * alive and reduces later with dsnt_wgrad_reduce_all (one launch for many convolutions). */
 #define DSNT_WGRAD_SHARE_CHIP 2
+/* bit 2, with DSNT_WGRAD_SHARE_CHIP, 3x3 halo kernel: half as many slabs / workgroups again (128 four-wave workgroups) — for
+ * launches in the middle of backward, where the stream they run on has slack and the dependency chain beside them does not */
+#define DSNT_WGRAD_NARROW 4
 int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g);
 int dsnt_conv_wgrad(const float* x, const float* in_scale, const float* in_shift, int in_relu,
                     const float* dy, float* ws, float* dw, float* dbias, int accumulate,
