@@ -4,6 +4,7 @@
 # from the TCC counters (two --pmc passes).  Output under gpurun_out/<tag>_* (copy the summaries into profiles/).
 tag=${1:-r04}; base=${2:-hg2}; batch=${3:-32}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+if [ "$2" != "pmc" ]; then
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python3 tools/train_loop.py 8 $batch $base > gpurun_out/${tag}_prof_train.log 2>&1 || exit 1
 cp $(ls gpurun_out/prof_train/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_train_kernel_stats.csv
 python3 tools/prof_summary.py gpurun_out/${tag}_train_kernel_stats.csv 10 40 > gpurun_out/${tag}_train_summary.txt
@@ -18,3 +19,23 @@ done
 python3 tools/step_traffic.py $steps "$base + DSNT + JS, batch $batch" > gpurun_out/${tag}_step_traffic.txt
 rm -rf gpurun_out/st_FETCH_SIZE gpurun_out/st_WRITE_SIZE
 head -12 gpurun_out/${tag}_step_traffic.txt
+fi
+
+# PMC evidence of the round-4 kernel and the dominant one (tools/collect_profiles_r04.sh <tag> pmc): SQ issue accounting and HBM
+# traffic (FETCH_SIZE / WRITE_SIZE / L2 hit rate, one counter group per pass) of
+#   bwd1 (256 -> 128 with the folded BatchNorm backward, 128 -> 256 given) and conv3s (3x3 128->128 @64)
+if [ "$2" = "pmc" ]; then
+  for spec in "b1a:bwd1_kernel:bwd1a:64 256 128 1" "b1b:bwd1_kernel:bwd1:64 128 256 1" "c3s:conv3s:fwd16s:64 128 128 3"; do
+    IFS=':' read name kern mode geo <<< "$spec"
+    bash tools/pmc_sweep.sh ${tag}_$name $kern $mode $geo > /dev/null || exit 1
+    python3 tools/pmc_account.py gpurun_out/pmcs_${tag}_$name.txt "$kern ($mode $geo, batch 32)" > gpurun_out/${tag}_pmc_$name.txt
+    for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+      bash tools/pmc.sh ${tag}_t_$name $kern "$c" -- python3 tools/one_kernel.py $mode $geo | grep -v "^rc=" >> gpurun_out/${tag}_pmc_$name.txt
+      rm -rf gpurun_out/${tag}_t_$name gpurun_out/${tag}_t_$name.log
+    done
+    timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python3 tools/one_kernel.py $mode $geo > /dev/null 2>&1
+    grep -E "$kern" $(ls gpurun_out/ks/*/*kernel_stats.csv | head -1) | head -2 >> gpurun_out/${tag}_pmc_$name.txt
+    rm -rf gpurun_out/ks
+  done
+  cat gpurun_out/${tag}_pmc_*.txt
+fi

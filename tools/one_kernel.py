@@ -29,6 +29,24 @@ planes16s = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
 if k == 3 and _lib.fn('dsnt_conv_fwd_stream_ok')(C.byref(g)):
     tab = torch.tensor([[w.data_ptr(), planes16s.data_ptr(), wb.data_ptr(), w.numel(), w.numel(), Cout, Cin]], dtype=torch.int64).to(dev)
     _lib.fn('dsnt_f16_prep_weights')(ptr(tab), 1, 7, st)
+if which.startswith('bwd1'):
+    # the one-pass 1x1 backward (csrc/bwd1.hip): x [M][Cin] seen through BN + ReLU, dY [M][Cout]; 'bwd1a' folds the BatchNorm
+    # backward of the layer behind (dY from dz and y), 'bwd1' takes dY as given
+    from dsnt._lib import BnBwdEpilogue, BnBwdApply
+    wd = torch.randn(Cin, Cout, device=dev) * 0.05
+    wbd = torch.zeros(64, device=dev)
+    _lib.fn('dsnt_amax')(ptr(wd), wd.numel(), ptr(wbd), st)
+    pld = torch.empty(2 * wd.numel(), dtype=torch.float16, device=dev)
+    _lib.fn('dsnt_split_f16x2')(ptr(wd), ptr(pld), wd.numel(), wd.numel(), ptr(wbd), st)
+    mu, isd = torch.randn(Cin, device=dev) * 0.1, torch.rand(Cin, device=dev) + 0.5
+    ysc, ymu, yis = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev) * 0.1, torch.rand(Cout, device=dev) + 0.5
+    coef = torch.randn(2, Cout, device=dev) * 1e-3
+    gbd = torch.full((64,), float(gy.abs().max()) * 16.0, device=dev)
+    xs1 = BnBwdEpilogue(ptr(x), ptr(sc), ptr(sh), ptr(mu), ptr(isd), 1)
+    ap1 = BnBwdApply(ptr(y), ptr(ysc), ptr(ymu), ptr(yis), ptr(coef))
+    nsp1 = _lib.fn('dsnt_conv1x1_bwd_splits')(C.byref(g), 0)
+    ws1 = torch.empty(_lib.fn('dsnt_conv1x1_bwd_ws_floats')(C.byref(g), 0), device=dev)
+    part1, dzx1 = torch.empty(nsp1, 2, Cin, device=dev), torch.empty(B, H, H, Cin, device=dev)
 reps = int(os.environ.get('ONE_KERNEL_REPS', '5'))
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
 for it in range(reps):
@@ -43,6 +61,9 @@ for it in range(reps):
         _lib.fn('dsnt_conv_wgrad_f16x3')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g), st)
     elif which == 'wgrad6':
         _lib.fn('dsnt_conv_wgrad_bf16x6')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, C.byref(g), st)
+    elif which.startswith('bwd1'):
+        assert _lib.fn('dsnt_conv1x1_bwd_f16x3')(C.byref(xs1), ptr(gy), C.byref(ap1) if which == 'bwd1a' else None, ptr(pld), wd.numel(),
+                                                 ptr(wbd), ptr(ab), ptr(gbd), ptr(dzx1), ptr(part1), ptr(ws1), None, 0, C.byref(g), st) == 0
     elif which == 'fwd':
         _lib.fn('dsnt_conv_fwd')(ptr(x), ptr(w), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
     else:
