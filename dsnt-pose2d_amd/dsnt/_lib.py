@@ -108,6 +108,7 @@ SIGNATURES = {
     'dsnt_conv_wgrad': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_bf16x6': [P, P, P, I, P, P, P, P, I, GP, P],
     'dsnt_conv_wgrad_f16x3': [P, P, P, I, P, P, P, P, I, P, P, GP, P],
+    'dsnt_conv1x1_fwd_f16x3': [P, P, L, P, P, P, P, P, P, I, P, P, GP, TP, P],
     'dsnt_conv1x1_bwd_f16x3': [BP, P, AP, P, L, P, P, P, P, P, P, P, I, GP, P],
     'dsnt_wgrad_reduce_all': [P, I, I, P],
     'dsnt_conv_wgrad_group': [P, I, I, P],
@@ -185,6 +186,8 @@ PLAIN = {
     'dsnt_conv_wgrad_f16x3_splits': (I, [GP, I]),
     'dsnt_conv_wgrad_f16x3_ws_floats': (L, [GP, I]),
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
+    'dsnt_conv1x1_fwd_ok': (I, [GP]),
+    'dsnt_conv1x1_fwd_stats_rows': (I, [GP, I]),
     'dsnt_conv1x1_bwd_ok': (I, [GP]),
     'dsnt_conv1x1_bwd_splits': (I, [GP, I]),
     'dsnt_conv1x1_bwd_ws_floats': (L, [GP, I]),

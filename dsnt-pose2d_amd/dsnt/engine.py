@@ -123,6 +123,7 @@ class Tape:
         # the whole backward of a 1x1 convolution in one launch (csrc/bwd1.hip): data gradient with the BatchNorm-backward
         # epilogue + weight gradient + (conv1 of a Bottleneck) the BatchNorm backward of the layer behind, each tensor read once
         self.bwd1 = 'bwd1' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
+        self.fwd1 = 'fwd1' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')      # ... and their forward (csrc/fwd1.hip)
         self._f16_w_stream = {}
         # DSNT_CONV_SHARE_CHIP on the side lanes' launches of the two persistent kernels (3x3: 3/2 workgroups per CU; 1x1: half of
         # the CUs): both hold most of a CU's LDS for the whole launch, and the chain's kernels need LDS too (-0.2 ms)
@@ -309,7 +310,7 @@ class Tape:
         return n.abound
 
     # launches that read weight planes or operand bounds: the preparation must have finished before the first of them
-    _PREP_CONSUMERS = ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_f16x3_stream', 'dsnt_conv_fwd_bf16x6_ex', 'dsnt_conv_fwd_bf16x6')
+    _PREP_CONSUMERS = ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_f16x3_stream', 'dsnt_conv1x1_fwd_f16x3', 'dsnt_conv_fwd_bf16x6_ex', 'dsnt_conv_fwd_bf16x6')
 
     def emit_f16_prep(self, pos, head=()):
         """Insert the per-step preparation launches at position `pos` of the forward list: fp16x3 weight planes and BN
@@ -805,9 +806,17 @@ class Tape:
             self.check_lane(src)
         part, tail = None, None
         use6 = self._use6(g) and p.wq is not None
+        # the large 1x1 convolutions with both operand bounds: the LDS-staged streaming kernel (csrc/fwd1.hip) — its statistics
+        # come one row per WORKGROUP, and how many that is depends on the launch's share flag (below)
+        x_amax_pre = None
+        if use6 and p.wq16 is not None and p.R == 1 and res2 is None and self.fwd1:
+            x_amax_pre = self.operand_amax_bn(src) if normed else self.operand_amax(x)
+        f1 = bool(use6 and self.use_f16x3 and p.wq16 is not None and p.R == 1 and res2 is None and self.fwd1 and
+                  ((self.training and normed) or x_amax_pre is not None) and self.lib.dsnt_conv1x1_fwd_ok(C.byref(g)))
+        f1_shr = 2 if (f1 and self.lane != 0 and self.conv_share) else 0
         if want_stats and self.training:
             bm = 128 if use6 else self.lib.dsnt_conv_fwd_bm(C.byref(g))
-            tiles = (y.M + bm - 1) // bm
+            tiles = self.lib.dsnt_conv1x1_fwd_stats_rows(C.byref(g), f1_shr) if f1 else (y.M + bm - 1) // bm
             part = self.empty(tiles, 2, p.Cout)
             y.stats = (part, tiles)
         if use6 and self.use_f16x3:
@@ -818,8 +827,8 @@ class Tape:
         if self.use_f16x3 and self.training and normed:
             self.f16_bn_bound(src)              # also for the weight gradient of convs whose forward is not fp16x3
         # fp16x3 needs a bound of the A operand: train-mode BatchNorm parameters, or the producer's max|x| for a raw x
-        x_amax = None
-        if use6 and p.wq16 is not None:
+        x_amax = x_amax_pre
+        if x_amax is None and use6 and p.wq16 is not None:
             x_amax = self.operand_amax_bn(src) if normed else self.operand_amax(x)
         use16 = use6 and self.use_f16x3 and p.wq16 is not None and ((self.training and normed) or x_amax is not None)
         if normed and (use16 or use6):
@@ -830,8 +839,12 @@ class Tape:
             ab = self.f16_bn_bound(src) if (normed and self.training) else x_amax
             # (bit 1 of in_relu: a persistent kernel on a side lane leaves CUs with free LDS for the chain's kernels)
             shr = 2 if ((st or p.R == 1) and self.lane != 0 and self.conv_share) else 0
-            e = self.f('dsnt_conv_fwd_f16x3_stream' if st else 'dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, ab,
-                       p.b, y.buf, sc, sh, relu | shr, r1, r2, part, g, None, tail)
+            if f1:
+                e = self.f('dsnt_conv1x1_fwd_f16x3', x.buf, p.wq16, p.wq_stride, p.wb, ab, p.b, y.buf, sc, sh, relu | f1_shr, r1,
+                           part, g, tail)
+            else:
+                e = self.f('dsnt_conv_fwd_f16x3_stream' if st else 'dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, ab,
+                           p.b, y.buf, sc, sh, relu | shr, r1, r2, part, g, None, tail)
             self.f16_uses.append((e, dict(kind='fwd', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
                                           w=p.w, w_bound=p.wb)))
         elif use6:

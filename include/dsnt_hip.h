@@ -352,6 +352,22 @@ int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g);
 int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g, int accumulate);
 int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate);
 
+/* Forward of a 1x1 / stride 1 convolution with >= 16384 rows on the second streaming kernel (csrc/fwd1.hip): the same contract as
+ * dsnt_conv_fwd_f16x3_ex for these shapes (BN+ReLU prologue or a raw operand, bias, ONE residual, operand bounds, `tail`) except
+ * for the statistics: stats_partial is [rows][2][Cout] with rows = dsnt_conv1x1_fwd_stats_rows(g, in_relu) — one row per
+ * WORKGROUP (<= 512) instead of one per 128 pixels; hand `rows` to dsnt_bn_finalize as its ntiles.  The activations are
+ * loaded as whole rows (16 bytes per lane) and staged through LDS once for all output columns, where the first streaming
+ * kernel (gemm1.hip, behind dsnt_conv_fwd_f16x3_ex) loads a row per lane.  in_relu: bit 0 = ReLU, bit 1 = DSNT_CONV_SHARE_CHIP.
+ * dsnt_conv1x1_fwd_ok(g) != 0: (Cin, Cout) in {(256, 128), (128, 256), (128, 128), (64, 64), (64, 128), (256, 256)},
+ * N*H*W % 32 == 0 and >= 16384.  Replaces nn.Conv2d 1x1 forward + the BatchNorm2d + ReLU in front of it
+ * (/root/reference/src/dsnt/hourglass.py:20,25,33-43,44-48,146-153). */
+int dsnt_conv1x1_fwd_ok(const dsnt_conv_geom* g);
+int dsnt_conv1x1_fwd_stats_rows(const dsnt_conv_geom* g, int in_relu);
+int dsnt_conv1x1_fwd_f16x3(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
+                           const float* a_bound, const float* bias, float* y, const float* in_scale,
+                           const float* in_shift, int in_relu, const float* res1, float* stats_partial,
+                           const dsnt_conv_geom* g, const dsnt_out_bounds* tail, void* stream);
+
 /* The WHOLE backward of a 1x1 / stride 1 convolution y = conv(relu?(bn(x))) in one pass over its tensors — what
  * autograd runs as cuDNN backward-data + backward-filter of /root/reference/src/dsnt/hourglass.py:20,25 (conv1 / conv3 of
  * every Bottleneck) plus, with `ap`, the BatchNorm backward of the layer behind (hourglass.py:21,36-37):

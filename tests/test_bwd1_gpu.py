@@ -152,3 +152,88 @@ def test_conv1x1_backward_refusals():
     rc = _lib.fn('dsnt_conv1x1_bwd_f16x3')(None, None, None, None, 0, None, None, None, None, None, None, None,
                                            0, C.byref(g), None)
     assert rc == 3
+
+
+FWD_CASES = [
+    # N, H, W, Cin, Cout
+    (4, 64, 64, 256, 128),     # conv1 of a Bottleneck
+    (4, 64, 64, 128, 256),     # conv3 (+ residual)
+    (4, 64, 64, 128, 128),
+    (2, 128, 128, 64, 64),     # four-wave workgroups
+    (2, 128, 128, 64, 128),
+    (4, 64, 64, 256, 256),     # two column chunks
+    (5, 64, 64, 128, 256),     # 640 stages over 214 workgroups: the last one is short
+]
+
+
+@pytest.mark.parametrize('case', FWD_CASES)
+@pytest.mark.parametrize('pro,res', [(True, True), (True, False), (False, True), (False, False)])
+def test_conv1x1_forward_on_the_lds_staged_streaming_kernel(case, pro, res):
+    """dsnt_conv1x1_fwd_f16x3 (csrc/fwd1.hip: conv1 / conv3 / shortcut / `fc` forward, hourglass.py:20,25,44-48,146-153) against
+    fp64 and against dsnt_conv_fwd_f16x3_ex (the first streaming kernel) on the same operands: output, the one-row-per-workgroup
+    statistics (summed: the same two sums), both operand-bound outputs, bit-reproducible; DSNT_CONV_SHARE_CHIP changes no value."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call, ConvGeom, BnTail
+    N, H, W, Cin, Cout = case
+    dev = torch.device('cuda:0')
+    tag = 'f1' + '_'.join(map(str, case))
+    M = N * H * W
+    g = ConvGeom(N, H, W, Cin, H, W, Cout, 1, 1, 1, 0, 1)
+    assert _lib.fn('dsnt_conv1x1_fwd_ok')(C.byref(g))
+    x = synthetic.tensor(tag + 'x', (M, Cin), seed=1)
+    sc = synthetic.tensor(tag + 's', (Cin,), seed=1, kind='uniform').abs() + 0.5
+    sh = synthetic.tensor(tag + 'h', (Cin,), seed=1, scale=0.3)
+    w = synthetic.tensor(tag + 'w', (Cout, Cin), seed=2) * 0.05
+    b = synthetic.tensor(tag + 'b', (Cout,), seed=2, scale=0.1)
+    r = synthetic.tensor(tag + 'r', (M, Cout), seed=3)
+    act = torch.relu(x.double() * sc.double() + sh.double()) if pro else x.double()
+    ref = act @ w.double().t() + b.double() + (r.double() if res else 0.0)
+    xd, scd, shd, wd, bd, rd = (t.to(dev) for t in (x, sc, sh, w, b, r))
+    wb = torch.zeros(64, device=dev)
+    call('dsnt_amax', ptr(wd), wd.numel(), ptr(wb))
+    planes = torch.empty(2 * wd.numel(), dtype=torch.float16, device=dev)
+    call('dsnt_split_f16x2', ptr(wd), ptr(planes), wd.numel(), wd.numel(), ptr(wb))
+    ab = torch.full((64,), act.abs().max().item() * 3.0, device=dev)
+    asc = (synthetic.tensor(tag + 'as', (Cout,), seed=4, kind='uniform').abs() + 0.5).to(dev)
+    ash = synthetic.tensor(tag + 'ah', (Cout,), seed=4, scale=0.2).to(dev)
+
+    def run(flags, name='dsnt_conv1x1_fwd_f16x3'):
+        y = torch.full((M, Cout), float('nan'), device=dev)
+        amax, amax_bn = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+        tl = BnTail()
+        tl.amax, tl.amax_bn, tl.amax_scale, tl.amax_shift, tl.amax_relu = (amax.data_ptr(), amax_bn.data_ptr(), asc.data_ptr(),
+                                                                            ash.data_ptr(), 1)
+        common = (ptr(xd), ptr(planes), wd.numel(), ptr(wb), ptr(ab), ptr(bd), ptr(y), ptr(scd) if pro else None,
+                  ptr(shd) if pro else None, 1 | flags, ptr(rd) if res else None)
+        if name == 'dsnt_conv1x1_fwd_f16x3':
+            rows = _lib.fn('dsnt_conv1x1_fwd_stats_rows')(C.byref(g), flags)
+            stats = torch.full((rows, 2, Cout), float('nan'), device=dev)
+            call(name, *common, ptr(stats), C.byref(g), C.byref(tl))
+        else:
+            rows = (M + 127) // 128
+            stats = torch.full((rows, 2, Cout), float('nan'), device=dev)
+            call(name, *common, None, ptr(stats), C.byref(g), None, C.byref(tl))
+        torch.cuda.synchronize()
+        return y, stats, amax, amax_bn, rows
+
+    y, stats, amax, amax_bn, rows = run(0)
+    assert 0 < rows <= 512 and bool(torch.isfinite(y).all()) and bool(torch.isfinite(stats).all())
+    scale = ref.abs().max().item()
+    e = (y.cpu().double() - ref).abs().max().item()
+    assert e <= 2e-6 * scale, (e, scale)
+    s = stats.cpu().double().sum(0)
+    assert ((s[0] - ref.sum(0)).abs() <= 1e-5 * ref.abs().sum(0)).all()
+    assert ((s[1] - (ref * ref).sum(0)).abs() <= 1e-5 * (ref * ref).sum(0)).all()
+    assert float(amax.max()) == float(y.abs().max())
+    want_bn = torch.relu(y * asc + ash).abs().max()
+    assert abs(float(amax_bn.max()) - float(want_bn)) <= 1e-6 * float(want_bn)
+    # the first streaming kernel on the same operands
+    y0, stats0, amax0, _, _ = run(0, 'dsnt_conv_fwd_f16x3_ex')
+    assert (y - y0).abs().max().item() <= 2e-6 * scale
+    assert ((stats.double().sum(0) - stats0.double().sum(0)).abs() <= 1e-5 * stats0.double().abs().sum(0) + 1e-6).all()
+    # bit-reproducible, and the share flag (fewer workgroups, other statistics rows) changes no output value
+    y2, stats2, _, _, _ = run(0)
+    assert torch.equal(y, y2) and torch.equal(stats, stats2)
+    y3, stats3, _, _, rows3 = run(2)
+    assert torch.equal(y, y3) and rows3 <= rows
+    assert ((stats3.double().sum(0) - stats.double().sum(0)).abs() <= 1e-5 * stats.double().abs().sum(0) + 1e-6).all()
