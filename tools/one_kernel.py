@@ -64,6 +64,9 @@ for it in range(reps):
     elif which.startswith('bwd1'):
         assert _lib.fn('dsnt_conv1x1_bwd_f16x3')(C.byref(xs1), ptr(gy), C.byref(ap1) if which == 'bwd1a' else None, ptr(pld), wd.numel(),
                                                  ptr(wbd), ptr(ab), ptr(gbd), ptr(dzx1), ptr(part1), ptr(ws1), None, 0, C.byref(g), st) == 0
+    elif which == 'fwd1':
+        assert _lib.fn('dsnt_conv1x1_fwd_f16x3')(ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1,
+                                                 ptr(gy) if Cout > Cin else None, ptr(stats), C.byref(g), None, st) == 0
     elif which == 'fwd':
         _lib.fn('dsnt_conv_fwd')(ptr(x), ptr(w), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), st)
     else:

@@ -29,5 +29,7 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
     step()
+t1 = time.perf_counter()
 torch.cuda.synchronize()
-print('%.3f ms/step over %d steps (+2 warm-up), batch %d, %s' % (1e3 * (time.perf_counter() - t0) / steps, steps, batch, base))
+print('%.3f ms/step over %d steps (+2 warm-up), batch %d, %s (host issue %.3f ms/step)'
+      % (1e3 * (time.perf_counter() - t0) / steps, steps, batch, base, 1e3 * (t1 - t0) / steps))
