@@ -262,12 +262,20 @@ def family_rooflines(batch, iters=20):
     assert _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(planes16), w.numel(), w.numel(), ptr(wb), st) == 0
     y = torch.empty(batch, H, H, 256, device=dev)
     bias = torch.zeros(256, device=dev)
-    stats = torch.empty((M + 127) // 128, 2, 256, device=dev)
-    fwd = _lib.fn('dsnt_conv_fwd_f16x3_ex')
-    us = timed(lambda: fwd(ptr(x128), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(bias), ptr(y), ptr(sc128), ptr(sh128),
-                           1, ptr(g256), None, ptr(stats), C.byref(g), None, None, st))
-    res.append(entry('1x1 GEMM 128->256 @64x64 B=%d (fp16x3, BN+ReLU prologue, residual add, statistics)' % batch, us,
-                     2.0 * M * 128 * 256, 4.0 * (M * 128 + 2 * M * 256), 'hbm'))
+    if _lib.fn('dsnt_conv1x1_fwd_ok')(C.byref(g)):
+        # (what the step launches since round 4: the LDS-staged streaming kernel of csrc/fwd1.hip, one statistics row per workgroup)
+        stats = torch.empty(_lib.fn('dsnt_conv1x1_fwd_stats_rows')(C.byref(g), 0), 2, 256, device=dev)
+        fwd1 = _lib.fn('dsnt_conv1x1_fwd_f16x3')
+        us = timed(lambda: fwd1(ptr(x128), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(bias), ptr(y), ptr(sc128), ptr(sh128),
+                                1, ptr(g256), ptr(stats), C.byref(g), None, st))
+        kname = '1x1 convolution 128->256 @64x64 B=%d forward (fp16x3, fwd1_kernel: BN+ReLU prologue, residual add, statistics)'
+    else:
+        stats = torch.empty((M + 127) // 128, 2, 256, device=dev)
+        fwd = _lib.fn('dsnt_conv_fwd_f16x3_ex')
+        us = timed(lambda: fwd(ptr(x128), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(bias), ptr(y), ptr(sc128), ptr(sh128),
+                               1, ptr(g256), None, ptr(stats), C.byref(g), None, None, st))
+        kname = '1x1 GEMM 128->256 @64x64 B=%d (fp16x3, BN+ReLU prologue, residual add, statistics)'
+    res.append(entry(kname % batch, us, 2.0 * M * 128 * 256, 4.0 * (M * 128 + 2 * M * 256), 'hbm'))
     # -- the whole backward of conv1 of a Bottleneck (256 -> 128) in one launch: data gradient + BatchNorm-backward sums +
     #    weight gradient + the folded BatchNorm backward of bn2 (csrc/bwd1.hip); every tensor once
     from dsnt._lib import BnBwdEpilogue, BnBwdApply
