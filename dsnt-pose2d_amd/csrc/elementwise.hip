@@ -413,9 +413,11 @@ extern "C" int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M,
                                     void* stream) {
     DSNT_REQUIRE(partial && coef && ntiles > 0 && C > 0 && M > 0, DSNT_ERR_ARG,
                  "dsnt_bn_bwd_finalize: bad argument");
+    // DSNT_BN_FROZEN: the forward ran on fixed (running) statistics — dx = scale dz, both coefficients zero; dgamma / dbeta as always
+    const double invM = (accumulate & DSNT_BN_FROZEN) ? 0.0 : 1.0 / (double)M;
     DSNT_LAUNCH(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
-                       partial, ntiles, 1.0 / (double)M, 1.0, C, nullptr, nullptr, nullptr, nullptr,
-                       0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate, BnBoundP{nullptr, nullptr, 0.f, nullptr});
+                       partial, ntiles, invM, 1.0, C, nullptr, nullptr, nullptr, nullptr,
+                       0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate & 1, BnBoundP{nullptr, nullptr, 0.f, nullptr});
     DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize");
 }
 

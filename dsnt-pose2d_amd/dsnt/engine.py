@@ -82,9 +82,14 @@ class Normed:
 
 
 class Tape:
-    def __init__(self, device, training):
+    def __init__(self, device, training, record=None):
         self.device = device
+        # `training` is the BatchNorm mode (batch statistics vs running statistics, nn.Module.train / eval); `record` says
+        # whether a backward list is built.  They differ for a backward through an EVAL-mode forward (frozen BatchNorm
+        # statistics: dx = scale dz, the two reductions only feed dgamma / dbeta) — rare (bin/train.py never does it), so that
+        # program runs on the bound-free kernels: bf16x6, none of the fp16x3-only fused kernels
         self.training = training
+        self.record = training if record is None else bool(record)
         self.fwd = []           # (cfunc, args)
         self.bwd = []
         self._bwd_emitters = []
@@ -170,6 +175,8 @@ class Tape:
         # bound is available without a host round-trip: train-mode BN+ReLU operands (bound from the BN parameters) and
         # weights (amax in the per-step prep launch)
         self.use_f16x3 = self.use_bf16x6 and os.environ.get('DSNT_SPLIT', 'f16x3') == 'f16x3'
+        if self.record and not self.training:
+            self.use_f16x3 = False      # (its backward operand bounds come from BATCH statistics: |xhat| <= sqrt(M))
         self._f16_w_rows, self._f16_w_seen = [], set()
         self._f16_bn_rows = []
         self._eval_bn_rows = []     # eval mode: every BatchNorm's vectors come from ONE table-driven launch per forward
@@ -413,7 +420,7 @@ class Tape:
         if not self.use_lanes:
             return
         self.fwd.append((None, (src, dst, torch.cuda.Event()), 'sync', 0))
-        if self.training and bwd:
+        if self.record and bwd:
             self._bwd_emitters.append(
                 lambda: self.bwd.append((None, (dst, src, torch.cuda.Event()), 'sync', 0)))
 
@@ -431,7 +438,7 @@ class Tape:
             return x
         xb = Act(x.buf, x.name + '/branch')
         xb.stats, xb.amax_tail = x.stats, x.amax_tail
-        if self.training and join:
+        if self.record and join:
             def join_grad():
                 if xb.grad is not None:
                     self.grad_identity(x, xb.grad, donate=False, g_amax=xb.grad_amax)
@@ -516,7 +523,7 @@ class Tape:
         """Forward position where parameter bucket k starts being used: in the (reversed) backward
         list the marker lands right after the last launch that writes bucket k's gradients."""
         self.cur_bucket = k
-        if self.training:
+        if self.record:
             def mark():
                 lane, self.lane = self.lane, self._flush_lane()
                 self.flush_wgrad()
@@ -774,12 +781,16 @@ class Tape:
                    dz_amax, bound)
             x.pending_apply = dict(dz=da, n=n, coef=coef, bound=bound, dz_amax=dz_amax)
             return
-        fused = (not finalised) and self.fuse_finalize and bn.C <= 256 and tiles * bn.C <= self.fuse_finalize_max
+        # eval-mode forward: the statistics are constants — dx = scale dz, i.e. the apply with both coefficients zero
+        # (DSNT_BN_FROZEN); the two sums still are dbeta / dgamma
+        frozen = not self.training
+        fused = (not finalised) and self.fuse_finalize and bn.C <= 256 and tiles * bn.C <= self.fuse_finalize_max and not frozen
+        assert not (frozen and finalised)
         if not finalised:
             acc_p = 1 if bn.uses > 0 else 0
             bn.uses += 1
             if not fused:
-                self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p, coef)
+                self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p | (2 if frozen else 0), coef)
         buf, acc = self.grad_target(x, amax='apply')
         if fused:
             # few tiles: the apply launch sums them itself in its prologue (coef) and writes dgamma / dbeta
@@ -864,7 +875,7 @@ class Tape:
             if normed:
                 self.materialize(src)
             self.f('dsnt_conv_fwd_ex', x.buf, p.w, p.b, y.buf, sc, sh, relu, r1, r2, part, g, None, tail)
-        if not self.training:
+        if not self.record:
             return y
         slot = None
         if need_input_grad and self.param_arena is not None:
@@ -1142,7 +1153,7 @@ class Tape:
             self.f('dsnt_bn_act_fwd_stats', x.buf, n.scale, n.shift, 1 if n.relu else 0, y.buf, None, x.M, x.C, y.amax_tail)
         else:
             self.f('dsnt_bn_act_fwd', x.buf, n.scale, n.shift, 1 if n.relu else 0, y.buf, x.M, x.C)
-        if self.training:
+        if self.record:
             def backward():
                 self._norm_backward(n, y.grad)
             self.on_backward(backward)
@@ -1163,7 +1174,7 @@ class Tape:
             self.f('dsnt_maxpool2_fwd_stats', x.buf, y.buf, idx, None, x.N, x.H, x.W, x.C, y.amax_tail)
         else:
             self.f('dsnt_maxpool2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
-        if self.training:
+        if self.record:
             def backward():
                 buf, acc = self.grad_target(x, amax=True)
                 if x.grad_amax is not None:
@@ -1179,7 +1190,7 @@ class Tape:
         y = self.act(x.N, Ho, Wo, x.C, name)
         idx = self.empty(x.N, Ho, Wo, x.C, dtype=torch.uint8)
         self.f('dsnt_maxpool3s2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
-        if self.training:
+        if self.record:
             def backward():
                 buf, acc = self.grad_target(x)
                 self.b('dsnt_maxpool3s2_bwd', y.grad, idx, buf, acc, x.N, x.H, x.W, x.C)
@@ -1194,7 +1205,7 @@ class Tape:
             relu = False
         self.materialize(n)
         self.f('dsnt_bn_add_act_fwd', x.buf, n.scale, n.shift, skip.buf, 1 if relu else 0, y.buf, x.M, x.C)
-        if self.training:
+        if self.record:
             def backward():
                 if relu:
                     dz = self.scratch('dz_tail', x.M * x.C).view(-1)[:x.M * x.C]
@@ -1219,7 +1230,7 @@ class Tape:
             self.f('dsnt_upsample2_add_fwd_stats', up.buf, low.buf, out.buf, None, up.N, up.H, up.W, up.C, out.amax_tail)
         else:
             self.f('dsnt_upsample2_add_fwd', up.buf, low.buf, out.buf, up.N, up.H, up.W, up.C)
-        if self.training:
+        if self.record:
             point = self.wgrad_lane is not None and low.M <= self.release_rows
             self._release_total += point
 
@@ -1240,9 +1251,9 @@ class Tape:
         """NHWC activation -> logical NCHW tensor [N, C, H, W] (model surface); returns the tensor.
         In backward the incoming NCHW gradient is transposed into x.grad (first writer)."""
         out = self.empty(x.N, C_logical, x.H, x.W)
-        gin = self.empty(x.N, C_logical, x.H, x.W) if self.training else None
+        gin = self.empty(x.N, C_logical, x.H, x.W) if self.record else None
         self.f('dsnt_nhwc_to_nchw', x.buf, out, x.N, C_logical, x.H * x.W, x.C)
-        if self.training:
+        if self.record:
             def backward():
                 assert x.grad is None, 'planar output must be the first gradient writer'
                 buf, _ = self.grad_target(x)

@@ -159,15 +159,18 @@ class Arena:
 
 # ====================================================================== traced programs
 class Program:
-    """Forward/backward launch lists for one (input shape, training mode)."""
+    """Forward/backward launch lists for one (input shape, BatchNorm mode, backward wanted or not)."""
 
-    def __init__(self, root, arena, in_shape, training, input_grad):
+    def __init__(self, root, arena, in_shape, training, input_grad, record=None):
         self.training = training
+        # a backward list is built in train mode, and — on request — for an eval-mode forward under autograd (frozen BatchNorm
+        # statistics; the reference's autograd allows it: model.py:273-307 has no mode check)
+        self.record = record = training if record is None else bool(record)
         self.token = 0
         self.in_flight = False      # a forward of this program is waiting for its backward (hourglass._Run)
         dev = arena.device
-        tape = Tape(dev, training)
-        tape.want_input_grad = bool(input_grad and training)     # the stem then keeps its data gradient (no space-to-depth form)
+        tape = Tape(dev, training, record)
+        tape.want_input_grad = bool(input_grad and record)     # the stem then keeps its data gradient (no space-to-depth form)
         tape.param_arena = arena.params
         self.tape = tape
         names = {id(m): n for n, m in root.named_modules()}
@@ -219,12 +222,12 @@ class Program:
             t, g = tape.to_planar(o, self.out_channels)
             self.outs.append(t)
             self.gins.append(g)
-        self.input_grad = input_grad and training
-        if training:
+        self.input_grad = input_grad and record
+        if record:
             tape.finish()
         # weight planes, operand bounds, data-gradient weights: before the first convolution that reads them
         tape.emit_f16_prep(prep_pos, prep_head)
-        if training:
+        if record:
             if self.input_grad:
                 self.gx = tape.empty(N, Cc, H, W)
                 if x.grad is None:
@@ -256,9 +259,8 @@ class _Run(Function):
     @staticmethod
     def backward(ctx, *gouts):
         prog, runner = ctx.prog, ctx.runner
-        if not prog.training:
-            raise RuntimeError('dsnt: backward through an eval-mode forward is not supported; '
-                               'call model.train() before the forward pass')
+        if not prog.record:
+            raise RuntimeError('dsnt: this forward was traced without a backward list')
         if prog.token != ctx.token:
             raise RuntimeError('dsnt: the saved activations of this forward were overwritten by a '
                                'later forward of the same shape; run backward before forwarding again')
@@ -311,9 +313,12 @@ class Runner:
         self.ensure(x.device)
         training = self.root.training
         grad_mode = torch.is_grad_enabled()
-        key = (tuple(x.shape), training, bool(x.requires_grad), self._bn_signature())
+        # an eval-mode forward under autograd gets a program with a backward list of its own (BatchNorm on its running statistics,
+        # their backward with frozen statistics); eval mode under no_grad — inference.py:33-48 — keeps the forward-only program
+        record = grad_mode and (training or x.requires_grad or any(p.requires_grad for p in self.params))
+        key = (tuple(x.shape), training, bool(x.requires_grad), self._bn_signature()) + (('eval+backward',) if (record and not training) else ())
         prog = self.programs.get(key)
-        if prog is not None and prog.in_flight and training and grad_mode:
+        if prog is not None and prog.in_flight and record:
             # the reference's autograd lets a caller run several forwards before the first backward (model.py:273-307 has no
             # restriction): each such forward needs its own set of saved activations, i.e. a further traced program of the same
             # shape (static buffers: ~190 MB per image for hg2) — created on demand, kept, at most MAX_IN_FLIGHT of them
@@ -329,9 +334,9 @@ class Runner:
             if x.requires_grad and not self.root.supports_input_grad:
                 raise NotImplementedError('dsnt: gradient with respect to the input image is not '
                                           'on the hot path (stride-2 stem data-gradient)')
-            prog = Program(self.root, self.arena, tuple(x.shape), training, bool(x.requires_grad))
+            prog = Program(self.root, self.arena, tuple(x.shape), training, bool(x.requires_grad), record=record or training)
             self.programs[key] = prog
-        if training and grad_mode:
+        if record:
             outs = _Run.apply(self, prog, x, *self.params)
         else:
             with torch.no_grad():
@@ -425,7 +430,7 @@ class Hourglass(TapeModule):
         g = self.hg[n - 1]
         # the full-resolution skip branch is independent of the whole low-resolution recursion:
         # trace it on the side lane so its few large kernels overlap the many small ones
-        if t.training and t.use_lanes and t.fuse_join:
+        if t.record and t.use_lanes and t.fuse_join:
             # Training: the branch is traced LAST, so that its backward is emitted first and its gradient exists when
             # the pool's backward is emitted — the main lane then waits for the side lane, takes the branch's gradient
             # buffer over as x's and the pool's backward ACCUMULATES into it (no separate x.grad += branch.grad pass:

@@ -451,7 +451,11 @@ int dsnt_bn_eval_prep(const int64_t* table, int rows, void* stream);
  *            dz = da * (y > 0), xhat = (x - mean)*invstd;
  *  finalize: dgamma (+)= sum dz*xhat, dbeta (+)= sum dz, coef[0][c] = mean(dz),
  *            coef[1][c] = mean(dz*xhat);
- *  apply:    dx (+)= gamma*invstd * (dz - coef0 - xhat*coef1). */
+ *  apply:    dx (+)= gamma*invstd * (dz - coef0 - xhat*coef1).
+ * `accumulate` of dsnt_bn_bwd_finalize: bit 0 = add to dgamma / dbeta; DSNT_BN_FROZEN = the forward ran on FIXED statistics
+ * (nn.BatchNorm2d in eval mode, i.e. a backward through `model.eval()`'s forward): coef is written as zeros, so that the apply
+ * gives dx = gamma*invstd * dz; dgamma / dbeta are the same two sums. */
+#define DSNT_BN_FROZEN 2
 int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const float* scale,
                            const float* shift, const float* mean, const float* invstd,
                            int relu, float* partial, int64_t M, int C, void* stream);

@@ -283,6 +283,50 @@ def test_resnet_pose_model_vs_oracle(base, dilate, truncate, size, batch, mfma, 
     assert all(not torch.equal(before[n], p.detach()) for n, p in m.named_parameters())   # tests/test_model.py:39-63
 
 
+@pytest.mark.parametrize('mfma', ['f32', 'bf16x6'])
+def test_resnet_backward_through_an_eval_mode_forward(mfma, monkeypatch):
+    """model.eval() + backward on a ResNet backbone (bn_add_act tails, strided data gradients): frozen BatchNorm statistics,
+    every gradient against the oracle on the smooth network."""
+    from dsnt.model import build_mpii_pose_model
+    from dsnt_oracle import model as omodel
+    import torch.nn as nn
+    monkeypatch.setenv('DSNT_MFMA', mfma)
+    if mfma == 'bf16x6':
+        monkeypatch.setenv('DSNT_BF16X6_MIN_ROWS', '0')
+    kw = dict(base='resnet18', output_strat='dsnt', reg='js')
+    with _SmoothResNet():
+        m = build_mpii_pose_model(**kw)
+        o = omodel.build_mpii_pose_model(**kw)
+        o.fcn[2] = nn.Identity()
+        synthetic.fill_state_dict(m, seed=8)
+        synthetic.fill_state_dict(o, seed=8)
+        m.cuda().train()
+        o.train()
+        x, target, mask = synthetic.batch(4, size=128, seed=9, mask_p=0.8)
+        for mod in list(m.modules()) + list(o.modules()):
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.momentum = 1.0
+        with torch.no_grad():
+            m(x.to(DEV)); o(x)
+        m.eval(); o.eval()
+        stats = {n: b.detach().clone() for n, b in m.named_buffers() if 'running' in n}
+        out = m(x.to(DEV))
+        loss = m.forward_loss(out, target.to(DEV), mask.to(DEV))
+        loss.backward()
+        out_o = o(x)
+        loss_o = o.forward_loss(out_o, target, mask)
+        loss_o.backward()
+    assert (out.detach().cpu() - out_o.detach()).abs().max().item() <= 1e-4
+    assert abs(loss.item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
+    floor = 1e-3 * max(q.grad.double().norm().item() for q in o.parameters())
+    for (n, p), (_, q) in zip(m.named_parameters(), o.named_parameters()):
+        e = (p.grad.cpu().double() - q.grad.double()).norm().item() / max(q.grad.double().norm().item(), floor)
+        assert e <= 2e-3, (n, e)
+    for n, b in m.named_buffers():
+        if 'running' in n:
+            assert torch.equal(b, stats[n]), n
+
+
 def test_resnet_surface():
     from dsnt.model import build_mpii_pose_model
     m = build_mpii_pose_model(base='resnet34')
