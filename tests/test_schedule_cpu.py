@@ -168,6 +168,32 @@ def test_eval_mode_schedule_of_hg2(monkeypatch_module):
     assert len(fwd) <= 135, len(fwd)
 
 
+def test_eval_mode_forward_with_a_backward_list(monkeypatch_module):
+    """A backward through an eval-mode forward (autograd on model.eval(): hourglass.Runner traces `record=True` beside
+    `training=False`): BatchNorm vectors from the running statistics, no statistics passes forward; backward, every BatchNorm
+    finalise carries DSNT_BN_FROZEN (zero coefficients: dx = gamma invstd dz) and none is folded into a consumer's prologue; none of
+    the fp16x3 kernels (their backward bounds assume batch statistics)."""
+    from dsnt.model import build_mpii_pose_model
+    from dsnt.hourglass import Arena, Program
+    from dsnt import _lib
+    import dsnt.engine as E
+    monkeypatch_module.setattr(_lib, 'ptr', lambda t: C.c_void_p(t.data_ptr()) if t is not None else None)
+    monkeypatch_module.setattr(E._lib, 'ptr', _lib.ptr)
+    m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+    m.eval()
+    prog = Program(m.hg, Arena(m.hg, torch.device('cpu')), (4, 3, 128, 128), False, False, record=True)
+    tape = prog.tape
+    assert prog.record and not prog.training and not tape.use_f16x3
+    fwd, bwd = _launches(tape.fwd), _launches(tape.bwd)
+    fn, bn = [n for n, _, _ in fwd], [n for n, _, _ in bwd]
+    assert fn.count('dsnt_bn_eval_prep') == 1 and 'dsnt_bn_finalize' not in fn and not any('stats' in n for n in fn)
+    fin = [a for n, _, a in bwd if n == 'dsnt_bn_bwd_finalize']
+    assert len(fin) >= 90 and all(int(a[6]) & 2 for a in fin)
+    assert 'dsnt_bn_act_bwd_apply_pro' not in bn and 'dsnt_bn_bwd_finalize_bound' not in bn
+    assert not any('_f16x3' in n or n.startswith('dsnt_f16_') for n in fn + bn)
+    assert bn.count('dsnt_wgrad_reduce_all') == 3
+
+
 def test_resnet34_train_schedule(monkeypatch_module):
     """BASELINE config 1's model (ResNet-34 + DSNT, batch 8, 8x8 heat-maps): one lane chain (no skip branches to fork),
     post-activation blocks as conv -> [BN+ReLU in the next conv's load] -> conv -> one bn_add_act launch, strided
