@@ -562,11 +562,20 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
                              '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...'
                              % (args.gpus, args.gpus))
+    # DSNT_BENCH_REHEARSAL=1 (a one-GPU box): the N > 1 code path with every rank on device 0 over gloo — RCCL refuses two ranks
+    # on one device.  It rehearses the control flow of the multi-GPU line (barriers, max over ranks, the `dp` block), not its speed;
+    # the line says so in `dp.rehearsal`.
+    rehearsal = world > 1 and os.environ.get('DSNT_BENCH_REHEARSAL', '0') == '1'
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from dsnt.model import build_mpii_pose_model
     from dsnt import synthetic, optim, parallel
@@ -698,6 +707,8 @@ def main():
                          'exposed_comm_ms': None if exposed is None else round(exposed, 4),
                          'gradient_mbytes': round(4e-6 * runner.arena.numel, 1), 'buckets': len(runner.arena.bucket_bounds),
                          'guard_flag_exchanged': True}
+            if rehearsal:
+                out['dp']['rehearsal'] = 'all %d ranks on one device over gloo: control flow only, not a scaling measurement' % world
             if args.baseline_ips:
                 out['dp']['baseline_ips'] = args.baseline_ips
                 out['dp']['efficiency'] = round(ips / (args.baseline_ips * world), 4)      # weak and strong alike: throughput per GPU kept
