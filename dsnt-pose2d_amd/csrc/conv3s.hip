@@ -308,6 +308,10 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     rd(F0, 0, bcur);
     zero();
 
+#ifndef C3_ABL
+#define C3_ABL 0        /* ablation builds (timing only, wrong results): 1 no weight stream, 2 no halo staging, 4 no barrier, 8 no fragment reads */
+#endif
+    if (C3_ABL & 8) rd(F1, 1, bcur);
     for (; v < ntiles; v += gridDim.x) {
         for (int c2 = 0; c2 < nchunks; c2 += 2) {
 #pragma unroll
@@ -315,9 +319,8 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 // first half: the MFMAs of step 2 it carry the fragment reads of step 2 it + 1, the copy of the pair after this
                 // one into the other slot (its last readers passed the previous barrier) and the fetch of the one after that
                 __builtin_amdgcn_sched_barrier(0);
-                rd(F1, 2 * it + 1, bcur);
-                storeB(bnxt);
-                gloadB();
+                if (!(C3_ABL & 8)) rd(F1, 2 * it + 1, bcur);
+                if (!(C3_ABL & 1)) { storeB(bnxt); gloadB(); }
                 mm(F0);
 #pragma unroll
                 for (int i = 0; i < 4 * TM; ++i) {
@@ -331,12 +334,13 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();                // the other slot / chunk buffer is written; this slot is read
+                if (!(C3_ABL & 4)) __syncthreads();                // the other slot / chunk buffer is written; this slot is read
                 // second half: the MFMAs of step 2 it + 1 carry the fragment reads of step 2 it + 2 and the halo staging: chunk
                 // c2 + 1 (buffer 1: read last at step 17 of the previous trip, next at step 9) is fetched at it = 0 and stored at
                 // it = 2; chunk c2 + 2 — or chunk 0 of the next tile — (buffer 0: read last at step 8) at it = 4 / it = 7.
                 // (Fetching four / five iterations ahead instead of two / three, the stores in the first half: 105 -> 108 us.)
-                rd(F0, 2 * it + 2, bnxt);
+                if (!(C3_ABL & 8)) rd(F0, 2 * it + 2, bnxt);
+                if (!(C3_ABL & 2)) {
                 if (it == 0) gloadA(c2 + 1);
                 if (it == 2) storeA(1, c2 + 1);
                 if (it == 4) {
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                     else { m0n = set_tile(v + (int)gridDim.x); gloadA(0); }      // the next tile's first chunk
                 }
                 if (it == 7) storeA(0, c2 + 2 < nchunks ? c2 + 2 : 0);
+                }
                 mm(F1);
 #pragma unroll
                 for (int i = 0; i < 4 * TM; ++i) {
