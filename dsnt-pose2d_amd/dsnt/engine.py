@@ -33,7 +33,7 @@ BN_MOMENTUM = 0.1
 class Act:
     """An activation on the tape: NHWC buffer + lazily created gradient / batch statistics."""
     __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'amax_tail', 'fold_ok',
-                 'pending_apply')
+                 'pending_apply', 'uses', 'gives_away', 'is_branch', 'grad_shared')
 
     def __init__(self, buf, name=''):
         self.buf = buf
@@ -44,6 +44,10 @@ class Act:
         self.grad_amax = None   # fp16x3: device scalar max|grad| when ONE bn-backward apply wrote the whole gradient
         self.fold_ok = False    # the producing 1x1 convolution can take the BatchNorm backward of its consumer into its own backward
         self.pending_apply = None   # ... and this is that BatchNorm backward, reduced but not applied (Tape._norm_backward)
+        self.uses = 0           # forward consumers (each contributes once to the gradient)
+        self.gives_away = False     # the producer's backward DONATES this gradient's buffer onwards (residual inputs, upsample + add)
+        self.is_branch = False  # `Tape.branch`: an alias of another activation (its gradient is joined to that one's)
+        self.grad_shared = False    # .grad is another activation's buffer, read in place (Tape.share_grads): readers must not be deferred
         self.name = name
 
     @property
@@ -137,6 +141,11 @@ class Tape:
         # DSNT_X=<name>=<value>,...: A/B overrides of scheduling constants (tools/ab_env.sh); not product switches
         self._x = dict(kv.split('=') for kv in os.environ.get('DSNT_X', '').split(',') if '=' in kv)
         self.wgrad_narrow = self._x.get('wgrad_narrow', '1')      # DSNT_WGRAD_NARROW: 0 never, 1 always, 2 stem bucket only, 3 stacks only
+        # a gradient shared instead of copied (A/B: DSNT_X=share_grads=0): a second residual input with ONE consumer reads dL/dy in
+        # place (hourglass.py:175: x + fc_ + score_ — fc_'s gradient IS the sum's): one 268 MB pass per intermediate supervision,
+        # 7 per hg8 step.  (The OTHER pass there — x.grad += the skip branch's gradient, Hourglass._level — stays: both buffers
+        # arrive by donation, and folding the sum into the branch's last apply would need a five-stream form of that kernel.)
+        self.share_grads = self._x.get('share_grads', '1') != '0'
         self.cur_bucket = 0         # parameter bucket of the layers being traced (mark_bucket)
         self._wgrad_lane_reads = set()
         # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
@@ -438,6 +447,8 @@ class Tape:
             return x
         xb = Act(x.buf, x.name + '/branch')
         xb.stats, xb.amax_tail = x.stats, x.amax_tail
+        xb.is_branch = True
+        x.uses += 1
         if self.record and join:
             def join_grad():
                 if xb.grad is not None:
@@ -810,6 +821,11 @@ class Tape:
         x = src.x if normed else src
         g = self.geom(x, p)
         y = self.act(x.N, g.Ho, g.Wo, p.Cout, name)
+        x.uses += 1
+        for r in (res1, res2):
+            if r is not None:
+                r.uses += 1
+                y.gives_away = True             # dL/dy's buffer is handed to a residual input in backward
         sc = src.scale if normed else None
         sh = src.shift if normed else None
         relu = 1 if (normed and src.relu) else 0
@@ -989,7 +1005,8 @@ class Tape:
                 if self.defer_reduce:
                     # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
                     # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
-                    grouped = (w6 and normed and res1 is None and res2 is None and wl == cur and
+                    # (... nor shared with an activation whose gradient is accumulated into later: `share_grads`)
+                    grouped = (w6 and normed and res1 is None and res2 is None and wl == cur and not y.grad_shared and
                                0 < g.N * g.Ho * g.Wo <= self.group_rows)
                     # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
                     w16 = w6 and self.use_f16x3 and (normed or x_amax is not None) and y.grad_amax is not None
@@ -1129,6 +1146,16 @@ class Tape:
             donated = False
             for r in (res1, res2):
                 if r is not None:
+                    if (donated and self.share_grads and r.grad is None and r.pending_apply is None and r.uses == 1 and
+                            not r.gives_away and not r.is_branch):
+                        # the buffer went to the first residual input; this one has a single consumer, so its gradient is dL/dy
+                        # and nothing else, and its producer only READS it (it gives no buffer away): shared, not copied.  Every
+                        # later writer of the buffer comes after that reader in lane order, or waits for the lane that reads
+                        # (`_wgrad_lane_reads` is keyed by the buffer)
+                        r.grad = gy
+                        r.grad_amax = y.grad_amax if self.amax_all else None
+                        r.grad_shared = True
+                        continue
                     donated = self.grad_identity(r, gy, donate=not donated, g_amax=y.grad_amax) or donated
 
         self.on_backward(backward)
@@ -1139,6 +1166,7 @@ class Tape:
         n = self.norm(x, bn, relu)
         self.materialize(n)
         y = self.act(x.N, x.H, x.W, x.C, name)
+        x.uses += 1
         big = self.use_f16x3 and y.M >= self.bf16x6_min_rows
         if self.training and self.fuse_op_stats:
             # the statistics of y (the first Bottleneck's BatchNorm reads it next) and the bound of its raw consumer
@@ -1161,6 +1189,7 @@ class Tape:
 
     def maxpool2(self, x, name=''):
         y = self.act(x.N, x.H // 2, x.W // 2, x.C, name)
+        x.uses += 1
         idx = self.empty(x.N, x.H // 2, x.W // 2, x.C, dtype=torch.uint8)
         if self.training and self.fuse_op_stats:
             # the consumer is a BatchNorm (hourglass.py:33): its batch statistics ride in the same pass
@@ -1188,6 +1217,7 @@ class Tape:
         """3x3 / stride 2 / pad 1 max-pool (the torchvision ResNet stem)."""
         Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
         y = self.act(x.N, Ho, Wo, x.C, name)
+        x.uses += 1
         idx = self.empty(x.N, Ho, Wo, x.C, dtype=torch.uint8)
         self.f('dsnt_maxpool3s2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
         if self.record:
@@ -1201,6 +1231,8 @@ class Tape:
         """y = relu(bn(x) + skip): the tail of a torchvision residual block (conv -> bn -> += identity -> relu)."""
         n = self.norm(x, bn, relu=False)
         y = self.act(x.N, x.H, x.W, x.C, name)
+        x.uses += 1
+        skip.uses += 1
         if os.environ.get('DSNT_DEBUG_NO_RELU'):
             relu = False
         self.materialize(n)
@@ -1219,6 +1251,9 @@ class Tape:
 
     def upsample2_add(self, up, low, name=''):
         out = self.act(up.N, up.H, up.W, up.C, name)
+        up.uses += 1
+        low.uses += 1
+        out.gives_away = True                   # dL/d out's buffer becomes dL/d up in backward
         if self.training and self.fuse_op_stats:
             tiles = (out.M + 127) // 128
             part = self.empty(tiles, 2, up.C)
@@ -1251,6 +1286,7 @@ class Tape:
         """NHWC activation -> logical NCHW tensor [N, C, H, W] (model surface); returns the tensor.
         In backward the incoming NCHW gradient is transposed into x.grad (first writer)."""
         out = self.empty(x.N, C_logical, x.H, x.W)
+        x.uses += 1
         gin = self.empty(x.N, C_logical, x.H, x.W) if self.record else None
         self.f('dsnt_nhwc_to_nchw', x.buf, out, x.N, C_logical, x.H * x.W, x.C)
         if self.record:
