@@ -179,7 +179,9 @@ class Tape:
         # ... up to this many (tiles x channels) of partial sums.  Measured (tools/bench_bn_prologue.py, MI355X): a finalise
         # launch costs the chain 4-5 us; the prologue costs every workgroup of the consumer 2.8 us at 16 KB of partials,
         # 3.2 us at 32 KB, 4.5 us at 64 KB (no gain), 9 us at 128 KB (a loss): fused up to 32 KB
-        self.fuse_finalize_max = int(os.environ.get('DSNT_X_FUSE_FINALIZE_MAX', '4096'))
+        # (round 4, with one statistics row per workgroup from the 1x1 kernels: hg2 is indifferent between 0 and 4096 — 12.00-12.03
+        # ms — and hg8 at batch 16 is best at 2048: 26.64 vs 26.84 at 4096, 26.76 at 1024, 26.99 with separate launches only)
+        self.fuse_finalize_max = int(os.environ.get('DSNT_X_FUSE_FINALIZE_MAX', '2048'))
         # fp16x3 (default; DSNT_SPLIT=bf16x6 turns it off): two fp16 planes + three MFMAs instead of three bf16 planes + six, where an operand
         # bound is available without a host round-trip: train-mode BN+ReLU operands (bound from the BN parameters) and
         # weights (amax in the per-step prep launch)
