@@ -13,7 +13,7 @@ int dsnt_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" int dsnt_version(void) { return 110; }      // 110: dsnt_f16_prep_weights takes its row width; dsnt_conv1x1_bwd_*
+extern "C" int dsnt_version(void) { return 111; }      // 110: dsnt_f16_prep_weights takes its row width; dsnt_conv1x1_bwd_*; 111 (additive): dsnt_conv1x1_fwd_*, DSNT_BN_FROZEN, dsnt_maxpool2_bwd_add
 extern "C" const char* dsnt_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ launch lists

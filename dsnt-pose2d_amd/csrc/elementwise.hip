@@ -650,8 +650,10 @@ extern "C" int dsnt_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int N, 
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_fwd");
 }
 
+// (`extra`, optional: a second gradient of x — same layout as dx — added in the same pass: dx (+)= extra + the routed dy)
 __global__ void maxpool2_bwd_kernel(const float4* __restrict__ dy, const uchar4* __restrict__ idx,
-                                    float4* dx, int accumulate, int N, int H, int W, int C4, unsigned* amax) {
+                                    float4* dx, int accumulate, const float4* __restrict__ extra,
+                                    int N, int H, int W, int C4, unsigned* amax) {
     const int Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * Ho * Wo * C4;
     float am = 0.f;
@@ -671,6 +673,7 @@ __global__ void maxpool2_bwd_kernel(const float4* __restrict__ dy, const uchar4*
             float4 o = make_float4(k.x == p ? g.x : 0.f, k.y == p ? g.y : 0.f, k.z == p ? g.z : 0.f,
                                    k.w == p ? g.w : 0.f);
             if (accumulate) { const float4 c = *q; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+            if (extra) { const float4 e = extra[q - dx]; o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
             *q = o;
             am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am);
         }
@@ -678,24 +681,29 @@ __global__ void maxpool2_bwd_kernel(const float4* __restrict__ dy, const uchar4*
     if (amax) amax_commit(am, amax);
 }
 
-static int maxpool2_bwd_impl(const float* dy, const uint8_t* idx, float* dx, int accumulate, int N, int H, int W,
+static int maxpool2_bwd_impl(const float* dy, const uint8_t* idx, float* dx, int accumulate, const float* extra, int N, int H, int W,
                              int C, float* amax, void* stream);
 extern "C" int dsnt_maxpool2_bwd(const float* dy, const uint8_t* idx, float* dx, int accumulate,
                                  int N, int H, int W, int C, void* stream) {
-    return maxpool2_bwd_impl(dy, idx, dx, accumulate, N, H, W, C, nullptr, stream);
+    return maxpool2_bwd_impl(dy, idx, dx, accumulate, nullptr, N, H, W, C, nullptr, stream);
 }
 extern "C" int dsnt_maxpool2_bwd_amax(const float* dy, const uint8_t* idx, float* dx, int accumulate,
                                       int N, int H, int W, int C, float* amax, void* stream) {
-    return maxpool2_bwd_impl(dy, idx, dx, accumulate, N, H, W, C, amax, stream);
+    return maxpool2_bwd_impl(dy, idx, dx, accumulate, nullptr, N, H, W, C, amax, stream);
 }
-static int maxpool2_bwd_impl(const float* dy, const uint8_t* idx, float* dx, int accumulate, int N, int H, int W,
+extern "C" int dsnt_maxpool2_bwd_add(const float* dy, const uint8_t* idx, float* dx, int accumulate, const float* extra,
+                                     int N, int H, int W, int C, float* amax, void* stream) {
+    DSNT_REQUIRE(extra && extra != dx && dsnt_aligned16(extra), DSNT_ERR_ARG, "dsnt_maxpool2_bwd_add: `extra` must be a second, aligned tensor");
+    return maxpool2_bwd_impl(dy, idx, dx, accumulate, extra, N, H, W, C, amax, stream);
+}
+static int maxpool2_bwd_impl(const float* dy, const uint8_t* idx, float* dx, int accumulate, const float* extra, int N, int H, int W,
                              int C, float* amax, void* stream) {
     DSNT_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0, DSNT_ERR_ARG, "dsnt_maxpool2_bwd: bad argument");
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_bwd: H and W must be even");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dy) && dsnt_aligned16(dx), DSNT_ERR_ALIGN, "dsnt_maxpool2_bwd: alignment");
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
     DSNT_LAUNCH(maxpool2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, N, H, W, C / 4, (unsigned*)amax);
+                       (const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, (const float4*)extra, N, H, W, C / 4, (unsigned*)amax);
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_bwd");
 }
 

@@ -126,6 +126,7 @@ SIGNATURES = {
     'dsnt_fill_zero': [P, L, P],
     'dsnt_axpy_amax': [P, P, F, I, L, P, P],
     'dsnt_maxpool2_bwd_amax': [P, P, P, I, I, I, I, I, P, P],
+    'dsnt_maxpool2_bwd_add': [P, P, P, I, P, I, I, I, I, P, P],
     'dsnt_upsample2_bwd_amax': [P, P, I, I, I, I, I, P, P],
     'dsnt_maxpool2_fwd': [P, P, P, I, I, I, I, P],
     'dsnt_maxpool2_bwd': [P, P, P, I, I, I, I, I, P],

@@ -33,7 +33,7 @@ BN_MOMENTUM = 0.1
 class Act:
     """An activation on the tape: NHWC buffer + lazily created gradient / batch statistics."""
     __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'amax_tail', 'fold_ok',
-                 'pending_apply', 'uses', 'gives_away', 'is_branch', 'grad_shared')
+                 'pending_apply', 'uses', 'gives_away', 'is_branch', 'grad_shared', 'pending_add')
 
     def __init__(self, buf, name=''):
         self.buf = buf
@@ -48,6 +48,7 @@ class Act:
         self.gives_away = False     # the producer's backward DONATES this gradient's buffer onwards (residual inputs, upsample + add)
         self.is_branch = False  # `Tape.branch`: an alias of another activation (its gradient is joined to that one's)
         self.grad_shared = False    # .grad is another activation's buffer, read in place (Tape.share_grads): readers must not be deferred
+        self.pending_add = None     # (gradient tensor, its bound slot) the NEXT writer of .grad adds in its own pass (Tape.add_later)
         self.name = name
 
     @property
@@ -649,12 +650,24 @@ class Tape:
                 main.wait_stream(st)
 
     # ------------------------------------------------------------------ gradient plumbing
-    def grad_target(self, a, amax=False):
+    def add_later(self, a, g, g_amax=None):
+        """a.grad += g, left to the next writer of a.grad if that writer can add a second tensor in its own pass
+        (`maxpool2`'s backward: dsnt_maxpool2_bwd_add); any other writer first emits the addition as a launch of its own."""
+        assert a.grad is not None and a.pending_add is None
+        a.pending_add = (g, g_amax)
+
+    def _flush_add(self, a):
+        (g, g_amax), a.pending_add = a.pending_add, None
+        self.grad_identity(a, g, donate=False, g_amax=g_amax)
+
+    def grad_target(self, a, amax=False, take_add=False):
         """(buffer, accumulate flag) for a kernel about to write a's gradient.  `amax`: the kernel leaves max|written|
         in a.grad_amax (fp16x3 operand bound).  Every writer rewrites the whole tensor, so the slot stays a valid bound
         while all writers since its creation report into it; a writer that cannot invalidates it."""
         if a.pending_apply is not None:          # a BatchNorm backward left to a's producer, and now a second contribution
             self.materialize_apply(a)
+        if a.pending_add is not None and not take_add:
+            self._flush_add(a)                   # this writer cannot add a second tensor in its pass: the separate launch after all
         acc = 1
         if a.grad is None:
             a.grad = self.empty(a.N, a.H, a.W, a.C)
@@ -676,6 +689,8 @@ class Tape:
         g_amax: the bound slot of g, if it has one (it moves with a donated buffer)."""
         if a.pending_apply is not None:
             self.materialize_apply(a)
+        if a.pending_add is not None:
+            self._flush_add(a)
         if a.grad is None and donate:
             a.grad = g
             a.grad_amax = g_amax if self.amax_all else None
@@ -1207,8 +1222,13 @@ class Tape:
             self.f('dsnt_maxpool2_fwd', x.buf, y.buf, idx, x.N, x.H, x.W, x.C)
         if self.record:
             def backward():
-                buf, acc = self.grad_target(x, amax=True)
-                if x.grad_amax is not None:
+                add, x.pending_add = x.pending_add, None
+                buf, acc = self.grad_target(x, amax=True, take_add=True)
+                if add is not None:
+                    # a second gradient of x that arrived in a buffer of its own (the skip branch's: Hourglass._level) rides along
+                    assert acc == 1
+                    self.b('dsnt_maxpool2_bwd_add', y.grad, idx, buf, acc, add[0], x.N, x.H, x.W, x.C, x.grad_amax)
+                elif x.grad_amax is not None:
                     self.b('dsnt_maxpool2_bwd_amax', y.grad, idx, buf, acc, x.N, x.H, x.W, x.C, x.grad_amax)
                 else:
                     self.b('dsnt_maxpool2_bwd', y.grad, idx, buf, acc, x.N, x.H, x.W, x.C)

@@ -445,7 +445,12 @@ class Hourglass(TapeModule):
             def take_branch_gradient():         # registered after the pool: runs right before the pool's backward
                 t.sync_bwd(side, 0)
                 if xb.grad is not None:
-                    t.grad_identity(x, xb.grad, donate=True, g_amax=xb.grad_amax)
+                    if x.grad is not None and x.pending_apply is None and t.share_grads:
+                        # x holds a gradient already (the stack input of hourglass.py:175: the residual sum's came first) and the
+                        # branch's arrived in a buffer of its own: the pool's backward, next on the list, adds it in its pass
+                        t.add_later(x, xb.grad, xb.grad_amax)
+                    else:
+                        t.grad_identity(x, xb.grad, donate=True, g_amax=xb.grad_amax)
             t.on_backward(take_branch_gradient)
             low = _trace_seq(g[1], t, pooled, P)
             low = self._level(n - 1, t, low, P) if n > 1 else _trace_seq(g[3], t, low, P)

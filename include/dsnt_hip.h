@@ -493,6 +493,12 @@ int dsnt_fill_zero(float* p, int64_t n, void* stream);
 int dsnt_axpy_amax(const float* x, float* y, float a, int accumulate, int64_t n, float* amax, void* stream);
 int dsnt_maxpool2_bwd_amax(const float* dy, const uint8_t* idx, float* dx, int accumulate, int N, int H, int W, int C,
                            float* amax, void* stream);
+/* ... with a SECOND gradient of x added in the same pass: dx (+)= extra + the routed dy (amax may be NULL).  The hourglass's
+ * stack input (hourglass.py:66-77: `up1 = self.hg[n-1][0](x)`, `low1 = F.max_pool2d(x, 2)` — and x also feeds the residual sum of
+ * hourglass.py:175) collects three gradients; the skip branch's arrives in a buffer of its own, and this launch adds it instead of a
+ * separate x.grad += branch.grad pass. */
+int dsnt_maxpool2_bwd_add(const float* dy, const uint8_t* idx, float* dx, int accumulate, const float* extra,
+                          int N, int H, int W, int C, float* amax, void* stream);
 int dsnt_upsample2_bwd_amax(const float* dout, float* dlow, int accumulate, int N, int H, int W, int C, float* amax,
                             void* stream);
 

@@ -180,6 +180,7 @@ def test_batchnorm_pieces(M, Cc):
 @pytest.mark.parametrize('N,H,W,Cc', [(2, 8, 8, 256), (3, 4, 6, 64), (1, 64, 64, 128)])
 def test_pool_upsample(N, H, W, Cc):
     from dsnt._lib import ptr, call
+    from dsnt._lib import fn as _lib_fn
     dev = torch.device('cuda:0')
     x = synthetic.tensor('px', (N, Cc, H, W), seed=5).requires_grad_()
     y_ref = F.max_pool2d(x, 2, stride=2)
@@ -196,6 +197,17 @@ def test_pool_upsample(N, H, W, Cc):
     assert torch.equal(dx.cpu().permute(0, 3, 1, 2), x.grad)
     call('dsnt_maxpool2_bwd', ptr(gyd), ptr(idx), ptr(dx), 1, N, H, W, Cc)
     assert torch.equal(dx.cpu().permute(0, 3, 1, 2), 2 * x.grad)
+    # ... with a second gradient of x added in the same pass (dsnt_maxpool2_bwd_add): dx (+)= extra + routed dy, and max |dx| out
+    extra = _nhwc(synthetic.tensor('pe', (N, Cc, H, W), seed=7)).to(dev)
+    base = dx.clone()
+    am = torch.zeros(64, device=dev)
+    call('dsnt_maxpool2_bwd_add', ptr(gyd), ptr(idx), ptr(dx), 1, ptr(extra), N, H, W, Cc, ptr(am))
+    want = (base + extra) + _nhwc(x.grad).to(dev)
+    assert (dx - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+    assert am.max().item() == dx.abs().max().item()
+    call('dsnt_maxpool2_bwd_add', ptr(gyd), ptr(idx), ptr(dx), 0, ptr(extra), N, H, W, Cc, None)
+    assert torch.equal(dx, extra + _nhwc(x.grad).to(dev))
+    assert _lib_fn('dsnt_maxpool2_bwd_add')(ptr(gyd), ptr(idx), ptr(dx), 1, ptr(dx), N, H, W, Cc, None, None) != 0     # extra must be a second tensor
 
     up = synthetic.tensor('uu', (N, Cc, H, W), seed=6)
     low = synthetic.tensor('ul', (N, Cc, H // 2, W // 2), seed=6).requires_grad_()

@@ -75,10 +75,13 @@ def test_backward_list_lanes_and_fusions(tape):
     assert all(lane == 2 for n, lane, _ in bwd if n in ('dsnt_wgrad_reduce_all', 'dsnt_conv_wgrad_group'))
     marks = [(e[1], e[3]) for e in tape.bwd if e[0] is None and e[2] == 'bucket']
     assert marks == [(2, 2), (1, 2), (0, 2)]
-    # every skip branch's gradient is joined inside the pool's backward: accumulate = 1 there, two axpy launches left
-    pools = [a for n, _, a in bwd if n.startswith('dsnt_maxpool2_bwd')]
-    assert len(pools) == 9 and sum(1 for a in pools if a[3] == 1) == 8
-    assert sum(1 for n, _, _ in bwd if n.startswith('dsnt_axpy')) == 1    # (x.grad += the top-level skip branch's gradient of stack 0; fc_ shares dL/dy)
+    # every skip branch's gradient is joined inside the pool's backward: accumulate = 1 there.  The stack input that also feeds the
+    # intermediate-supervision sum (hourglass.py:175) holds that sum's gradient already when its branch's arrives in a buffer of its
+    # own: the pool's backward adds it in the same pass (dsnt_maxpool2_bwd_add), and fc_ READS dL/dy in place — no axpy launch left
+    pools = [(n, a) for n, _, a in bwd if n.startswith('dsnt_maxpool2_bwd')]
+    assert len(pools) == 9 and sum(1 for _, a in pools if a[3] == 1) == 8
+    assert sum(1 for n, _ in pools if n == 'dsnt_maxpool2_bwd_add') == 1
+    assert sum(1 for n, _, _ in bwd if n.startswith('dsnt_axpy')) == 0
     # nothing of the per-step weight preparation is left at the head of the backward list
     assert [n for n, _, _ in bwd[:3]][0] == 'dsnt_fill_zero' and 'dsnt_conv_pack_dgrad_all' not in [n for n, _, _ in bwd]
 
