@@ -492,7 +492,10 @@ __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const flo
                                         const float4* __restrict__ scale, const float4* __restrict__ shift,
                                         const float4* __restrict__ mean, const float4* __restrict__ invstd,
                                         const float4* coef, int relu, float4* dx,
-                                        int accumulate, long n4, int C4, unsigned* __restrict__ amax, BnBwdProP pro) {
+                                        const float4* base, long n4, int C4, unsigned* __restrict__ amax, BnBwdProP pro) {
+    // base: what the result is added to — null (dx = value), dx itself (accumulate in place) or ANOTHER tensor (dx = base + value:
+    // the gradient it continues stays intact for a reader that comes later, dsnt_bn_act_bwd_apply_base)
+    const bool accumulate = base != nullptr;
     if (pro.partial) {                   // dsnt_bn_act_bwd_apply_pro: coef / dgamma / dbeta from the tile sums, here
         __shared__ double pro_sh[256];
         bn_pro_backward<256>(pro, pro_sh, blockIdx.x == 0);
@@ -512,7 +515,7 @@ __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const flo
         for (; i + stride < n4; i += 2 * stride) {
             const float4 g0 = da[i], x0 = x[i], g1 = da[i + stride], x1 = x[i + stride];
             float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-            if (accumulate) { p0 = dx[i]; p1 = dx[i + stride]; }
+            if (accumulate) { p0 = base[i]; p1 = base[i + stride]; }
             float4 o0 = bn_apply_one(g0, x0, v, relu), o1 = bn_apply_one(g1, x1, v, relu);
             if (accumulate) {
                 o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
@@ -523,14 +526,14 @@ __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const flo
         }
         if (i < n4) {
             float4 o = bn_apply_one(da[i], x[i], v, relu);
-            if (accumulate) { const float4 p = dx[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+            if (accumulate) { const float4 p = base[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
             dx[i] = o;
             amx(o);
         }
     } else {
         for (; i < n4; i += stride) {
             float4 o = bn_apply_one(da[i], x[i], vec((int)(i % C4)), relu);
-            if (accumulate) { const float4 p = dx[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+            if (accumulate) { const float4 p = base[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
             dx[i] = o;
             amx(o);
         }
@@ -541,7 +544,7 @@ __global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const flo
 static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, const float* coef, int relu, float* dx,
                                  int accumulate, int64_t M, int C, float* amax, void* stream,
-                                 const BnBwdProP* pro = nullptr);
+                                 const BnBwdProP* pro = nullptr, const float* base = nullptr);
 
 extern "C" int dsnt_bn_act_bwd_apply_amax(const float* da, const float* x, const float* scale,
                                           const float* shift, const float* mean, const float* invstd,
@@ -569,11 +572,12 @@ extern "C" int dsnt_bn_act_bwd_apply(const float* da, const float* x, const floa
 
 static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, const float* coef, int relu, float* dx,
-                                 int accumulate, int64_t M, int C, float* amax, void* stream, const BnBwdProP* pro) {
+                                 int accumulate, int64_t M, int C, float* amax, void* stream, const BnBwdProP* pro, const float* base) {
     DSNT_REQUIRE(da && x && scale && shift && mean && invstd && coef && dx && M > 0 && C > 0,
                  DSNT_ERR_ARG, "dsnt_bn_act_bwd_apply: bad argument");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(da) && dsnt_aligned16(x) && dsnt_aligned16(dx) &&
-                 dsnt_aligned16(coef), DSNT_ERR_ALIGN, "dsnt_bn_act_bwd_apply: alignment");
+                 dsnt_aligned16(coef) && dsnt_aligned16(base), DSNT_ERR_ALIGN, "dsnt_bn_act_bwd_apply: alignment");
+    if (!base && accumulate) base = dx;
     const long n4 = (long)M * C / 4;
     int grid = flat_grid(n4, 256);
     BnBwdProP q;
@@ -587,12 +591,12 @@ static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* s
         DSNT_LAUNCH(bn_act_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0,
                     (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
                     (const float4*)shift, (const float4*)mean, (const float4*)invstd,
-                    (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax, q);
+                    (const float4*)coef, relu, (float4*)dx, (const float4*)base, n4, C / 4, (unsigned*)amax, q);
     else
         DSNT_LAUNCH(bn_act_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0,
                     (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
                     (const float4*)shift, (const float4*)mean, (const float4*)invstd,
-                    (const float4*)coef, relu, (float4*)dx, accumulate, n4, C / 4, (unsigned*)amax, q);
+                    (const float4*)coef, relu, (float4*)dx, (const float4*)base, n4, C / 4, (unsigned*)amax, q);
     DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_apply");
 }
 
@@ -609,6 +613,27 @@ extern "C" int dsnt_bn_act_bwd_apply_pro(const float* da, const float* x, const 
     q.partial = partial; q.tiles = ntiles; q.C = C; q.invM = 1.0 / (double)M;
     q.dgamma = dgamma; q.dbeta = dbeta; q.accumulate = accumulate_params; q.coef = coef;
     return bn_act_bwd_apply_impl(da, x, scale, shift, mean, invstd, coef, relu, dx, accumulate, M, C, amax, stream, &q);
+}
+// dx = base + value with `base` a tensor of its own (read, never written): the gradient that dx continues stays intact — for a
+// weight gradient that reads it at the end of its parameter bucket (the grouped launch), after dx has long been written.
+// amax may be NULL.  The _pro form: dsnt_bn_act_bwd_apply_pro likewise.
+extern "C" int dsnt_bn_act_bwd_apply_base(const float* da, const float* x, const float* scale, const float* shift,
+                                          const float* mean, const float* invstd, const float* coef, int relu,
+                                          const float* base, float* dx, int64_t M, int C, float* amax, void* stream) {
+    DSNT_REQUIRE(base && base != dx, DSNT_ERR_ARG, "dsnt_bn_act_bwd_apply_base: `base` must be a second tensor");
+    return bn_act_bwd_apply_impl(da, x, scale, shift, mean, invstd, coef, relu, dx, 1, M, C, amax, stream, nullptr, base);
+}
+extern "C" int dsnt_bn_act_bwd_apply_pro_base(const float* da, const float* x, const float* scale, const float* shift,
+                                              const float* mean, const float* invstd, const float* partial, int ntiles,
+                                              float* dgamma, float* dbeta, int accumulate_params, float* coef, int relu,
+                                              const float* base, float* dx, int64_t M, int C, float* amax, void* stream) {
+    DSNT_REQUIRE(base && base != dx, DSNT_ERR_ARG, "dsnt_bn_act_bwd_apply_pro_base: `base` must be a second tensor");
+    DSNT_REQUIRE(partial && ntiles > 0 && coef && C <= 256 && (long)ntiles * C <= 16384, DSNT_ERR_ARG,
+                 "dsnt_bn_act_bwd_apply_pro_base: needs partial sums of at most 256 channels / 128 KB and a coef buffer");
+    BnBwdProP q;
+    q.partial = partial; q.tiles = ntiles; q.C = C; q.invM = 1.0 / (double)M;
+    q.dgamma = dgamma; q.dbeta = dbeta; q.accumulate = accumulate_params; q.coef = coef;
+    return bn_act_bwd_apply_impl(da, x, scale, shift, mean, invstd, coef, relu, dx, 1, M, C, amax, stream, &q, base);
 }
 // ---------------------------------------------------------------- pooling / upsampling
 __global__ void maxpool2_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y,

@@ -122,6 +122,8 @@ SIGNATURES = {
     'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
     'dsnt_bn_act_bwd_apply_amax': [P, P, P, P, P, P, P, I, P, I, L, I, P, P],
     'dsnt_bn_act_bwd_apply_pro': [P, P, P, P, P, P, P, I, P, P, I, P, I, P, I, L, I, P, P],
+    'dsnt_bn_act_bwd_apply_base': [P, P, P, P, P, P, P, I, P, P, L, I, P, P],
+    'dsnt_bn_act_bwd_apply_pro_base': [P, P, P, P, P, P, P, I, P, P, I, P, I, P, P, L, I, P, P],
     'dsnt_conv_fwd_pro': [P, P, P, P, PP, I, P, P, P, GP, TP, P],
     'dsnt_fill_zero': [P, L, P],
     'dsnt_axpy_amax': [P, P, F, I, L, P, P],

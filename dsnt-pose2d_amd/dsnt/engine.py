@@ -32,13 +32,16 @@ BN_MOMENTUM = 0.1
 
 class Act:
     """An activation on the tape: NHWC buffer + lazily created gradient / batch statistics."""
-    __slots__ = ('buf', 'N', 'H', 'W', 'C', 'grad', 'stats', 'name', 'grad_amax', 'amax_tail', 'fold_ok',
-                 'pending_apply', 'uses', 'gives_away', 'is_branch', 'grad_shared', 'pending_add')
+    __slots__ = ('buf', 'N', 'H', 'W', 'C', '_grad', 'stats', 'name', 'grad_amax', 'amax_tail', 'fold_ok',
+                 'pending_apply', 'uses', 'gives_away', 'is_branch', 'grad_shared', 'pending_add', 'base', 'base_amax')
 
     def __init__(self, buf, name=''):
         self.buf = buf
         self.N, self.H, self.W, self.C = buf.shape
-        self.grad = None        # torch tensor once some backward op has written it
+        self._grad = None       # torch tensor once some backward op has written it (`grad`)
+        # a gradient this activation's CONTINUES without owning it (Tape.conv's backward, `defer_res`): the next writer writes
+        # base + its value into a buffer of its own (`Tape.grad_target`), so that the base stays intact for a deferred reader
+        self.base, self.base_amax = None, None
         self.stats = None       # (partial tensor, ntiles)
         self.amax_tail = None   # fp16x3: the dsnt_out_bounds of the producing launch if it can leave max|buf| (operand_amax)
         self.grad_amax = None   # fp16x3: device scalar max|grad| when ONE bn-backward apply wrote the whole gradient
@@ -54,6 +57,18 @@ class Act:
     @property
     def M(self):
         return self.N * self.H * self.W
+
+    @property
+    def grad(self):
+        if self._grad is None and self.base is not None:
+            # read before any further writer came: the gradient IS the base, read in place (`base` stays set: a later writer
+            # still goes out of place, `Tape.grad_target`)
+            self._grad, self.grad_amax, self.grad_shared = self.base, self.base_amax, True
+        return self._grad
+
+    @grad.setter
+    def grad(self, g):
+        self._grad = g
 
 
 class ConvParams:
@@ -147,8 +162,13 @@ class Tape:
         # 7 per hg8 step.  (The OTHER pass there — x.grad += the skip branch's gradient, Hourglass._level — stays: both buffers
         # arrive by donation, and folding the sum into the branch's last apply would need a five-stream form of that kernel.)
         self.share_grads = self._x.get('share_grads', '1') != '0'
+        # the weight gradient of a low-resolution convolution WITH residual inputs (conv3 of a Bottleneck: 2-32 workgroups, 17-25 us
+        # on the dependency chain each; 15 per hg2 step, 63 per hg8 step) joins its bucket's grouped launch too: its dL/dy is not
+        # donated to the residual input but becomes the `base` that input's gradient continues out of place (Act.base)
+        self.defer_res = self._x.get('defer_res', '1') != '0'
         self.cur_bucket = 0         # parameter bucket of the layers being traced (mark_bucket)
         self._wgrad_lane_reads = set()
+        self._writer_base = None
         # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
         # phase: a `release point` is the backward of an up-sampling whose low-resolution operand has at most
         # DSNT_WGRAD_RELEASE_ROWS rows.  Issued as they come, the weight gradients share the chip with the large
@@ -660,7 +680,12 @@ class Tape:
         (g, g_amax), a.pending_add = a.pending_add, None
         self.grad_identity(a, g, donate=False, g_amax=g_amax)
 
-    def grad_target(self, a, amax=False, take_add=False):
+    def take_base(self):
+        """After grad_target(..., base_ok=True): the tensor the writer has to add to its value (or None)."""
+        b, self._writer_base = self._writer_base, None
+        return b
+
+    def grad_target(self, a, amax=False, take_add=False, base_ok=False):
         """(buffer, accumulate flag) for a kernel about to write a's gradient.  `amax`: the kernel leaves max|written|
         in a.grad_amax (fp16x3 operand bound).  Every writer rewrites the whole tensor, so the slot stays a valid bound
         while all writers since its creation report into it; a writer that cannot invalidates it."""
@@ -668,6 +693,24 @@ class Tape:
             self.materialize_apply(a)
         if a.pending_add is not None and not take_add:
             self._flush_add(a)                   # this writer cannot add a second tensor in its pass: the separate launch after all
+        self._writer_base = None
+        if a.base is not None:
+            # a's gradient continues one it does not own: base + this writer's value go into a NEW buffer.  A writer that can
+            # read the base itself (base_ok: `take_base`) does that in its own pass; any other finds a copy in place
+            base, base_amax, a.base, a.base_amax = a.base, a.base_amax, None, None
+            a._grad, a.grad_shared = self.empty(a.N, a.H, a.W, a.C), False
+            if self.use_f16x3 and amax and self.amax_all:
+                a.grad_amax = self.amax_slot()
+            else:
+                a.grad_amax = None
+            if base_ok:
+                self._writer_base = base
+                return a._grad, 0
+            if a.grad_amax is not None:
+                self.b('dsnt_axpy_amax', base, a._grad, 1.0, 0, base.numel(), a.grad_amax)
+            else:
+                self.b('dsnt_axpy', base, a._grad, 1.0, 0, base.numel())
+            return a._grad, 1
         acc = 1
         if a.grad is None:
             a.grad = self.empty(a.N, a.H, a.W, a.C)
@@ -819,12 +862,20 @@ class Tape:
             bn.uses += 1
             if not fused:
                 self.b('dsnt_bn_bwd_finalize', part, tiles, x.M, bn.C, bn.ggamma, bn.gbeta, acc_p | (2 if frozen else 0), coef)
-        buf, acc = self.grad_target(x, amax='apply')
+        buf, acc = self.grad_target(x, amax='apply', base_ok=True)
+        base = self.take_base()         # x's gradient continues one it does not own: dx = base + value (`conv`, defer_res)
         if fused:
             # few tiles: the apply launch sums them itself in its prologue (coef) and writes dgamma / dbeta
             coef = self.empty(2 * bn.C)          # private: the launch writes it (a shared scratch could still be in use)
-            self.b('dsnt_bn_act_bwd_apply_pro', da, x.buf, n.scale, n.shift, n.mean, n.invstd, part, tiles,
-                   bn.ggamma, bn.gbeta, acc_p, coef, relu, buf, acc, x.M, bn.C, x.grad_amax)
+            if base is not None:
+                self.b('dsnt_bn_act_bwd_apply_pro_base', da, x.buf, n.scale, n.shift, n.mean, n.invstd, part, tiles,
+                       bn.ggamma, bn.gbeta, acc_p, coef, relu, base, buf, x.M, bn.C, x.grad_amax)
+            else:
+                self.b('dsnt_bn_act_bwd_apply_pro', da, x.buf, n.scale, n.shift, n.mean, n.invstd, part, tiles,
+                       bn.ggamma, bn.gbeta, acc_p, coef, relu, buf, acc, x.M, bn.C, x.grad_amax)
+        elif base is not None:
+            self.b('dsnt_bn_act_bwd_apply_base', da, x.buf, n.scale, n.shift, n.mean, n.invstd, coef, relu,
+                   base, buf, x.M, bn.C, x.grad_amax)
         elif x.grad_amax is not None:
             self.b('dsnt_bn_act_bwd_apply_amax', da, x.buf, n.scale, n.shift, n.mean, n.invstd, coef, relu,
                    buf, acc, x.M, bn.C, x.grad_amax)
@@ -936,6 +987,7 @@ class Tape:
             if fused and ap is None and y.grad_amax is None:
                 fused = False
             cur = wl = self.lane
+            defer_res = False
             if fused:
                 nw = p.w.numel()
                 shr = 2 if (self.lane != 0 and self.conv_share) else 0
@@ -1023,8 +1075,14 @@ class Tape:
                     # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
                     # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
                     # (... nor shared with an activation whose gradient is accumulated into later: `share_grads`)
-                    grouped = (w6 and normed and res1 is None and res2 is None and wl == cur and not y.grad_shared and
-                               0 < g.N * g.Ho * g.Wo <= self.group_rows)
+                    groupable = (w6 and normed and wl == cur and not y.grad_shared and 0 < g.N * g.Ho * g.Wo <= self.group_rows)
+                    # ... or, WITH residual inputs (conv3 of the low-resolution Bottlenecks): dL/dy is not donated to them but
+                    # handed over as the `base` their own gradient continues out of place, and so stays intact as well
+                    residuals = [r for r in (res1, res2) if r is not None]
+                    defer_res = bool(groupable and residuals and self.share_grads and self.defer_res and all(
+                        r._grad is None and r.base is None and r.pending_apply is None and r.pending_add is None and not r.is_branch
+                        for r in residuals))
+                    grouped = groupable and (not residuals or defer_res)
                     # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
                     w16 = w6 and self.use_f16x3 and (normed or x_amax is not None) and y.grad_amax is not None
                     ab = (self.f16_bn_bound_bwd(src) if normed else x_amax) if w16 else None
@@ -1162,6 +1220,9 @@ class Tape:
                 self.sync_bwd(wl, cur)
             donated = False
             for r in (res1, res2):
+                if r is not None and defer_res:
+                    r.base, r.base_amax = gy, (y.grad_amax if self.amax_all else None)
+                    continue
                 if r is not None:
                     if (donated and self.share_grads and r.grad is None and r.pending_apply is None and r.uses == 1 and
                             not r.gives_away and not r.is_branch):

@@ -486,6 +486,17 @@ int dsnt_bn_act_bwd_apply_pro(const float* da, const float* x, const float* scal
                               const float* mean, const float* invstd, const float* partial, int ntiles,
                               float* dgamma, float* dbeta, int accumulate_params, float* coef, int relu,
                               float* dx, int accumulate, int64_t M, int C, float* amax, void* stream);
+/* Both with the result added to a tensor of its OWN instead of accumulated in place: dx = base + value, `base` read and never
+ * written (amax may be NULL).  The gradient that dx continues — dL/d(block output) of a Bottleneck, hourglass.py:48 `out += residual`
+ * — stays intact for a reader that comes later: the weight gradient of the block's conv3 then waits for its parameter bucket's grouped
+ * launch like the other low-resolution weight gradients, instead of costing the dependency chain a launch of 2..32 workgroups. */
+int dsnt_bn_act_bwd_apply_base(const float* da, const float* x, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* coef, int relu,
+                               const float* base, float* dx, int64_t M, int C, float* amax, void* stream);
+int dsnt_bn_act_bwd_apply_pro_base(const float* da, const float* x, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, const float* partial, int ntiles,
+                                   float* dgamma, float* dbeta, int accumulate_params, float* coef, int relu,
+                                   const float* base, float* dx, int64_t M, int C, float* amax, void* stream);
 int dsnt_fill_zero(float* p, int64_t n, void* stream);
 /* The other kernels that (re)write a whole gradient tensor, with the same amax side output: a tensor written by several
  * of them in turn is bounded by the maximum over their amaxes (each rewrites all of it), so gradients accumulated along
