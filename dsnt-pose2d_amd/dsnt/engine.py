@@ -1080,7 +1080,7 @@ class Tape:
                     # handed over as the `base` their own gradient continues out of place, and so stays intact as well
                     residuals = [r for r in (res1, res2) if r is not None]
                     defer_res = bool(groupable and residuals and self.share_grads and self.defer_res and all(
-                        r._grad is None and r.base is None and r.pending_apply is None and r.pending_add is None and not r.is_branch
+                        r._grad is None and r.base is None and r.pending_apply is None and r.pending_add is None
                         for r in residuals))
                     grouped = groupable and (not residuals or defer_res)
                     # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
