@@ -21,11 +21,14 @@ static inline unsigned tile_grid_y(long tiles, int C4) { const int c = tile_cgs(
 
 // ---------------------------------------------------------------- per-channel tile reductions
 // MODE 0: (sum x, sum x^2)          MODE 1: (sum dz, sum dz*xhat) for y = relu?(bn(x))
+// MODE 2: the same sums for y = relu?(bn(x) + skip) (the tail of a torchvision residual block): the ReLU mask comes from the stored
+// output (`ymask` > 0) and dz = a * mask is WRITTEN (`dz_out`: the skip branch's gradient and the apply pass read it)
 template <int MODE>
 __global__ __launch_bounds__(256) void tile_reduce_kernel(
     const float* __restrict__ a, const float* __restrict__ x, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, int relu, float* __restrict__ partial, long M, int C, int cgs) {
+    const float* __restrict__ invstd, int relu, float* __restrict__ partial, long M, int C, int cgs,
+    const float* __restrict__ ymask = nullptr, float* __restrict__ dz_out = nullptr) {
     __shared__ float red[256 * 8];
     const int tid = threadIdx.x;
     const int C4 = C >> 2;
@@ -42,6 +45,8 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(
             if (MODE == 1) {
                 sc = reinterpret_cast<const float4*>(scale)[cg];
                 sh = reinterpret_cast<const float4*>(shift)[cg];
+            }
+            if (MODE >= 1) {
                 mu = reinterpret_cast<const float4*>(mean)[cg];
                 is = reinterpret_cast<const float4*>(invstd)[cg];
             }
@@ -54,7 +59,16 @@ __global__ __launch_bounds__(256) void tile_reduce_kernel(
                 } else {
                     const float4 xv = reinterpret_cast<const float4*>(x + r * C)[cg];
                     float4 dz = v;
-                    if (relu) {
+                    if (MODE == 2) {
+                        if (relu) {
+                            const float4 yv = reinterpret_cast<const float4*>(ymask + r * C)[cg];
+                            if (yv.x <= 0.f) dz.x = 0.f;
+                            if (yv.y <= 0.f) dz.y = 0.f;
+                            if (yv.z <= 0.f) dz.z = 0.f;
+                            if (yv.w <= 0.f) dz.w = 0.f;
+                        }
+                        reinterpret_cast<float4*>(dz_out + r * C)[cg] = dz;
+                    } else if (relu) {
                         if (fmaf(xv.x, sc.x, sh.x) <= 0.f) dz.x = 0.f;
                         if (fmaf(xv.y, sc.y, sh.y) <= 0.f) dz.y = 0.f;
                         if (fmaf(xv.z, sc.z, sh.z) <= 0.f) dz.z = 0.f;
@@ -281,6 +295,19 @@ extern "C" int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const flo
     DSNT_LAUNCH(tile_reduce_kernel<1>, dim3(tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0, (hipStream_t)stream, da, x,
                        scale, shift, mean, invstd, relu, partial, (long)M, C, tile_cgs(tiles, C / 4));
     DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_reduce");
+}
+
+// The backward of y = relu?(bn(x) + skip) up to the BatchNorm's two reductions, in one pass: dz = da * (y > 0) written, and the
+// tile sums (sum dz, sum dz * xhat) for dsnt_bn_bwd_finalize — dsnt_relu_bwd + dsnt_bn_act_bwd_reduce(relu = 0) as one launch.
+extern "C" int dsnt_bn_add_act_bwd_reduce(const float* da, const float* y, const float* x, const float* mean, const float* invstd,
+                                          int relu, float* dz, float* partial, int64_t M, int C, void* stream) {
+    DSNT_REQUIRE(da && y && x && mean && invstd && dz && partial && M > 0 && C > 0, DSNT_ERR_ARG, "dsnt_bn_add_act_bwd_reduce: bad argument");
+    DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(x) && dsnt_aligned16(da) && dsnt_aligned16(y) && dsnt_aligned16(dz) && dsnt_aligned16(partial) &&
+                 dsnt_aligned16(mean) && dsnt_aligned16(invstd), DSNT_ERR_ALIGN, "dsnt_bn_add_act_bwd_reduce: C %% 4 and 16-byte alignment required");
+    const int tiles = (int)((M + TILE_ROWS - 1) / TILE_ROWS);
+    DSNT_LAUNCH(tile_reduce_kernel<2>, dim3(tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0, (hipStream_t)stream, da, x,
+                       nullptr, nullptr, mean, invstd, relu, partial, (long)M, C, tile_cgs(tiles, C / 4), y, dz);
+    DSNT_CHECK_LAUNCH("dsnt_bn_add_act_bwd_reduce");
 }
 
 // Combine tile partials: 16 channels x 64 tile-lanes per 1024-thread block (the kernel is pure

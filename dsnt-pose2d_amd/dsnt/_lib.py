@@ -122,6 +122,7 @@ SIGNATURES = {
     'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
     'dsnt_bn_act_bwd_apply_amax': [P, P, P, P, P, P, P, I, P, I, L, I, P, P],
     'dsnt_bn_act_bwd_apply_pro': [P, P, P, P, P, P, P, I, P, P, I, P, I, P, I, L, I, P, P],
+    'dsnt_bn_add_act_bwd_reduce': [P, P, P, P, P, I, P, P, L, I, P],
     'dsnt_bn_act_bwd_apply_base': [P, P, P, P, P, P, P, I, P, P, L, I, P, P],
     'dsnt_bn_act_bwd_apply_pro_base': [P, P, P, P, P, P, P, I, P, P, I, P, I, P, P, L, I, P, P],
     'dsnt_conv_fwd_pro': [P, P, P, P, PP, I, P, P, P, GP, TP, P],

@@ -169,6 +169,7 @@ class Tape:
         self.cur_bucket = 0         # parameter bucket of the layers being traced (mark_bucket)
         self._wgrad_lane_reads = set()
         self._writer_base = None
+        self._ident = None
         # ... and they are HELD BACK (launches collected, not yet on the list) until the chain enters a launch-bound
         # phase: a `release point` is the backward of an up-sampling whose low-resolution operand has at most
         # DSNT_WGRAD_RELEASE_ROWS rows.  Issued as they come, the weight gradients share the chip with the large
@@ -680,6 +681,14 @@ class Tape:
         (g, g_amax), a.pending_add = a.pending_add, None
         self.grad_identity(a, g, donate=False, g_amax=g_amax)
 
+    def identity_bn(self, Cc):
+        """(ones, zeros) of >= Cc channels: the BatchNorm prologue that changes nothing (a raw operand for a launch form that only
+        exists with a prologue — the grouped weight gradients)."""
+        if self._ident is None or self._ident[0].numel() < Cc:
+            n = max(Cc, 2048)
+            self._ident = (torch.ones(n, device=self.device), torch.zeros(n, device=self.device))
+        return self._ident
+
     def take_base(self):
         """After grad_target(..., base_ok=True): the tensor the writer has to add to its value (or None)."""
         b, self._writer_base = self._writer_base, None
@@ -1075,7 +1084,9 @@ class Tape:
                     # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
                     # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
                     # (... nor shared with an activation whose gradient is accumulated into later: `share_grads`)
-                    groupable = (w6 and normed and wl == cur and not y.grad_shared and 0 < g.N * g.Ho * g.Wo <= self.group_rows)
+                    # (a RAW operand — conv1 of a torchvision BasicBlock, resnet.py — rides with the identity prologue: scale 1, shift 0)
+                    groupable = (w6 and (normed or self.share_grads) and wl == cur and not y.grad_shared and
+                                 0 < g.N * g.Ho * g.Wo <= self.group_rows)
                     # ... or, WITH residual inputs (conv3 of the low-resolution Bottlenecks): dL/dy is not donated to them but
                     # handed over as the `base` their own gradient continues out of place, and so stays intact as well
                     residuals = [r for r in (res1, res2) if r is not None]
@@ -1095,18 +1106,20 @@ class Tape:
                     self._ws_ptrs.add(ws.data_ptr())
                     if grouped:
                         desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
+                        gsc, gsh = (sc, sh) if normed else self.identity_bn(x.C)
                         if w16:
-                            nblk = self.lib.dsnt_conv_wgrad_desc_f16x3(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
+                            nblk = self.lib.dsnt_conv_wgrad_desc_f16x3(_lib.ptr(x.buf), _lib.ptr(gsc), _lib.ptr(gsh), relu,
                                                                        _lib.ptr(gy), _lib.ptr(ws), _lib.ptr(ab),
                                                                        _lib.ptr(y.grad_amax), C.byref(g), desc)
                         else:
-                            nblk = self.lib.dsnt_conv_wgrad_desc(_lib.ptr(x.buf), _lib.ptr(sc), _lib.ptr(sh), relu,
+                            nblk = self.lib.dsnt_conv_wgrad_desc(_lib.ptr(x.buf), _lib.ptr(gsc), _lib.ptr(gsh), relu,
                                                                  _lib.ptr(gy), _lib.ptr(ws), C.byref(g), desc)
                         if nblk <= 0:
                             raise RuntimeError('dsnt_conv_wgrad_desc failed: %s' % self.lib.dsnt_last_error().decode())
                         self._pending_group.append((desc.raw, nblk))
                         if w16:
-                            self._pending_group_uses.append(dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu,
+                            self._pending_group_uses.append(dict(kind='wgrad', name=name, x=x.buf, sc=sc if normed else None,
+                                                                 sh=sh if normed else None, relu=relu,
                                                                  a_bound=ab, g=gy, g_bound=y.grad_amax))
                     elif w16:
                         e = self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, share, ab, y.grad_amax, g)
@@ -1208,12 +1221,13 @@ class Tape:
                         self._norm_backward(src, dz, reduced=(part, tiles), dz_amax=dz_amax)
                     else:
                         # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
-                        buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16)
+                        buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16, base_ok=True)
+                        base = self.take_base()         # (x's gradient continues one it does not own: the residual operand)
                         tl = None
                         if x.grad_amax is not None:
                             tl = BnTail()
                             tl.amax = x.grad_amax.data_ptr()
-                        dgrad(buf, buf if acc else None, tail=tl)
+                        dgrad(buf, base if base is not None else (buf if acc else None), tail=tl)
             # identity branches last: gy is dead after the launches above (the weight-gradient lane
             # must have read it before anyone accumulates into the donated buffer)
             if res1 is not None or res2 is not None:
@@ -1323,12 +1337,23 @@ class Tape:
         if self.record:
             def backward():
                 if relu:
+                    # the ReLU mask (from the stored y), dz and the BatchNorm's two reductions in ONE pass
                     dz = self.scratch('dz_tail', x.M * x.C).view(-1)[:x.M * x.C]
-                    self.b('dsnt_relu_bwd', y.grad, y.buf, dz, x.M * x.C)
+                    tiles = (x.M + 127) // 128
+                    part = self.scratch('bnpart', tiles * 2 * bn.C).view(-1)
+                    self.b('dsnt_bn_add_act_bwd_reduce', y.grad, y.buf, x.buf, n.mean, n.invstd, 1, dz, part, x.M, bn.C)
+                    self._norm_backward(n, dz, reduced=(part, tiles))
                 else:
                     dz = y.grad
-                self._norm_backward(n, dz)
-                self.grad_identity(skip, dz, donate=False)
+                    self._norm_backward(n, dz)
+                if (self.share_grads and skip._grad is None and skip.base is None and skip.pending_apply is None and
+                        skip.pending_add is None):
+                    # the block input's gradient starts as dz and continues out of place (the data gradient of conv1 adds it as its
+                    # residual operand): no copy.  dz is scratch — it lives until the NEXT bn_add_act's backward, which comes after
+                    # every reader of this one (the blocks are a chain); a reader that would be deferred is not (grad_shared)
+                    skip.base, skip.base_amax = dz, None
+                else:
+                    self.grad_identity(skip, dz, donate=False)
             self.on_backward(backward)
         return y
 

@@ -459,6 +459,11 @@ int dsnt_bn_eval_prep(const int64_t* table, int rows, void* stream);
 int dsnt_bn_act_bwd_reduce(const float* da, const float* x, const float* scale,
                            const float* shift, const float* mean, const float* invstd,
                            int relu, float* partial, int64_t M, int C, void* stream);
+/* ... of y = relu?(bn(x) + skip) (`out = relu(bn2(conv2(..)) + identity)`, the tail of a torchvision BasicBlock / Bottleneck): the ReLU
+ * mask is taken from the stored y, dz = da * (y > 0) is written (the skip branch's gradient and the apply read it) and the same tile sums
+ * are left — dsnt_relu_bwd + dsnt_bn_act_bwd_reduce in one pass. */
+int dsnt_bn_add_act_bwd_reduce(const float* da, const float* y, const float* x, const float* mean, const float* invstd,
+                               int relu, float* dz, float* partial, int64_t M, int C, void* stream);
 int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M, int C,
                          float* dgamma, float* dbeta, int accumulate, float* coef,
                          void* stream);

@@ -1104,6 +1104,23 @@ def test_batchnorm_finalised_in_the_consumers_prologue(shape):
              bt, ptr(dg), ptr(db), accp, ptr(coef), 1, ptr(dx), accp, M, Cin, None)
         for a_, b_ in ((dg, dg_ref), (db, db_ref), (coef, coef_ref), (dx, dx_ref)):
             assert (a_ - b_).abs().max().item() <= 2e-6 * max(1.0, b_.abs().max().item())
+    # ---- the out-of-place forms: dx = base + value, `base` a tensor of its own that stays intact (dsnt_bn_act_bwd_apply_base /
+    # _pro_base) == the in-place accumulation started from a copy of base, bit for bit; max |dx| in the bound slots
+    base = synthetic.tensor(tag + 'base', (N, H, W, Cin), seed=33).to(dev)
+    keep = base.clone()
+    want = base.clone()
+    call('dsnt_bn_act_bwd_apply', ptr(da), ptr(x), ptr(v_ref[2]), ptr(v_ref[3]), ptr(v_ref[0]), ptr(v_ref[1]), ptr(coef_ref),
+         1, ptr(want), 1, M, Cin)
+    got, am = torch.empty_like(base), torch.zeros(64, device=dev)
+    call('dsnt_bn_act_bwd_apply_base', ptr(da), ptr(x), ptr(v_ref[2]), ptr(v_ref[3]), ptr(v_ref[0]), ptr(v_ref[1]), ptr(coef_ref),
+         1, ptr(base), ptr(got), M, Cin, ptr(am))
+    assert torch.equal(got, want) and torch.equal(base, keep) and am.max().item() == want.abs().max().item()
+    dg, db, coef, got2 = torch.zeros(Cin, device=dev), torch.zeros(Cin, device=dev), torch.empty(2, Cin, device=dev), torch.empty_like(base)
+    call('dsnt_bn_act_bwd_apply_pro_base', ptr(da), ptr(x), ptr(v_ref[2]), ptr(v_ref[3]), ptr(v_ref[0]), ptr(v_ref[1]), ptr(bpart),
+         bt, ptr(dg), ptr(db), 0, ptr(coef), 1, ptr(base), ptr(got2), M, Cin, None)
+    assert (got2 - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item()) and torch.equal(base, keep)
+    assert _lib.fn('dsnt_bn_act_bwd_apply_base')(ptr(da), ptr(x), ptr(v_ref[2]), ptr(v_ref[3]), ptr(v_ref[0]), ptr(v_ref[1]),
+                                                 ptr(coef_ref), 1, ptr(got), ptr(got), M, Cin, None, None) != 0      # base must differ from dx
 
 
 @pytest.mark.parametrize('path', ['f32', 'bf16x6', 'f16x3'])

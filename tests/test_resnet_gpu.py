@@ -56,6 +56,18 @@ def test_block_tail_and_zero_insert():
     dz = torch.empty_like(g)
     call('dsnt_relu_bwd', ptr(g), ptr(y.clamp_min(0)), ptr(dz), M * Cc)
     assert torch.equal(dz, torch.where(y > 0, g, torch.zeros_like(g)))
+    # ... and with the BatchNorm's two reductions in the same pass (dsnt_bn_add_act_bwd_reduce): the same dz, bit for bit, and
+    # the tile sums of dsnt_bn_act_bwd_reduce over it
+    mu = synthetic.tensor('tm', (Cc,), seed=7, scale=0.2).to(DEV)
+    inv = (synthetic.tensor('ti', (Cc,), seed=8, kind='uniform').abs() + 0.5).to(DEV)
+    tiles = (M + 127) // 128
+    for relu in (1, 0):
+        dz2, part, part_ref = torch.empty_like(g), torch.empty(tiles, 2, Cc, device=DEV), torch.empty(tiles, 2, Cc, device=DEV)
+        call('dsnt_bn_add_act_bwd_reduce', ptr(g), ptr(y), ptr(x), ptr(mu), ptr(inv), relu, ptr(dz2), ptr(part), M, Cc)
+        want_dz = dz if relu else g
+        assert torch.equal(dz2, want_dz)
+        call('dsnt_bn_act_bwd_reduce', ptr(want_dz), ptr(x), ptr(sc), ptr(sh), ptr(mu), ptr(inv), 0, ptr(part_ref), M, Cc)
+        assert torch.equal(part, part_ref)
     # zero stuffing == the scatter half of conv_transpose2d
     N, Ho, Wo, s = 2, 3, 4, 2
     dy = synthetic.tensor('zi', (N, Ho, Wo, 8), seed=6).to(DEV)

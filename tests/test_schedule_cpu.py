@@ -82,6 +82,11 @@ def test_backward_list_lanes_and_fusions(tape):
     assert len(pools) == 9 and sum(1 for _, a in pools if a[3] == 1) == 8
     assert sum(1 for n, _ in pools if n == 'dsnt_maxpool2_bwd_add') == 1
     assert sum(1 for n, _, _ in bwd if n.startswith('dsnt_axpy')) == 0
+    # the weight gradients of the low-resolution convolutions with a residual input (conv3 of the Bottlenecks below 32 x 32) wait for
+    # their bucket's grouped launch as well: dL/dy is the BASE the skip gradient continues out of place (dsnt_bn_act_bwd_apply_base),
+    # not a donated buffer — one weight-gradient launch is left on the dependency chain's lanes (fc_: its dL/dy is shared)
+    assert sum(1 for x in wg if x[1] in (0, 1, 3)) <= 1
+    assert sum(1 for n, _, _ in bwd if n in ('dsnt_bn_act_bwd_apply_base', 'dsnt_bn_act_bwd_apply_pro_base')) >= 14
     # nothing of the per-step weight preparation is left at the head of the backward list
     assert [n for n, _, _ in bwd[:3]][0] == 'dsnt_fill_zero' and 'dsnt_conv_pack_dgrad_all' not in [n for n, _, _ in bwd]
 
