@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdsnt_hip.so')
-SOURCES = ['api.cpp', 'conv.hip', 'wgrad3.hip', 'wgrad1.hip', 'gemm1.hip', 'bwd1.hip', 'fwd1.hip', 'conv3s.hip', 'dgrad_up.hip', 'elementwise.hip', 'head.hip', 'heatmap.hip', 'debug.hip']
+SOURCES = ['api.cpp', 'conv.hip', 'wgrad3.hip', 'wgrad1.hip', 'gemm1.hip', 'bwd1.hip', 'fwd1.hip', 'stem4.hip', 'conv3s.hip', 'dgrad_up.hip', 'elementwise.hip', 'head.hip', 'heatmap.hip', 'debug.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result']
 if os.environ.get('DSNT_TIMELINE'):      # wave timeline stamps in the conv kernels (tools/timeline*.py)

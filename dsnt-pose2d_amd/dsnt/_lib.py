@@ -122,6 +122,7 @@ SIGNATURES = {
     'dsnt_bn_act_bwd_apply': [P, P, P, P, P, P, P, I, P, I, L, I, P],
     'dsnt_bn_act_bwd_apply_amax': [P, P, P, P, P, P, P, I, P, I, L, I, P, P],
     'dsnt_bn_act_bwd_apply_pro': [P, P, P, P, P, P, P, I, P, P, I, P, I, P, I, L, I, P, P],
+    'dsnt_stem4_fwd_f16x3': [P, P, L, P, P, P, P, P, GP, TP, P],
     'dsnt_bn_add_act_bwd_reduce': [P, P, P, P, P, I, P, P, L, I, P],
     'dsnt_bn_act_bwd_apply_base': [P, P, P, P, P, P, P, I, P, P, L, I, P, P],
     'dsnt_bn_act_bwd_apply_pro_base': [P, P, P, P, P, P, P, I, P, P, I, P, I, P, P, L, I, P, P],
@@ -192,6 +193,8 @@ PLAIN = {
     'dsnt_conv_wgrad_ws_floats': (L, [GP]),
     'dsnt_conv1x1_fwd_ok': (I, [GP]),
     'dsnt_conv1x1_fwd_stats_rows': (I, [GP, I]),
+    'dsnt_stem4_fwd_ok': (I, [GP]),
+    'dsnt_stem4_fwd_stats_rows': (I, [GP]),
     'dsnt_conv1x1_bwd_ok': (I, [GP]),
     'dsnt_conv1x1_bwd_splits': (I, [GP, I]),
     'dsnt_conv1x1_bwd_ws_floats': (L, [GP, I]),

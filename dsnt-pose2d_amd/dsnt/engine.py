@@ -149,6 +149,7 @@ class Tape:
         # epilogue + weight gradient + (conv1 of a Bottleneck) the BatchNorm backward of the layer behind, each tensor read once
         self.bwd1 = 'bwd1' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
         self.fwd1 = 'fwd1' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')      # ... and their forward (csrc/fwd1.hip)
+        self.stem4 = 'stem4' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')    # the stem's forward (csrc/stem4.hip)
         self._f16_w_stream = {}
         # DSNT_CONV_SHARE_CHIP on the side lanes' launches of the two persistent kernels (3x3: 3/2 workgroups per CU; 1x1: half of
         # the CUs): both hold most of a CU's LDS for the whole launch, and the chain's kernels need LDS too (-0.2 ms)
@@ -350,7 +351,8 @@ class Tape:
         return n.abound
 
     # launches that read weight planes or operand bounds: the preparation must have finished before the first of them
-    _PREP_CONSUMERS = ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_f16x3_stream', 'dsnt_conv1x1_fwd_f16x3', 'dsnt_conv_fwd_bf16x6_ex', 'dsnt_conv_fwd_bf16x6')
+    _PREP_CONSUMERS = ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_f16x3_stream', 'dsnt_conv1x1_fwd_f16x3', 'dsnt_stem4_fwd_f16x3',
+                       'dsnt_conv_fwd_bf16x6_ex', 'dsnt_conv_fwd_bf16x6')
 
     def emit_f16_prep(self, pos, head=()):
         """Insert the per-step preparation launches at position `pos` of the forward list: fp16x3 weight planes and BN
@@ -918,9 +920,13 @@ class Tape:
         f1 = bool(use6 and self.use_f16x3 and p.wq16 is not None and p.R == 1 and res2 is None and self.fwd1 and
                   ((self.training and normed) or x_amax_pre is not None) and self.lib.dsnt_conv1x1_fwd_ok(C.byref(g)))
         f1_shr = 2 if (f1 and self.lane != 0 and self.conv_share) else 0
+        # the stem's space-to-depth convolution (4x4, 16 -> 64 channels, a raw operand): the halo kernel of csrc/stem4.hip
+        s4 = bool(use6 and self.use_f16x3 and self.stem4 and p.wq16 is not None and not normed and res1 is None and res2 is None and
+                  self.lib.dsnt_stem4_fwd_ok(C.byref(g)))
         if want_stats and self.training:
             bm = 128 if use6 else self.lib.dsnt_conv_fwd_bm(C.byref(g))
-            tiles = self.lib.dsnt_conv1x1_fwd_stats_rows(C.byref(g), f1_shr) if f1 else (y.M + bm - 1) // bm
+            tiles = (self.lib.dsnt_conv1x1_fwd_stats_rows(C.byref(g), f1_shr) if f1 else
+                     self.lib.dsnt_stem4_fwd_stats_rows(C.byref(g)) if s4 else (y.M + bm - 1) // bm)
             part = self.empty(tiles, 2, p.Cout)
             y.stats = (part, tiles)
         if use6 and self.use_f16x3:
@@ -946,6 +952,8 @@ class Tape:
             if f1:
                 e = self.f('dsnt_conv1x1_fwd_f16x3', x.buf, p.wq16, p.wq_stride, p.wb, ab, p.b, y.buf, sc, sh, relu | f1_shr, r1,
                            part, g, tail)
+            elif s4:
+                e = self.f('dsnt_stem4_fwd_f16x3', x.buf, p.wq16, p.wq_stride, p.wb, ab, p.b, y.buf, part, g, tail)
             else:
                 e = self.f('dsnt_conv_fwd_f16x3_stream' if st else 'dsnt_conv_fwd_f16x3_ex', x.buf, p.wq16, p.wq_stride, p.wb, ab,
                            p.b, y.buf, sc, sh, relu | shr, r1, r2, part, g, None, tail)

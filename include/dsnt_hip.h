@@ -367,6 +367,18 @@ int dsnt_conv1x1_fwd_f16x3(const float* x, const void* w_planes, int64_t plane_s
                            const float* a_bound, const float* bias, float* y, const float* in_scale,
                            const float* in_shift, int in_relu, const float* res1, float* stats_partial,
                            const dsnt_conv_geom* g, const dsnt_out_bounds* tail, void* stream);
+/* The stem (hourglass.py:157 `self.conv1`, 7x7 / stride 2 / pad 3 on the image) in its space-to-depth form: a 4x4 / stride 1 /
+ * pad 1 convolution of the 16-channel image dsnt_s2d_input leaves ([N][H/2+1][W/2+1][16]), 64 output channels, fp16x3 — on a halo
+ * kernel of its own (csrc/stem4.hip: the 7 x 35 input halo of a 4 x 32 output patch staged once for all 16 taps, weights in
+ * registers).  dsnt_stem4_fwd_ok(g): 4x4, stride 1, pad 1, Cin 16, Cout 64, Ho % 4 == 0, Wo % 32 == 0.  Statistics: ONE row per
+ * workgroup — dsnt_stem4_fwd_stats_rows(g) rows of [2][64], handed to dsnt_bn_finalize as ntiles.  w_planes: the plain
+ * [Cout][4][4][16] planes of dsnt_s2d_weights_prep / dsnt_split_f16x2; tail: dsnt_out_bounds.amax only. */
+int dsnt_stem4_fwd_ok(const dsnt_conv_geom* g);
+int dsnt_stem4_fwd_stats_rows(const dsnt_conv_geom* g);
+int dsnt_stem4_fwd_f16x3(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
+                         const float* a_bound, const float* bias, float* y, float* stats_partial,
+                         const dsnt_conv_geom* g, const dsnt_out_bounds* tail, void* stream);
+
 
 /* The WHOLE backward of a 1x1 / stride 1 convolution y = conv(relu?(bn(x))) in one pass over its tensors — what
  * autograd runs as cuDNN backward-data + backward-filter of /root/reference/src/dsnt/hourglass.py:20,25 (conv1 / conv3 of

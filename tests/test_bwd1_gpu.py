@@ -237,3 +237,73 @@ def test_conv1x1_forward_on_the_lds_staged_streaming_kernel(case, pro, res):
     y3, stats3, _, _, rows3 = run(2)
     assert torch.equal(y, y3) and rows3 <= rows
     assert ((stats3.double().sum(0) - stats.double().sum(0)).abs() <= 1e-5 * stats.double().abs().sum(0) + 1e-6).all()
+
+
+STEM_CASES = [
+    # N, Ho (= Wo): the space-to-depth image is [N][Ho + 1][Wo + 1][16]
+    (2, 128),      # the 256-pixel input of every BASELINE configuration: 256 tiles
+    (3, 64),       # the 128-pixel goldens
+    (9, 128),      # 1152 tiles on 512 persistent workgroups: 2-3 tiles each, ragged
+    (1, 32),       # 8 tiles
+]
+
+
+@pytest.mark.parametrize('N,Ho', STEM_CASES)
+@pytest.mark.parametrize('with_bias', [True, False])
+def test_stem_forward_on_its_halo_kernel(N, Ho, with_bias):
+    """dsnt_stem4_fwd_f16x3 (csrc/stem4.hip): the stem of /root/reference/src/dsnt/hourglass.py:157 (`conv1`, 7x7 / stride 2 / pad 3)
+    in its space-to-depth form — a 4x4 / stride 1 / pad 1 convolution of the 16-channel image, 64 output channels — against the
+    tiled fp16x3 kernel on the same operands (same K order, same products: bit-identical outputs), against torch in fp64 (the fp32
+    bar), with its statistics (one row per workgroup: the column sums of y and y^2) and the bound of its output."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, ConvGeom, BnTail
+    dev = torch.device('cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    Hi = Ho + 1
+    g = ConvGeom(N, Hi, Hi, 16, Ho, Ho, 64, 4, 4, 1, 1, 1)
+    assert _lib.fn('dsnt_stem4_fwd_ok')(C.byref(g)) == 1
+    tag = 'stem%d_%d' % (N, Ho)
+    x = synthetic.tensor(tag + 'x', (N, Hi, Hi, 16), seed=1).to(dev)
+    w = (synthetic.tensor(tag + 'w', (64, 4, 4, 16), seed=2) * 0.1).to(dev)
+    b = synthetic.tensor(tag + 'b', (64,), seed=3).to(dev) if with_bias else None
+    wb, ab = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    planes = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+    assert _lib.fn('dsnt_amax')(ptr(w), w.numel(), ptr(wb), st) == 0
+    assert _lib.fn('dsnt_amax')(ptr(x), x.numel(), ptr(ab), st) == 0
+    assert _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(planes), w.numel(), w.numel(), ptr(wb), st) == 0
+    M = N * Ho * Ho
+    rows = _lib.fn('dsnt_stem4_fwd_stats_rows')(C.byref(g))
+    assert 0 < rows <= N * (Ho // 4) * (Ho // 32)
+    y = torch.full((N, Ho, Ho, 64), float('nan'), device=dev)
+    part = torch.full((rows, 2, 64), float('nan'), device=dev)
+    am = torch.zeros(64, device=dev)
+    tail = BnTail()
+    tail.amax = am.data_ptr()
+    assert _lib.fn('dsnt_stem4_fwd_f16x3')(ptr(x), ptr(planes), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(part), C.byref(g),
+                                           C.byref(tail), st) == 0
+    # the tiled kernel on the same planes and bounds
+    y_t = torch.empty_like(y)
+    part_t = torch.empty((M + 127) // 128, 2, 64, device=dev)
+    assert _lib.fn('dsnt_conv_fwd_f16x3_ex')(ptr(x), ptr(planes), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y_t), None, None, 0, None, None,
+                                             ptr(part_t), C.byref(g), None, None, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_t)
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2),
+                                     None if b is None else b.double(), stride=1, padding=1).permute(0, 2, 3, 1)
+    assert ref.shape == y.shape
+    assert (y.double() - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    s1, s2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    yd = y.double().reshape(-1, 64)
+    assert (s1 - yd.sum(0)).abs().max().item() <= 1e-5 * max(1.0, yd.abs().sum(0).max().item())
+    assert (s2 - (yd * yd).sum(0)).abs().max().item() <= 1e-5 * (yd * yd).sum(0).max().item()
+    assert am.max().item() == y.abs().max().item()
+    # without statistics / bound; refusals
+    y2 = torch.empty_like(y)
+    assert _lib.fn('dsnt_stem4_fwd_f16x3')(ptr(x), ptr(planes), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y2), None, C.byref(g), None, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y)
+    bad = ConvGeom(N, Hi, Hi, 16, Ho, Ho, 128, 4, 4, 1, 1, 1)
+    assert _lib.fn('dsnt_stem4_fwd_ok')(C.byref(bad)) == 0
+    bad3 = ConvGeom(N, Ho, Ho, 16, Ho, Ho, 64, 3, 3, 1, 1, 1)
+    assert _lib.fn('dsnt_stem4_fwd_ok')(C.byref(bad3)) == 0
+    assert _lib.fn('dsnt_stem4_fwd_f16x3')(ptr(x), ptr(planes), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y2), None, C.byref(bad3), None, st) != 0

@@ -46,8 +46,9 @@ def test_forward_list_preparation_runs_beside_the_stem(tape):
     # BatchNorm + ReLU with statistics) BEFORE it waits for the side lane's preparation
     first_sync = next(i for i, e in enumerate(fwd) if e[2] == 'sync' and e[1][0] == 1 and e[1][1] == 0)
     before = [e[2] for e in fwd[:first_sync] if e[3] == 0 and e[0] is not None]
-    assert before[:5] == ['dsnt_fill_zero', 'dsnt_s2d_input', 'dsnt_s2d_weights_prep', 'dsnt_conv_fwd_f16x3_ex', 'dsnt_bn_finalize']
-    assert 'dsnt_bn_act_fwd_stats' in before and before.count('dsnt_conv_fwd_f16x3_ex') == 1
+    # (the stem convolution itself: the halo kernel of csrc/stem4.hip, one statistics row per workgroup)
+    assert before[:5] == ['dsnt_fill_zero', 'dsnt_s2d_input', 'dsnt_s2d_weights_prep', 'dsnt_stem4_fwd_f16x3', 'dsnt_bn_finalize']
+    assert 'dsnt_bn_act_fwd_stats' in before and before.count('dsnt_stem4_fwd_f16x3') == 1 and 'dsnt_conv_fwd_f16x3_ex' not in before
     # ... and that wait comes before the first launch that reads ANY prepared plane or bound, the stream-layout 3x3 kernel included
     readers = ('dsnt_conv_fwd_f16x3_ex', 'dsnt_conv_fwd_f16x3_stream', 'dsnt_conv_fwd_bf16x6_ex', 'dsnt_conv_fwd_bf16x6')
     first_reader = next(i for i, e in enumerate(fwd) if e[2] in readers and id(e) not in tape._prep_exempt)
