@@ -22,6 +22,7 @@
 #include "wgrad3.h"
 #include "gemm1.h"
 #include "conv3s.h"
+#include "stem4.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -2386,6 +2387,7 @@ extern "C" int64_t dsnt_conv_wgrad_ws_floats(const dsnt_conv_geom* g) {
     if (!g) return 0;
     int64_t n = wgrad_ws_floats_plain(g);
     const int64_t per = (int64_t)g->Cout * (g->R * g->S * g->Cin) + g->Cout;
+    if (const int s4 = dsnt_stem4_wgrad_slabs(g)) { if (s4 * per > n) n = s4 * per; }
     for (int share = 0; share < 2; ++share) {
         const Wg3Plan p3 = dsnt_wg3_plan(g, share);
         if (p3.ok && p3.nslabs * per > n) n = p3.nslabs * per;
@@ -2491,6 +2493,24 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
     DSNT_REQUIRE(dsnt_conv_wgrad_bf16x6_ok(g), DSNT_ERR_SHAPE,
                  "dsnt_conv_wgrad_f16x3: geometry not supported (need Wo %% 4 == 0, tensors < 2 GiB)");
     DSNT_REQUIRE(a_bound && g_bound, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: both operand bounds are required");
+    // the stem's space-to-depth convolution (4x4, 16 -> 64 channels, raw operand): its own kernel (stem4.hip), one slab per workgroup
+    if (const int s4 = dsnt_stem4_wgrad_slabs(g)) {
+        if (int e = check_geom(g, "dsnt_conv_wgrad_f16x3")) return e;
+        DSNT_REQUIRE(x && dy && ws, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: null tensor");
+        DSNT_REQUIRE(dw || !dbias, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: dbias without dw");
+        DSNT_REQUIRE(!in_scale && !in_shift, DSNT_ERR_ARG, "dsnt_conv_wgrad_f16x3: the 4x4 / 16 -> 64 stem geometry takes a raw operand only");
+        DSNT_REQUIRE(dsnt_aligned16(x) && dsnt_aligned16(dy) && dsnt_aligned16(ws) && (!dw || dsnt_aligned16(dw)),
+                     DSNT_ERR_ALIGN, "dsnt_conv_wgrad_f16x3: tensors must be 16-byte aligned");
+        hipStream_t st = (hipStream_t)stream;
+        dsnt_stem4_wgrad_launch(x, dy, ws, a_bound, g_bound, g, st);
+        if (dw) {
+            const int CK = g->Cout * 16 * g->Cin;
+            const int total = CK / 4 + (g->Cout + 3) / 4;
+            DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias, s4, CK,
+                        g->Cout, accumulate & 1);
+        }
+        DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_f16x3");
+    }
     // 3x3 / stride 1 convolutions: the halo kernel (wgrad3.hip) — every operand element staged once for all nine taps
     const Wg3Plan pl = dsnt_wg3_plan(g, wg3_share(accumulate));
     if (pl.ok) {
@@ -2540,6 +2560,7 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
 // equal to dsnt_conv_wgrad_splits / _ws_floats where the implicit-GEMM kernel runs.
 extern "C" int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g, int accumulate) {
     if (!g) return 0;
+    if (const int s4 = dsnt_stem4_wgrad_slabs(g)) return s4;
     const Wg3Plan pl = dsnt_wg3_plan(g, wg3_share(accumulate));
     if (pl.ok) return pl.nslabs;
     const Wg1Plan p1 = dsnt_wg1_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);
@@ -2547,6 +2568,7 @@ extern "C" int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g, int accumul
 }
 extern "C" int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate) {
     if (!g) return 0;
+    if (const int s4 = dsnt_stem4_wgrad_slabs(g)) return (int64_t)s4 * g->Cout * (16 * g->Cin) + (int64_t)s4 * g->Cout;
     const Wg3Plan pl = dsnt_wg3_plan(g, wg3_share(accumulate));
     if (pl.ok) return (int64_t)pl.nslabs * g->Cout * (9 * g->Cin) + (int64_t)pl.nslabs * g->Cout;
     const Wg1Plan p1 = dsnt_wg1_plan(g, (accumulate & DSNT_WGRAD_SHARE_CHIP) != 0);

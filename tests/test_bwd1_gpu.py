@@ -307,3 +307,46 @@ def test_stem_forward_on_its_halo_kernel(N, Ho, with_bias):
     bad3 = ConvGeom(N, Ho, Ho, 16, Ho, Ho, 64, 3, 3, 1, 1, 1)
     assert _lib.fn('dsnt_stem4_fwd_ok')(C.byref(bad3)) == 0
     assert _lib.fn('dsnt_stem4_fwd_f16x3')(ptr(x), ptr(planes), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y2), None, C.byref(bad3), None, st) != 0
+
+
+@pytest.mark.parametrize('N,Ho', STEM_CASES)
+def test_stem_weight_gradient_on_its_own_kernel(N, Ho):
+    """The weight gradient of the same convolution (csrc/stem4.hip: stem4_wgrad_kernel, reached through dsnt_conv_wgrad_f16x3): both
+    operands read transposed from pixel-major LDS images, one slab and one bias partial per workgroup — against torch in fp64 (the
+    weight-gradient bar of the other fp16x3 kernels), with and without the in-call reduction, accumulating, and the refusal of a
+    BatchNorm prologue (the stem's operand is the raw image)."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, ConvGeom
+    dev = torch.device('cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    Hi = Ho + 1
+    g = ConvGeom(N, Hi, Hi, 16, Ho, Ho, 64, 4, 4, 1, 1, 1)
+    tag = 'stemw%d_%d' % (N, Ho)
+    x = synthetic.tensor(tag + 'x', (N, Hi, Hi, 16), seed=1).to(dev)
+    gy = (synthetic.tensor(tag + 'g', (N, Ho, Ho, 64), seed=2) * 1e-2).to(dev)
+    ab, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    assert _lib.fn('dsnt_amax')(ptr(x), x.numel(), ptr(ab), st) == 0
+    assert _lib.fn('dsnt_amax')(ptr(gy), gy.numel(), ptr(gb), st) == 0
+    splits = _lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g), 0)
+    nws = _lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 0)
+    assert 0 < splits <= N * (Ho // 4) * (Ho // 32) and nws == splits * (64 * 256 + 64)
+    assert _lib.fn('dsnt_conv_wgrad_ws_floats')(C.byref(g)) >= nws
+    ws = torch.full((nws,), float('nan'), device=dev)
+    dw, db = torch.empty(64, 4, 4, 16, device=dev), torch.empty(64, device=dev)
+    wg = _lib.fn('dsnt_conv_wgrad_f16x3')
+    assert wg(ptr(x), None, None, 0, ptr(gy), ptr(ws), ptr(dw), ptr(db), 0, ptr(ab), ptr(gb), C.byref(g), st) == 0
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (64, 16, 4, 4), gy.double().permute(0, 3, 1, 2),
+                                      stride=1, padding=1).permute(0, 2, 3, 1)
+    refb = gy.double().sum((0, 1, 2))
+    assert not torch.isnan(ws).any()
+    assert (dw.double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    assert (db.double() - refb).abs().max().item() <= 4e-6 * max(refb.abs().max().item(), gy.abs().sum().item() * 1e-3)
+    # the slabs alone add up to the same gradient (what the engine's one reduction per bucket does), and accumulate adds
+    slabs = ws[:splits * 64 * 256].view(splits, 64, 4, 4, 16).double().sum(0)
+    assert (slabs - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    assert wg(ptr(x), None, None, 0, ptr(gy), ptr(ws), ptr(dw), ptr(db), 1, ptr(ab), ptr(gb), C.byref(g), st) == 0
+    torch.cuda.synchronize()
+    assert (dw.double() - 2 * ref).abs().max().item() <= 8e-6 * ref.abs().max().item()
+    sc, sh = torch.ones(16, device=dev), torch.zeros(16, device=dev)
+    assert wg(ptr(x), ptr(sc), ptr(sh), 0, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g), st) != 0

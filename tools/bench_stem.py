@@ -44,6 +44,15 @@ if _lib.fn('dsnt_stem4_fwd_ok')(C.byref(g)):
     f4 = timed(lambda: s4(ptr(x), ptr(wq16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y4), ptr(stats4), C.byref(g), None, st))
 f = timed(lambda: fwd(ptr(x), ptr(wq16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), None, None, 0, None, None, ptr(stats), C.byref(g), None, None, st))
 wgt = timed(lambda: wg(ptr(x), None, None, 0, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g), st))
+# the weight gradient against torch (fp64) on a slice of the batch
+dw, db = torch.empty_like(w), torch.empty(Cout, device=dev)
+assert wg(ptr(x), None, None, 0, ptr(gy), ptr(ws), ptr(dw), ptr(db), 0, ptr(ab), ptr(gb), C.byref(g), st) == 0
+torch.cuda.synchronize()
+ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (Cout, Cin, k, k), gy.double().permute(0, 3, 1, 2), stride=1, padding=1)
+ref = ref.permute(0, 2, 3, 1)
+print('weight gradient: %d slabs; max |dW - fp64| = %.3e of max |dW| %.3e; max |db - fp64| = %.3e of %.3e'
+      % (_lib.fn('dsnt_conv_wgrad_f16x3_splits')(C.byref(g), 0), (dw.double() - ref).abs().max().item(), ref.abs().max().item(),
+         (db.double() - gy.double().sum((0, 1, 2))).abs().max().item(), gy.double().sum((0, 1, 2)).abs().max().item()))
 mb_f = 4e-6 * (x.numel() + y.numel())
 mb_w = 4e-6 * (x.numel() + gy.numel())
 if f4 is not None:
