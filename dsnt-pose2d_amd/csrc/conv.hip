@@ -1777,28 +1777,48 @@ extern "C" int dsnt_conv_pack_dgrad(const float* w, float* wd, int Cout, int R, 
 // All data-gradient weight packs of a backward pass in ONE launch: for conv c (table row c =
 // {src offset, dst offset, Cout, R, S, Cin}) write wd[ci][R-1-r][S-1-s][co] = w[co][r][s][ci] as fp32
 // and as three bf16 planes (plane stride = `total` elements).
-__global__ void pack_dgrad_all_kernel(const int* __restrict__ table, const float* __restrict__ params,
-                                      float* __restrict__ out, unsigned short* __restrict__ planes, long total) {
+// One tap of one convolution is a [Cout][Cin] matrix with row pitch R S Cin; it lands transposed, [Cin][Cout] with row pitch
+// R S Cout.  32 x 32 tiles through LDS: 128-byte runs along ci on the way in, along co on the way out (element by element the
+// reads were 4 bytes per cache line: 360 MB fetched for the 27 MB of hg2's weights, and — 24 000 workgroups for hg8 — a flood that
+// kept the dependency chain's 4-workgroup BatchNorm finalise waiting 140-240 us for a slot at the start of every step).
+__global__ __launch_bounds__(256) void pack_dgrad_all_kernel(const int* __restrict__ table, const float* __restrict__ params,
+                                                            float* __restrict__ out, unsigned short* __restrict__ planes, long total) {
+    __shared__ float tl[32][33];
     const int* t = table + blockIdx.y * 6;
     const int src = t[0], dst = t[1], Cout = t[2], R = t[3], S = t[4], Cin = t[5];
-    const int n = Cout * R * S * Cin;
     const float* w = params + src;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int co = i % Cout;
-        int q = i / Cout;
-        const int s_ = q % S; q /= S;
-        const int r = q % R;
-        const int ci = q / R;
-        const float v = w[((co * R + (R - 1 - r)) * S + (S - 1 - s_)) * Cin + ci];
-        out[dst + i] = v;
-        // exact 3-way bf16 split (round-to-nearest-even by hand: one scalar at a time)
-        float rem = v;
-        for (int pl = 0; pl < 3; ++pl) {
-            unsigned u = __float_as_uint(rem);
-            unsigned rb = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-            planes[(long)pl * total + dst + i] = (unsigned short)(rb >> 16);
-            rem -= __uint_as_float(rb);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int cits = (Cin + 31) >> 5, cots = (Cout + 31) >> 5, RS = R * S;
+    const int ntiles = RS * cits * cots;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tap = tile % RS;
+        int q = tile / RS;
+        const int cit = q % cits, cot = q / cits;
+        const int r = tap / S, s_ = tap - r * S;            // DESTINATION tap; the source is the flipped one
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = cot * 32 + ty + 8 * i, ci = cit * 32 + tx;
+            tl[ty + 8 * i][tx] = (co < Cout && ci < Cin) ? w[((co * R + (R - 1 - r)) * S + (S - 1 - s_)) * Cin + ci] : 0.f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = cit * 32 + ty + 8 * i, co = cot * 32 + tx;
+            if (ci < Cin && co < Cout) {
+                const float v = tl[tx][ty + 8 * i];
+                const long o = (long)dst + ((long)(ci * R + r) * S + s_) * Cout + co;
+                out[o] = v;
+                // exact 3-way bf16 split (round-to-nearest-even by hand: one scalar at a time)
+                float rem = v;
+                for (int pl = 0; pl < 3; ++pl) {
+                    unsigned u = __float_as_uint(rem);
+                    unsigned rb = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+                    planes[(long)pl * total + o] = (unsigned short)(rb >> 16);
+                    rem -= __uint_as_float(rb);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1806,7 +1826,7 @@ extern "C" int dsnt_conv_pack_dgrad_all(const int* table, int nconv, const float
                                         void* planes, int64_t total, void* stream) {
     DSNT_REQUIRE(table && params && out && planes && nconv > 0 && total > 0, DSNT_ERR_ARG,
                  "dsnt_conv_pack_dgrad_all: bad argument");
-    DSNT_LAUNCH(pack_dgrad_all_kernel, dim3(64, nconv), dim3(256), 0, (hipStream_t)stream, table, params,
+    DSNT_LAUNCH(pack_dgrad_all_kernel, dim3(16, nconv), dim3(256), 0, (hipStream_t)stream, table, params,
                        out, (unsigned short*)planes, (long)total);
     DSNT_CHECK_LAUNCH("dsnt_conv_pack_dgrad_all");
 }

@@ -1245,3 +1245,34 @@ def test_stem_as_space_to_depth_convolution():
     lhs = float((w2.double() * g2.double()).sum())
     rhs = float((w_ohwi.double() * back.double()).sum())
     assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs)) and not torch.isnan(back).any()
+
+
+def test_pack_of_all_data_gradient_weights_in_one_launch():
+    """dsnt_conv_pack_dgrad_all (the per-step re-pack of every convolution's weights for its data gradient: wd[ci][R-1-r][S-1-s][co] =
+    w[co][r][s][ci], fp32 + three bf16 planes; /root/reference/src/dsnt/hourglass.py:20-25 backward) — 32 x 32 tiles through LDS —
+    against the index formula, for ragged channel counts, 1x1 / 3x3 / 7x7 filters and several convolutions in one table."""
+    from dsnt._lib import ptr, call
+    dev = torch.device('cuda:0')
+    convs = [(128, 3, 3, 128), (256, 1, 1, 128), (16, 1, 1, 256), (256, 1, 1, 16), (64, 7, 7, 4), (48, 3, 3, 80), (36, 1, 1, 20)]
+    srcs, rows, off_s, off_d = [], [], 0, 0
+    for (co, r, s_, ci) in convs:
+        n = co * r * s_ * ci
+        srcs.append(torch.randn(n, device=dev))
+        rows.append([off_s, off_d, co, r, s_, ci])
+        off_s += n
+        off_d += (n + 7) // 8 * 8
+    params = torch.cat(srcs)
+    total = off_d
+    out = torch.full((total,), float('nan'), device=dev)
+    planes = torch.zeros(3 * total, dtype=torch.bfloat16, device=dev)
+    table = torch.tensor(rows, dtype=torch.int32, device=dev)
+    call('dsnt_conv_pack_dgrad_all', ptr(table), len(convs), ptr(params), ptr(out), ptr(planes), total)
+    torch.cuda.synchronize()
+    for (co, r, s_, ci), w, row in zip(convs, srcs, rows):
+        n = co * r * s_ * ci
+        want = w.view(co, r, s_, ci).flip(1, 2).permute(3, 1, 2, 0).contiguous().view(-1)
+        got = out[row[1]:row[1] + n]
+        assert torch.equal(got, want), (co, r, s_, ci)
+        p = [planes[k * total + row[1]:k * total + row[1] + n].float() for k in range(3)]
+        assert torch.equal(p[0] + p[1] + p[2], want) or (p[0] + p[1] + p[2] - want).abs().max().item() <= 1e-7 * want.abs().max().item()
+        assert torch.equal(p[0], want.to(torch.bfloat16).float())
