@@ -1701,6 +1701,36 @@ __global__ __launch_bounds__(256) void s2d_weights_prep_kernel(const float* __re
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     float m = 0.f;
+    auto emit = [&](const int q, const float4 v, const float sc) {
+        if (w2) reinterpret_cast<float4*>(w2)[q] = v;
+        uint2 a, b, c;
+        split4(v, a, b, c);
+        p6[q] = a; p6[n4 + q] = b; p6[2 * n4 + q] = c;
+        split4h(make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc), a, b);
+        p16[q] = a; p16[n4 + q] = b;
+    };
+    if (n4 <= 16 * 256) {
+        // (Cout <= 64, every stem: the 16 groups of a thread are fetched at once and kept — this one-workgroup launch sits on the
+        // dependency chain at the head of every step, and 2 x 16 dependent round trips to L2 were 24-55 us of it)
+        float4 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = threadIdx.x + 256 * j;
+            v[j] = q < n4 ? fetch(q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            m = fmaxf(fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))), m);
+        m = block_max(m, red);
+        if (threadIdx.x < DSNT_BOUND_SLOTS) bound[threadIdx.x] = m;
+        const float sc = pow2_scale(m);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = threadIdx.x + 256 * j;
+            if (q < n4) emit(q, v[j], sc);
+        }
+        return;
+    }
     for (int q = threadIdx.x; q < n4; q += 256) {
         const float4 v = fetch(q);
         m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
@@ -1708,15 +1738,7 @@ __global__ __launch_bounds__(256) void s2d_weights_prep_kernel(const float* __re
     m = block_max(m, red);
     if (threadIdx.x < DSNT_BOUND_SLOTS) bound[threadIdx.x] = m;
     const float sc = pow2_scale(m);
-    for (int q = threadIdx.x; q < n4; q += 256) {
-        const float4 v = fetch(q);
-        if (w2) reinterpret_cast<float4*>(w2)[q] = v;
-        uint2 a, b, c;
-        split4(v, a, b, c);
-        p6[q] = a; p6[n4 + q] = b; p6[2 * n4 + q] = c;
-        split4h(make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc), a, b);
-        p16[q] = a; p16[n4 + q] = b;
-    }
+    for (int q = threadIdx.x; q < n4; q += 256) emit(q, fetch(q), sc);
 }
 
 extern "C" int dsnt_s2d_weights_prep(const float* w, float* w2, void* planes16, void* planes_bf16, float* bound, int Cout,
