@@ -8,6 +8,27 @@ from dsnt._lib import ptr, ConvGeom
 dev = torch.device('cuda:0')
 which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
 B = 32
+if which in ('stem4', 'stem4w'):
+    # the stem's own kernels (csrc/stem4.hip): 4x4 / stride 1 / pad 1 on the 16-channel space-to-depth image, 64 channels, batch 32
+    Hs, Cin, Cout, k = 129, 16, 64, 4
+    g = ConvGeom(B, Hs, Hs, Cin, 128, 128, Cout, k, k, 1, 1, 1)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(B, Hs, Hs, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
+    y = torch.empty(B, 128, 128, Cout, device=dev); gy = torch.randn(B, 128, 128, Cout, device=dev) * 1e-3
+    planes16 = torch.empty(2 * w.numel(), dtype=torch.float16, device=dev)
+    wb, ab, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    for t_, s_ in ((w, wb), (x, ab), (gy, gb)):
+        _lib.fn('dsnt_amax')(ptr(t_), t_.numel(), ptr(s_), st)
+    _lib.fn('dsnt_split_f16x2')(ptr(w), ptr(planes16), w.numel(), w.numel(), ptr(wb), st)
+    stats = torch.empty(_lib.fn('dsnt_stem4_fwd_stats_rows')(C.byref(g)), 2, Cout, device=dev)
+    ws = torch.empty(_lib.fn('dsnt_conv_wgrad_f16x3_ws_floats')(C.byref(g), 0), device=dev)
+    for it in range(int(os.environ.get('ONE_KERNEL_REPS', '5'))):
+        if which == 'stem4':
+            assert _lib.fn('dsnt_stem4_fwd_f16x3')(ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), None, ptr(y), ptr(stats), C.byref(g), None, st) == 0
+        else:
+            assert _lib.fn('dsnt_conv_wgrad_f16x3')(ptr(x), None, None, 0, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g), st) == 0
+    torch.cuda.synchronize()
+    sys.exit(0)
 H, Cin, Cout, k = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (64, 128, 128, 3)
 g = ConvGeom(B, H, H, Cin, H, H, Cout, k, k, 1, k // 2, 1)
 x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05
