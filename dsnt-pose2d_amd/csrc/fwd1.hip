@@ -242,7 +242,9 @@ Fwd1Plan dsnt_fwd1_plan(const dsnt_conv_geom* g, bool share) {
     if (!(g->R == 1 && g->S == 1 && g->stride == 1 && g->pad == 0 && g->Ho == g->H && g->Wo == g->W)) return pl;
     const long M = (long)g->N * g->H * g->W;
     static long min_rows = -1;
-    if (min_rows < 0) { const char* e = getenv("DSNT_X_FWD1_MIN_ROWS"); min_rows = e ? atol(e) : 16384; }      // A/B only
+    // (16384 when the kernel was written; with the gradient plumbing of the end of round 4 the 16 x 16 level gains too: hg2 batch 32
+    // 11.25-11.29 vs 11.30-11.37 ms at 8192 rows, hg8 batch 16 -0.08 ms at 4096 together with DSNT_BF16X6_MIN_ROWS; 2048: +0.07)
+    if (min_rows < 0) { const char* e = getenv("DSNT_X_FWD1_MIN_ROWS"); min_rows = e ? atol(e) : 4096; }      // A/B only
     if (M % 32 != 0 || M < min_rows) return pl;
     if ((size_t)M * g->Cin * 4u >= (1ull << 31) || (size_t)M * g->Cout * 4u >= (1ull << 31)) return pl;
     int cfg = -1;

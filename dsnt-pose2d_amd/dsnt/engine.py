@@ -120,7 +120,9 @@ class Tape:
         self.bytes_fwd, self.bytes_bwd, self.bytes_by_name, self._ws_ptrs = 0, 0, {}, set()
         # fp32-accurate split-bf16 matrix-core path for the large convolutions (DSNT_MFMA=f32 disables)
         self.use_bf16x6 = os.environ.get('DSNT_MFMA', 'bf16x6') != 'f32'
-        self.bf16x6_min_rows = int(os.environ.get('DSNT_BF16X6_MIN_ROWS', '8192'))      # (16384 -> 8192, the 16x16 level at batch 32: -0.08 ms; 2048: +0.09)
+        # (16384 -> 8192, the 16x16 level at batch 32: -0.08 ms; -> 4096 once fwd1 took the 1x1 convolutions of that size: the 16x16
+        # level at batch 16, hg8 -0.08 ms, nothing between 4096 and 8192 rows at batch 32; 2048: +0.07 ... +0.09)
+        self.bf16x6_min_rows = int(os.environ.get('DSNT_BF16X6_MIN_ROWS', '4096'))
         # lanes: 0 = the caller's stream, 1 = a side stream for independent branches (the full-resolution
         # skip branch of every hourglass level runs beside the low-resolution recursion)
         self.lane = 0
