@@ -352,7 +352,7 @@ int dsnt_conv_wgrad_halo_ok(const dsnt_conv_geom* g);
 int dsnt_conv_wgrad_f16x3_splits(const dsnt_conv_geom* g, int accumulate);
 int64_t dsnt_conv_wgrad_f16x3_ws_floats(const dsnt_conv_geom* g, int accumulate);
 
-/* Forward of a 1x1 / stride 1 convolution with >= 16384 rows on the second streaming kernel (csrc/fwd1.hip): the same contract as
+/* Forward of a 1x1 / stride 1 convolution with >= 4096 rows on the second streaming kernel (csrc/fwd1.hip): the same contract as
  * dsnt_conv_fwd_f16x3_ex for these shapes (BN+ReLU prologue or a raw operand, bias, ONE residual, operand bounds, `tail`) except
  * for the statistics: stats_partial is [rows][2][Cout] with rows = dsnt_conv1x1_fwd_stats_rows(g, in_relu) — one row per
  * WORKGROUP (<= 512) instead of one per 128 pixels; hand `rows` to dsnt_bn_finalize as its ntiles.  The activations are
