@@ -13,6 +13,26 @@ int dsnt_set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+int dsnt_device_id(void) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d < DSNT_MAX_DEVICES ? d : DSNT_MAX_DEVICES - 1;
+}
+
+int dsnt_device_cus(void) {
+    static std::atomic<int> cus[DSNT_MAX_DEVICES];
+    const int d = dsnt_device_id();
+    int c = cus[d].load(std::memory_order_acquire);
+    if (!c) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        c = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+        cus[d].store(c, std::memory_order_release);
+    }
+    return c;
+}
+
 extern "C" int dsnt_version(void) { return 111; }      // 110: dsnt_f16_prep_weights takes its row width; dsnt_conv1x1_bwd_*; 111 (additive): dsnt_conv1x1_fwd_*, DSNT_BN_FROZEN, dsnt_maxpool2_bwd_add
 extern "C" const char* dsnt_last_error(void) { return g_err; }
 

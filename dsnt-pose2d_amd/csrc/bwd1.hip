@@ -390,13 +390,7 @@ Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g, bool share) {
         if (g->Cout == b1_cfgs[i].cout && g->Cin == b1_cfgs[i].cin) cfg = i;
     if (cfg < 0) return pl;
     const B1Cfg& c = b1_cfgs[cfg];
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = dsnt_device_cus();
     const int nstages = (int)(M / 32);
     // workgroups that fit the chip at once: one eight-wave workgroup per CU, two four-wave ones; column chunks side by side.
     // share (DSNT_CONV_SHARE_CHIP): the launch runs on a lane beside the dependency chain; a workgroup holds up to 140 KB of a
@@ -416,11 +410,7 @@ Bwd1Plan dsnt_bwd1_plan(const dsnt_conv_geom* g, bool share) {
 
 template <int NN, int CW, int NWV, int MODE, bool RAW>
 static void b1_launch_k(const Bwd1Plan& pl, const Bwd1P& p, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)bwd1_kernel<NN, CW, NWV, MODE, RAW>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds);
-        attr_done = true;
-    }
+    DSNT_SET_MAX_LDS((bwd1_kernel<NN, CW, NWV, MODE, RAW>), pl.lds);
     DSNT_LAUNCH((bwd1_kernel<NN, CW, NWV, MODE, RAW>), dim3(pl.nwg, pl.chunks), dim3(64 * NWV), pl.lds, st, p);
 }
 

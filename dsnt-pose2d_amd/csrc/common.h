@@ -29,6 +29,30 @@ dsnt_list* dsnt_recording(void);
 
 static inline bool dsnt_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Per-DEVICE host caches (one process may drive several devices; entry points may be called from several threads — autograd's
+// backward thread).  dsnt_device_id(): the current device, clamped to the cache size.  dsnt_device_cus(): its CU count.
+#define DSNT_MAX_DEVICES 16
+int dsnt_device_id(void);
+int dsnt_device_cus(void);
+// One-time (per kernel instantiation and device) opt-in to `bytes` of dynamic LDS; a failure is left in dsnt_last_error() and the
+// launch that follows reports it.  Not a stream operation: safe while a launch list is recording.
+#ifdef __HIPCC__
+#include <atomic>
+#define DSNT_SET_MAX_LDS(kernel, bytes)                                                                              \
+    do {                                                                                                             \
+        static std::atomic<int> done_[DSNT_MAX_DEVICES];                                                             \
+        const int d_ = dsnt_device_id();                                                                             \
+        if (done_[d_].load(std::memory_order_acquire) < (int)(bytes)) {                                              \
+            hipError_t e_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (e_ != hipSuccess)                                                                                    \
+                dsnt_set_error(DSNT_ERR_HIP, "hipFuncSetAttribute(%s, %d bytes of LDS): %s", #kernel, (int)(bytes),  \
+                               hipGetErrorString(e_));                                                               \
+            else                                                                                                     \
+                done_[d_].store((int)(bytes), std::memory_order_release);                                            \
+        }                                                                                                            \
+    } while (0)
+#endif
+
 // ---- launch lists (include/dsnt_hip.h: dsnt_list_*).  While a list is recording on this thread, every kernel launch
 // of the entry points is captured (arguments by value) instead of enqueued, and the entry point's `stream` argument is a
 // LANE index; dsnt_list_replay then issues the captured launches from C with no per-launch host work in the caller's

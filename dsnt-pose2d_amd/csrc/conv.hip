@@ -874,17 +874,11 @@ static int launch_fwd(const ConvP& p, bool pro, hipStream_t st) {
     const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float);
     const int grid = p.mtiles * p.ntiles;
     // one-time opt-in to > 64 KiB of dynamic LDS (not a stream operation; safe under capture)
-    static bool attr_done = false;
-    if (!attr_done && lds > 65536) {
-        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, true, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, false, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, true, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv_fwd_kernel<WM, WN, TM, TN, false, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+    if (lds > 65536) {
+        DSNT_SET_MAX_LDS((conv_fwd_kernel<WM, WN, TM, TN, true, true>), lds);
+        DSNT_SET_MAX_LDS((conv_fwd_kernel<WM, WN, TM, TN, false, true>), lds);
+        DSNT_SET_MAX_LDS((conv_fwd_kernel<WM, WN, TM, TN, true, false>), lds);
+        DSNT_SET_MAX_LDS((conv_fwd_kernel<WM, WN, TM, TN, false, false>), lds);
     }
     const bool fast = (p.Cin % BK == 0) && (p.R * p.S * (BM / 32) <= 64) &&
                       ((size_t)p.N * p.H * p.W * p.Cin * 4u < (1ull << 31)) &&
@@ -1425,11 +1419,9 @@ static void launch_conv3x3_6(const ConvP& p, bool pro, hipStream_t st) {
     size_t lds = (size_t)((F16 ? 2 : 1) * NPL * 192 + 2 * NPL * BN) * PITCH6 * 2;
     const size_t epi = (size_t)128 * (BN + 4) * 4;
     if (epi > lds) lds = epi;
-    static bool attr_done = false;
-    if (!attr_done && lds > 65536) {
-        hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv3x3_bf16x6_kernel<TN, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+    if (lds > 65536) {
+        DSNT_SET_MAX_LDS((conv3x3_bf16x6_kernel<TN, true, F16>), lds);
+        DSNT_SET_MAX_LDS((conv3x3_bf16x6_kernel<TN, false, F16>), lds);
     }
     dim3 gr(p.mtiles * p.ntiles), bl(512);
     if (pro) DSNT_LAUNCH((conv3x3_bf16x6_kernel<TN, true, F16>), gr, bl, lds, st, p);
@@ -2519,11 +2511,7 @@ extern "C" int dsnt_conv_wgrad_group(const void* table, int nconv, int max_block
     DSNT_REQUIRE(table && nconv > 0 && nconv <= 65535 && max_blocks > 0, DSNT_ERR_ARG,
                  "dsnt_conv_wgrad_group: bad argument");
     const int lds = 2 * 2 * 3 * 128 * PITCH6 * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    DSNT_SET_MAX_LDS(conv_wgrad_bf16x6_group_kernel, lds);
     DSNT_LAUNCH(conv_wgrad_bf16x6_group_kernel, dim3(max_blocks, nconv), dim3(512), lds, (hipStream_t)stream,
                        (const WgradP*)table);
     DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_group");
@@ -2646,19 +2634,11 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
     if (bf16x6) {
         const int lds_full = 2 * 2 * 3 * 128 * PITCH6 * 2;
         const int lds = share ? share_lds : lds_full;
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
-            hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
-            attr_done = true;
-        }
+        DSNT_SET_MAX_LDS((conv_wgrad_bf16x6_kernel<true, false>), share_lds);
+        DSNT_SET_MAX_LDS((conv_wgrad_bf16x6_kernel<false, false>), share_lds);
         if (a_bound) {              // fp16x3 (role-split kernel; its two fp16 planes need 2/3 of the LDS)
-            static bool attr16 = false;
-            if (!attr16) {
-                hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
-                hipFuncSetAttribute((const void*)conv_wgrad_bf16x6_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, share_lds);
-                attr16 = true;
-            }
+            DSNT_SET_MAX_LDS((conv_wgrad_bf16x6_kernel<true, true>), share_lds);
+            DSNT_SET_MAX_LDS((conv_wgrad_bf16x6_kernel<false, true>), share_lds);
             const int lds16 = share ? share_lds : 2 * 2 * 2 * 128 * PITCH6 * 2;
             if (in_scale) DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<true, true>), dim3(grid), dim3(512), lds16, st, p);
             else DSNT_LAUNCH((conv_wgrad_bf16x6_kernel<false, true>), dim3(grid), dim3(512), lds16, st, p);

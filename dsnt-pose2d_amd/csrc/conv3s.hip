@@ -425,18 +425,8 @@ bool dsnt_conv3s_ok(const ConvP& p) {
 template <int CO, bool PRO, int MODE, int PW>
 static void c3_launch_k(const ConvP& p, hipStream_t st, bool share) {
     const int lds = 2 * C3_ABUF + 2 * 2 * CO * C3_BP + 1024;       // halo buffers, weight ring, BatchNorm vectors
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)conv3s_kernel<CO, PRO, MODE, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        hipGetDevice(&dev);
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    DSNT_SET_MAX_LDS((conv3s_kernel<CO, PRO, MODE, PW>), lds);
+    const int cus = dsnt_device_cus();
     const int ntiles = p.N * (p.H / (128 / PW)) * (p.W / PW);
     int grid = 2 * cus;                         // two workgroups per CU (LDS), persistent over the tiles
     // DSNT_CONV_SHARE_CHIP: a launch on a side lane.  Two of these workgroups take a CU's whole LDS for the life of the launch,

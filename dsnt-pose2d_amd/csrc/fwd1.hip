@@ -252,13 +252,7 @@ Fwd1Plan dsnt_fwd1_plan(const dsnt_conv_geom* g, bool share) {
         if (g->Cin == f1_cfgs[i].cin && g->Cout == f1_cfgs[i].cout) cfg = i;
     if (cfg < 0) return pl;
     const F1Cfg& c = f1_cfgs[cfg];
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = dsnt_device_cus();
     const int nstages = (int)(M / 32);
     int nwg = cus * (c.nwv == 4 ? 2 : 1) / c.chunks;
     if (share) nwg = nwg / 2 > 0 ? nwg / 2 : 1;             // DSNT_CONV_SHARE_CHIP: half of the CUs (gemm1.hip, bwd1.hip)
@@ -274,11 +268,7 @@ Fwd1Plan dsnt_fwd1_plan(const dsnt_conv_geom* g, bool share) {
 
 template <int KK, int CW, int NWV, bool PRO, bool RES>
 static void f1_launch_k(const Fwd1Plan& pl, const Fwd1P& p, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)fwd1_kernel<KK, CW, NWV, PRO, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds);
-        attr_done = true;
-    }
+    DSNT_SET_MAX_LDS((fwd1_kernel<KK, CW, NWV, PRO, RES>), pl.lds);
     DSNT_LAUNCH((fwd1_kernel<KK, CW, NWV, PRO, RES>), dim3(pl.nwg, pl.chunks), dim3(64 * NWV), pl.lds, st, p);
 }
 template <int KK, int CW, int NWV>

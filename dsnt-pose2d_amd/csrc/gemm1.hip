@@ -309,21 +309,11 @@ template <int KS, int NTW, bool PRO, int MODE>
 static void g1_launch_k(const ConvP& p, hipStream_t st, bool share) {
     constexpr int K = KS * 16, CHUNK = NTW * 32, PB = KS * 32 + 16;
     const int lds = 2 * CHUNK * PB + 2 * K * 4 + 8 * CHUNK * 2 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm1_kernel<KS, NTW, PRO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    DSNT_SET_MAX_LDS((gemm1_kernel<KS, NTW, PRO, MODE>), lds);
     const int rows_it = 8 * (8 / NTW) * 32;
     const int niter = p.M / rows_it;
     const int chunks = p.Cout / CHUNK;
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        hipGetDevice(&dev);
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = dsnt_device_cus();
     // one workgroup per CU (LDS), persistent over its share of the row blocks; column chunks side by side
     int gx = cus / chunks;
     // DSNT_CONV_SHARE_CHIP: a launch on a side lane.  One of these workgroups takes 139 of a CU's 160 KB of LDS for the whole

@@ -187,13 +187,7 @@ static bool s4_geom_ok(const dsnt_conv_geom* g) {
 }
 
 static int s4_grid(const dsnt_conv_geom* g) {
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        hipGetDevice(&dev);
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = dsnt_device_cus();
     const int ntiles = g->N * (g->Ho / 4) * (g->Wo / 32);
     const int grid = 2 * cus;                   // two workgroups per CU, persistent over the tiles
     return grid < ntiles ? grid : ntiles;
@@ -400,13 +394,7 @@ __global__ __launch_bounds__(512, 1) void stem4_wgrad_kernel(Stem4WP p, int ntil
 }
 
 static int s4w_grid(const dsnt_conv_geom* g) {
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        hipGetDevice(&dev);
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = dsnt_device_cus();
     const int ntiles = g->N * (g->Ho / 4) * (g->Wo / 32);
     return cus < ntiles ? cus : ntiles;          // one eight-wave workgroup per CU
 }
@@ -425,10 +413,6 @@ void dsnt_stem4_wgrad_launch(const float* x, const float* dy, float* ws, const f
     p.nwg = s4w_grid(g);
     const int ntiles = g->N * (g->Ho / 4) * (g->Wo / 32);
     const int lds = S4_ABUF + 2 * S4_GPL;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)stem4_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    DSNT_SET_MAX_LDS((stem4_wgrad_kernel), lds);
     DSNT_LAUNCH(stem4_wgrad_kernel, dim3(p.nwg), dim3(512), lds, st, p, ntiles);
 }

@@ -284,11 +284,7 @@ Wg1Plan dsnt_wg1_plan(const dsnt_conv_geom* g, bool share) {
 
 template <int KTW, int NTW>
 static void w1_launch_cfg(const Wg1Plan& pl, const Wg1P& p, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)wgrad1_kernel<KTW, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds);
-        attr_done = true;
-    }
+    DSNT_SET_MAX_LDS((wgrad1_kernel<KTW, NTW>), pl.lds);
     DSNT_LAUNCH((wgrad1_kernel<KTW, NTW>), dim3(pl.blocks), dim3(256), pl.lds, st, p);
 }
 

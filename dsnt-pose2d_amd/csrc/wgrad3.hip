@@ -356,11 +356,7 @@ static void wg3_launch_cfg(const Wg3Plan& pl, const Wg3P& p, hipStream_t st) {
     const int share_lds = 84 * 1024;
     const int lds = CFG == 2 ? share_lds : pl.lds;
     const int blocks = CFG == 2 ? 2 * pl.blocks : pl.blocks;       // 32 instead of 64 input channels per workgroup
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)wgrad3_kernel<CFG, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    DSNT_SET_MAX_LDS((wgrad3_kernel<CFG, WS>), lds);
     DSNT_LAUNCH((wgrad3_kernel<CFG, WS>), dim3(blocks), dim3(CFG == 2 ? 256 : 512), lds, st, p);
 }
 

@@ -1346,9 +1346,14 @@ class Tape:
         self.f('dsnt_bn_add_act_fwd', x.buf, n.scale, n.shift, skip.buf, 1 if relu else 0, y.buf, x.M, x.C)
         if self.record:
             def backward():
+                # the block input's gradient can START as dz and continue out of place (below): dz is then handed out as a `base`
+                # that later launches — possibly of another lane, possibly held back — still read, so it gets a buffer of its own
+                # (a shared scratch would be overwritten by the next block's backward with nothing ordering its readers first)
+                share = bool(self.share_grads and skip._grad is None and skip.base is None and skip.pending_apply is None and
+                             skip.pending_add is None)
                 if relu:
                     # the ReLU mask (from the stored y), dz and the BatchNorm's two reductions in ONE pass
-                    dz = self.scratch('dz_tail', x.M * x.C).view(-1)[:x.M * x.C]
+                    dz = (self.empty(x.M * x.C) if share else self.scratch('dz_tail', x.M * x.C).view(-1)[:x.M * x.C])
                     tiles = (x.M + 127) // 128
                     part = self.scratch('bnpart', tiles * 2 * bn.C).view(-1)
                     self.b('dsnt_bn_add_act_bwd_reduce', y.grad, y.buf, x.buf, n.mean, n.invstd, 1, dz, part, x.M, bn.C)
@@ -1356,11 +1361,9 @@ class Tape:
                 else:
                     dz = y.grad
                     self._norm_backward(n, dz)
-                if (self.share_grads and skip._grad is None and skip.base is None and skip.pending_apply is None and
-                        skip.pending_add is None):
+                if share and skip._grad is None and skip.base is None:
                     # the block input's gradient starts as dz and continues out of place (the data gradient of conv1 adds it as its
-                    # residual operand): no copy.  dz is scratch — it lives until the NEXT bn_add_act's backward, which comes after
-                    # every reader of this one (the blocks are a chain); a reader that would be deferred is not (grad_shared)
+                    # residual operand): no copy
                     skip.base, skip.base_amax = dz, None
                 else:
                     self.grad_identity(skip, dz, donate=False)

@@ -36,7 +36,10 @@ class NanGuard:
         self.steps_checked = 0
 
     def check(self, loss):
-        """Enqueue the non-finite test of `loss` (scalar or any fp32 tensor) on the current stream."""
+        """Enqueue the non-finite test of `loss` (scalar or any fp32 tensor) on the current stream.
+        Under dsnt.parallel.DataParallel call it before `loss.backward()` returns (the reference checks right after
+        forward_loss: train.py:360): the flag is exchanged between the ranks once per backward, in the reducer's wait()
+        just before the gradients are published; a check enqueued after that would stay rank-local for this step."""
         x = loss.detach()
         if x.dtype != torch.float32:
             x = x.float()

@@ -168,6 +168,7 @@ class Program:
         self.record = record = training if record is None else bool(record)
         self.token = 0
         self.in_flight = False      # a forward of this program is waiting for its backward (hourglass._Run)
+        self.owner = None           # ... and this is that forward's token
         dev = arena.device
         tape = Tape(dev, training, record)
         tape.want_input_grad = bool(input_grad and record)     # the stem then keeps its data gradient (no space-to-depth form)
@@ -248,11 +249,11 @@ class _Run(Function):
         # this program's saved activations belong to this forward until its backward has run — or until autograd drops the
         # graph (the caller let go of the outputs): a second forward of the same shape meanwhile takes another program
         prog.in_flight = True
-        token = prog.token
+        token = prog.owner = prog.token
 
         def release(p=prog, t=token):
-            if p.token == t:
-                p.in_flight = False
+            if p.owner == t:            # (not p.token: a forward that does not record bumps the token without taking ownership)
+                p.in_flight, p.owner = False, None
         weakref.finalize(ctx, release)
         return tuple(o.clone() for o in prog.outs)
 
@@ -262,6 +263,8 @@ class _Run(Function):
         if not prog.record:
             raise RuntimeError('dsnt: this forward was traced without a backward list')
         if prog.token != ctx.token:
+            if prog.owner == ctx.token:        # this forward's activations are gone: nothing is waiting for them any more
+                prog.in_flight, prog.owner = False, None
             raise RuntimeError('dsnt: the saved activations of this forward were overwritten by a '
                                'later forward of the same shape; run backward before forwarding again')
         for g, gin in zip(gouts, prog.gins):
@@ -274,6 +277,7 @@ class _Run(Function):
             runner.before_publish()
         runner.arena.publish_grads(runner.params)
         prog.in_flight = False                 # (a second backward through the same graph re-reads the same activations: allowed)
+        prog.owner = None
         gx = prog.gx.clone() if prog.input_grad else None
         return (None, None, gx) + (None,) * ctx.nparams
 
@@ -318,10 +322,12 @@ class Runner:
         record = grad_mode and (training or x.requires_grad or any(p.requires_grad for p in self.params))
         key = (tuple(x.shape), training, bool(x.requires_grad), self._bn_signature()) + (('eval+backward',) if (record and not training) else ())
         prog = self.programs.get(key)
-        if prog is not None and prog.in_flight and record:
+        if prog is not None and prog.in_flight and (record or training):
             # the reference's autograd lets a caller run several forwards before the first backward (model.py:273-307 has no
             # restriction): each such forward needs its own set of saved activations, i.e. a further traced program of the same
-            # shape (static buffers: ~190 MB per image for hg2) — created on demand, kept, at most MAX_IN_FLIGHT of them
+            # shape (static buffers: ~190 MB per image for hg2) — created on demand, kept, at most MAX_IN_FLIGHT of them.  A forward
+            # that records nothing (train mode under no_grad) takes another program as well instead of overwriting the
+            # activations a pending backward still needs
             k = 1
             while (key, k) in self.programs and self.programs[(key, k)].in_flight:
                 k += 1

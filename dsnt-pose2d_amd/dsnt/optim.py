@@ -85,13 +85,15 @@ class _FlatOptimizer(torch.optim.Optimizer):
             pg = {k: v for k, v in g.items() if k != 'params'}
             pg['params'] = list(range(len(g['params'])))
             # which order the indices follow: 'model' = model.parameters() (torch.optim's own numbering).  Revisions before
-            # round 3 numbered them in the arena's slot order (bucket by bucket) and wrote no marker: such a checkpoint is
-            # refused on load, because a permutation of equal-shaped parameters (hg stack 0 / stack 1) cannot be detected
+            # round 3 numbered them in the arena's slot order (bucket by bucket) and wrote no marker: load_state_dict cannot
+            # detect that permutation of equal-shaped parameters (hg stack 0 / stack 1) — it warns when a marker-less state
+            # does not look like torch.optim's and takes `order='arena'` for such a checkpoint
             pg['dsnt_order'] = 'model'
             groups.append(pg)
         return {'state': state, 'param_groups': groups}
 
-    def load_state_dict(self, state_dict):
+    def load_state_dict(self, state_dict, order=None):
+        """order: 'model' / 'arena' overrides the state's own `dsnt_order` marker (see below); None = use the marker."""
         groups = state_dict['param_groups']
         if len(groups) != 1 or len(groups[0]['params']) != len(self._where):
             raise ValueError('dsnt.optim: loaded state dict has a different number of parameters')
@@ -99,12 +101,23 @@ class _FlatOptimizer(torch.optim.Optimizer):
         # optimizer.state_dict()) both mean model.parameters() order.  A checkpoint of a dsnt.optim revision before round 3
         # numbered the parameters in ARENA order and carries no marker either — it cannot be told from torch's, so it has to be
         # re-tagged by hand (param_groups[0]['dsnt_order'] = 'arena') and is then re-numbered here; anything else is refused.
-        order = groups[0].get('dsnt_order', 'model')
+        if order is None:
+            order = groups[0].get('dsnt_order')
+            if order is None:
+                order = 'model'
+                # torch.optim's own param_groups carry keys this class never wrote ('foreach', 'maximize', ...): a marker-less
+                # state WITHOUT them was written by a dsnt.optim revision before round 3, i.e. in arena order — it would load
+                # silently with the state of equal-shaped parameters permuted, which no shape check can see
+                if not any(k in groups[0] for k in ('foreach', 'maximize', 'capturable', 'differentiable')):
+                    import warnings
+                    warnings.warn("dsnt.optim: the loaded state has no 'dsnt_order' marker and does not look like a torch.optim "
+                                  "state dict; taking its indices as model.parameters() order.  If it was written by a dsnt.optim "
+                                  "revision before round 3 (arena order), load it with load_state_dict(state, order='arena')",
+                                  stacklevel=2)
         if order == 'arena':
             pos = {name: i for i, (name, _, _, _) in enumerate(self.runner.arena.slots)}
             st, remap = state_dict['state'], {}
             n_arena = len(pos)
-            extra_seen = 0
             for i, (kind, key) in enumerate(self._where):
                 j = pos[key] if kind == 'arena' else n_arena + key      # (arena order listed the out-of-arena parameters last)
                 e = st.get(j, st.get(str(j)))

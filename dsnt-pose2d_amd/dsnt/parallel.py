@@ -38,9 +38,12 @@ class GradientAllReducer:
         self.flat = flat
         self.bounds = list(bounds)          # [(start, end)] element ranges, one per bucket
         self.group = group
-        # the non-finite guard's device flag (dsnt.guard.NanGuard.flag, int32): exchanged with MAX beside the first bucket of
-        # every backward, so that EVERY rank takes the same skip decision in the optimiser kernels — a NaN loss on one rank
-        # stops the whole job's update, as the reference's single process stops itself (bin/train.py:360-371)
+        # the non-finite guard's device flag (dsnt.guard.NanGuard.flag, int32): exchanged with MAX in `wait()` — after the last
+        # bucket, before the gradients are published — so that EVERY rank takes the same skip decision in the optimiser kernels:
+        # a NaN loss on one rank stops the whole job's update, as the reference's single process stops itself
+        # (bin/train.py:360-371).  In wait(), not beside the first bucket: `guard.check(loss)` may be enqueued before OR after
+        # `loss.backward()` and is covered either way (the collective is ordered after everything on the publishing stream);
+        # it queues right behind the last bucket's all-reduce, one small message
         self.flag = flag
         self.exposed_ms = []                # diagnostics (bench.py): host time spent waiting for the collectives, per backward
         self.time_waits = False
@@ -52,14 +55,11 @@ class GradientAllReducer:
     def bucket_ready(self, k, late=False):
         if k in self.fired:
             return
-        first = not self.fired
         self.fired.add(k)
         if late:
             self.last_late.append(k)
         if self.world == 1:
             return
-        if first and self.flag is not None:
-            self.pending.append(dist.all_reduce(self.flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
         s, e = self.bounds[k]
         if e > s:
             self.pending.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
@@ -73,7 +73,9 @@ class GradientAllReducer:
         """Every bucket is reduced when this returns: the ones no marker announced are enqueued here."""
         self.last_late = []
         self.reduce_all(late=True)
-        if self.time_waits and self.pending and self.flat.is_cuda:
+        if self.world > 1 and self.flag is not None:
+            self.pending.append(dist.all_reduce(self.flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+        if self.time_waits and self.pending and self.flat.is_cuda and self.stream_ordered():
             # exposed communication: what the publishing stream still has to wait for once backward has been enqueued
             # (device time between two events around the waits; read by `exposed_comm_ms` after a synchronisation)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -88,8 +90,18 @@ class GradientAllReducer:
         self.pending = []
         self.fired = set()
 
+    def stream_ordered(self):
+        """The backend's Work.wait() blocks the current STREAM (nccl = RCCL), not the host (gloo): only then do two events
+        around the waits measure what the publishing stream was held up by."""
+        return dist.is_initialized() and dist.get_backend(self.group) == 'nccl'
+
+    def bucket_bytes(self):
+        """Bytes each bucket's all-reduce moves per rank (fp32 gradient elements), in bucket order."""
+        return [4 * (e - s) for s, e in self.bounds]
+
     def exposed_comm_ms(self):
-        """Mean device time per backward that the publishing stream waited for the collectives (time_waits = True)."""
+        """Mean device time per backward that the publishing stream waited for the collectives (time_waits = True);
+        None when nothing was timed — in particular under a host-blocking backend (gloo), where the figure would read ~0."""
         if not self.exposed_ms:
             return None
         torch.cuda.synchronize()
@@ -119,7 +131,10 @@ class DataParallel:
         for b in model.buffers():
             if b.dtype.is_floating_point:
                 broadcast_flat(b.data, 0, group)
-        # (an optimiser built with guard= hands its flag over: the skip decision is then the same on every rank)
+        # (an optimiser built with guard= hands its flag over: the skip decision is then the same on every rank.  The flag is
+        # exchanged once per backward, in the reducer's wait() right before the gradients are published: a `guard.check(loss)`
+        # enqueued on the current stream at any point between the forward and the end of `loss.backward()` is covered; one
+        # enqueued AFTER backward returns belongs to the next step's exchange)
         guard = getattr(optimizer, 'guard', None)
         self.reducer = GradientAllReducer(arena.fresh, arena.bucket_bounds, group,
                                           flag=guard.flag if guard is not None else None)

@@ -1,7 +1,15 @@
-"""The round-3 kernels against the kernels they replace, end to end: one hg2 + DSNT + JS train step (batch 16, 256 px: every
-one of conv3s / gemm1 / wgrad3 / wgrad1 is eligible at the 64 x 64 level) in two processes — default, and with
-DSNT_OFF=conv3s+gemm1+wgrad3+wgrad1 (the library reads the switch once per process) — must agree to fp32 rounding of another
-summation order: loss, coordinates, every parameter gradient, running statistics."""
+"""The fused kernels and gradient plumbing of rounds 3 and 4 against what they replace, end to end, at the sizes they run at.
+
+One train step (hg2 + DSNT + JS at batch 32 / 256 px = BASELINE config 3; hg8 at batch 16 = config 5's per-GPU half) in
+separate processes — the library reads DSNT_OFF / DSNT_X once per process —:
+  * default  vs  DSNT_OFF=conv3s+gemm1+wgrad3+wgrad1       (round 3: the 3x3 persistent kernel, streaming 1x1, halo weight gradients)
+  * default  vs  DSNT_OFF=bwd1+fwd1+stem4+stem4w           (round 4: the one-pass 1x1 backward / forward, the stem kernels)
+  * default  vs  DSNT_X=share_grads=0,defer_res=0          (round 4: shared / continued gradients back to copies and donations)
+must agree to fp32 rounding of another summation order: loss, coordinates, every parameter gradient, running statistics.
+On the SMOOTH network (DSNT_DEBUG_NO_RELU: no mask bit can flip between two summation orders) every parameter gradient
+agrees to 1e-4 relative L2; with the ReLUs on, the flip-tolerant bar of tests/test_model_gpu.py.  A wrong BatchNorm
+coefficient vector, a stale `Act.base` or a shared gradient read after it was accumulated into on ONE layer fails the
+smooth bar by orders of magnitude.  (Reference: /root/reference/src/dsnt/hourglass.py:30-50,155-177.)"""
 import os
 import subprocess
 import sys
@@ -30,16 +38,24 @@ torch.save({'loss': loss.item(), 'coords': (out[-1] if isinstance(out, (list, tu
             'grads': {n: p.grad.detach().cpu() for n, p in m.named_parameters()},
             'running': {n: b.detach().cpu() for n, b in m.named_buffers() if 'running' in n},
             'stream_launches': names.count('dsnt_conv_fwd_f16x3_stream'),
+            'bwd1_launches': names.count('dsnt_conv1x1_bwd_f16x3'), 'fwd1_launches': names.count('dsnt_conv1x1_fwd_f16x3'),
+            'stem4_launches': names.count('dsnt_stem4_fwd_f16x3'), 'axpy_launches': names.count('dsnt_axpy') + names.count('dsnt_axpy_amax'),
+            'base_launches': sum(names.count(n) for n in ('dsnt_bn_act_bwd_apply_base', 'dsnt_bn_act_bwd_apply_pro_base')),
             'strided_launches': names.count('dsnt_conv_dgrad_strided'), 'stuffed_launches': names.count('dsnt_zero_insert')},
            sys.argv[1])
 '''
 
 
-def _run(tmp_path, tag, off, base='hg2', batch=16, size=256):
+def _run(tmp_path, tag, off, base='hg2', batch=16, size=256, x=None, smooth=False):
     env = dict(os.environ)
-    env.pop('DSNT_OFF', None)
+    for k in ('DSNT_OFF', 'DSNT_X', 'DSNT_DEBUG_NO_RELU'):
+        env.pop(k, None)
     if off:
         env['DSNT_OFF'] = off
+    if x:
+        env['DSNT_X'] = x
+    if smooth:
+        env['DSNT_DEBUG_NO_RELU'] = '1'
     path = str(tmp_path / (tag + '.pt'))
     subprocess.run([sys.executable, '-c', SCRIPT % {'root': ROOT, 'base': base, 'batch': batch, 'size': size}, path],
                    check=True, env=env, timeout=600)
@@ -77,3 +93,47 @@ def test_native_strided_data_gradient_agrees_with_zero_stuffing(tmp_path):
     worst = max(((new['grads'][n].double() - v.double()).norm().item() / max(v.double().norm().item(), floor), n)
                 for n, v in old['grads'].items())
     assert worst[0] <= 1e-4, worst
+
+
+_CACHE = {}
+
+
+def _cached(tmp_path_factory, base, batch, smooth, variant):
+    key = (base, batch, smooth, variant)
+    if key not in _CACHE:
+        off, x = {'default': (None, None), 'off_r4': ('bwd1+fwd1+stem4+stem4w', None),
+                  'copies': (None, 'share_grads=0,defer_res=0')}[variant]
+        d = tmp_path_factory.mktemp('%s_b%d_%s_%s' % (base, batch, 'smooth' if smooth else 'relu', variant))
+        _CACHE[key] = _run(d, 'run', off, base, batch, 256, x=x, smooth=smooth)
+    return _CACHE[key]
+
+
+def _compare(new, old, smooth):
+    assert abs(new['loss'] - old['loss']) <= 2e-6 * abs(old['loss'])
+    assert (new['coords'] - old['coords']).abs().max().item() <= 5e-6
+    floor = 1e-3 * max(v.double().norm().item() for v in old['grads'].values())
+    worst = max(((new['grads'][n].double() - v.double()).norm().item() / max(v.double().norm().item(), floor), n)
+                for n, v in old['grads'].items())
+    assert worst[0] <= (1e-4 if smooth else 3e-2), worst
+    fn = torch.cat([v.reshape(-1) for v in new['grads'].values()]).double()
+    fo = torch.cat([v.reshape(-1) for v in old['grads'].values()]).double()
+    cos = (fn @ fo / (fn.norm() * fo.norm())).item()
+    assert cos >= (1 - 1e-7 if smooth else 0.9999), cos
+    for n, v in old['running'].items():
+        assert (new['running'][n] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), n
+
+
+@pytest.mark.parametrize('smooth', [True, False], ids=['smooth', 'relu'])
+@pytest.mark.parametrize('base,batch', [('hg2', 32), ('hg8', 16)], ids=['hg2_b32', 'hg8_b16'])
+@pytest.mark.parametrize('variant', ['off_r4', 'copies'])
+def test_round4_kernels_and_gradient_plumbing_agree_with_what_they_replace(tmp_path_factory, variant, base, batch, smooth):
+    new = _cached(tmp_path_factory, base, batch, smooth, 'default')
+    old = _cached(tmp_path_factory, base, batch, smooth, variant)
+    stacks = int(base[2:])
+    assert new['bwd1_launches'] >= 8 + 10 * stacks and new['fwd1_launches'] >= 8 + 10 * stacks and new['stem4_launches'] == 1
+    if variant == 'off_r4':          # the switch reached the engine and the library
+        assert old['bwd1_launches'] == 0 and old['fwd1_launches'] == 0 and old['stem4_launches'] == 0
+    else:
+        assert new['axpy_launches'] == 0 and new['base_launches'] > 0
+        assert old['axpy_launches'] >= stacks - 1 and old['base_launches'] == 0
+    _compare(new, old, smooth)

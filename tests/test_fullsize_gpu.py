@@ -151,3 +151,55 @@ def test_every_activation_and_gradient_is_bit_reproducible(base, batch):
                    if ref[kind][i] is not None and not torch.equal(ref[kind][i], cur[kind][i])]
             assert not bad, (rep, ('activation', 'statistics', 'gradient')[kind - 1], bad[:4])
         assert torch.equal(ref[4], cur[4]), rep
+
+
+def test_resnet34_batch8_properties():
+    """BASELINE config 1 at its full size (resnet34 + DSNT + JS, 256 px, batch 8, dilate 0 -> 8 x 8 heat-maps;
+    /root/reference/src/dsnt/model.py:79-201) on the production path: the same size-independent properties as above.
+    (Its value check against the oracle at this very size is tests/test_resnet_gpu.py CASES.)"""
+    from dsnt.model import build_mpii_pose_model
+    from dsnt_oracle import nn as onn
+    m = build_mpii_pose_model(base='resnet34', output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(m, seed=0)
+    m.to(DEV).train()
+    x, t, k = synthetic.batch(8, size=256, seed=1, mask_p=0.9)
+    x, t, k = x.to(DEV), t.to(DEV), k.to(DEV)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        out = m(x)
+        loss = m.forward_loss(out, t, k)
+        loss.backward()
+        return out, loss
+
+    out, loss1 = step()
+    hm = m.heatmaps
+    assert out.shape == (8, 16, 2) and hm.shape == (8, 16, 8, 8) and float(hm.detach().min()) >= 0.0
+    assert (hm.double().sum((-1, -2)) - 1).abs().max().item() <= 1e-5
+    xs = ((2 * torch.arange(8, device=DEV, dtype=torch.float64) - 7) / 8)
+    ex = (hm.double().sum(-2) * xs).sum(-1)
+    ey = (hm.double().sum(-1) * xs).sum(-1)
+    assert (torch.stack([ex, ey], -1) - out.double()).abs().max().item() <= 2e-6
+    hc, cc = hm.detach().cpu(), out.detach().cpu()
+    total = onn.euclidean_loss(cc, t.cpu(), k.cpu()).item() + onn.js_reg_loss(hc, t.cpu(), 2.0 / 8, k.cpu()).item()
+    assert abs(loss1.item() - total) <= 1e-5 * abs(total)
+    g1 = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    _, loss2 = step()
+    g2 = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert loss1.item() == loss2.item() and torch.equal(g1, g2)
+    assert torch.isfinite(g1).all() and float(g1.norm()) > 0
+    params = list(m.parameters())
+    d = [p.grad.clone() / g1.norm() for p in params]
+    eps = 2.5e-4
+    with torch.no_grad():
+        for p, dp in zip(params, d):
+            p.add_(dp, alpha=eps)
+        lp = m.forward_loss(m(x), t, k).item()
+        for p, dp in zip(params, d):
+            p.add_(dp, alpha=-2 * eps)
+        lm = m.forward_loss(m(x), t, k).item()
+        for p, dp in zip(params, d):
+            p.add_(dp, alpha=eps)
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - float(g1.norm())) <= 0.03 * float(g1.norm()), (fd, float(g1.norm()))

@@ -684,6 +684,23 @@ def test_several_forwards_before_the_first_backward():
     with pytest.raises(RuntimeError, match='waiting for their backward'):
         for _ in range(runner.MAX_IN_FLIGHT + 1):
             keep.append(m(xa))
+    # a forward that records nothing (train mode under no_grad) while another waits for its backward takes a program of its
+    # own instead of overwriting the saved activations: the pending backward gives the gradient of ITS forward, and no
+    # program is left marked in flight afterwards (round-4 advice: the flag could stick for good)
+    del keep
+    gc.collect()
+    for p in m.parameters():
+        p.grad = None
+    m.forward_loss(m(xa), ta, ka).backward()
+    want_a = grads()
+    for p in m.parameters():
+        p.grad = None
+    la = m.forward_loss(m(xa), ta, ka)
+    with torch.no_grad():
+        m(xb)
+    la.backward()
+    assert (grads() - want_a).abs().max().item() <= 2e-6 * want_a.abs().max().item()
+    assert not any(p.in_flight for p in runner.programs.values())
 
 
 @pytest.mark.parametrize('smooth', [True, False])

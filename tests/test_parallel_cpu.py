@@ -33,20 +33,24 @@ def _worker(rank, world, port, q):
         red.wait()
         want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
         ok_sum = torch.equal(flat, want)
-        # the non-finite guard's flag travels with the first bucket of a backward (MAX): rank 1 saw a NaN loss, rank 0 did
-        # not -> both ranks end with the loss bit up and skip the same update (bin/train.py:360-371 stops its one process)
+        # the non-finite guard's flag is exchanged (MAX) in wait(), behind the last bucket: rank 1 saw a NaN loss, rank 0 did
+        # not -> both ranks end with the loss bit up and skip the same update (bin/train.py:360-371 stops its one process);
+        # a flag raised AFTER the first bucket went out (guard.check enqueued after backward started) is still covered
         flag = torch.tensor([1 if rank == 1 else 0, 0], dtype=torch.int32)
         red3 = parallel.GradientAllReducer(torch.ones(8) * (rank + 1), [(0, 4), (4, 8)], flag=flag)
+        flag0 = torch.zeros(2, dtype=torch.int32)
+        red3 = parallel.GradientAllReducer(torch.ones(8) * (rank + 1), [(0, 4), (4, 8)], flag=flag0)
         red3.bucket_ready(1)
+        flag0.copy_(flag)                      # raised between the first bucket and the wait
         red3.bucket_ready(0)
-        n_pending = len(red3.pending)          # one flag exchange + two buckets
+        n_pending = len(red3.pending)          # two buckets; the flag goes out in wait()
         red3.wait()
-        ok_sum = ok_sum and flag.tolist() == [1, 0] and n_pending == 3
-        red3.flag.zero_()                      # the next backward exchanges it again, and only once
+        ok_sum = ok_sum and flag0.tolist() == [1, 0] and n_pending == 2 and red3.bucket_bytes() == [16, 16]
+        red3.flag.zero_()                      # the next backward exchanges it again
         red3.reduce_all()
-        ok_sum = ok_sum and len(red3.pending) == 3
+        ok_sum = ok_sum and len(red3.pending) == 2
         red3.wait()
-        ok_sum = ok_sum and flag.tolist() == [0, 0]
+        ok_sum = ok_sum and flag0.tolist() == [0, 0] and red3.exposed_comm_ms() is None
         # broadcast rank 0's weights
         w = torch.full((17,), float(rank + 5))
         parallel.broadcast_flat(w, 0)

@@ -1,6 +1,9 @@
 """Data parallelism on the GPU with TWO ranks (north_star: gradient all-reduce overlapped with backward).
-Both ranks share the one MI355X of the test box, so the process group is `gloo` over device tensors (RCCL refuses two
-ranks on one device); everything else is the production path: the traced backward list with its three lanes, the
+On a box with >= 2 devices the process group is `nccl` (= RCCL), one device per rank — the production transport, whose
+collectives are ordered after the CURRENT stream at enqueue (the bucket hook runs with the producing lane's stream
+current) and whose Work.wait() holds the publishing stream, not the host.  On the one-MI355X test box both ranks share
+the device, so the group is `gloo` over device tensors (RCCL refuses two ranks on one device); everything else is the
+production path: the traced backward list with its three lanes, the
 bucket markers fired on the lane that finishes a bucket's slab reduction, the asynchronous all-reduce per bucket, the
 1/world scale in the publish kernel.  Checked: every rank ends with the SAME gradient, equal to the mean of the two
 shards' single-process gradients, for an hourglass and a ResNet model (the latter has one bucket and an out-of-arena
@@ -14,14 +17,31 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, base, strat, size, q):
+def _backend():
+    """('nccl', one device per rank) when the box has two devices, else ('gloo', both ranks on cuda:0)."""
+    return 'nccl' if torch.cuda.device_count() >= 2 else 'gloo'
+
+
+def _init(rank, world, port, backend):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = torch.device('cuda:%d' % (rank if backend == 'nccl' else 0))
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    assert dist.get_backend() == backend
+    return dev
+
+
+def _worker(rank, world, port, base, strat, size, q, backend):
     import torch.distributed as dist
     from dsnt.model import build_mpii_pose_model
     from dsnt import parallel, synthetic
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = _init(rank, world, port, backend)
     try:
-        dev = torch.device('cuda:0')
         m = build_mpii_pose_model(base=base, output_strat=strat, reg='js')
         synthetic.fill_state_dict(m, seed=0)
         m.to(dev).train()
@@ -63,7 +83,7 @@ def test_two_ranks_average_their_gradients(base, strat, size):
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, base, strat, size, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, base, strat, size, q, _backend())) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -80,15 +100,13 @@ def test_two_ranks_average_their_gradients(base, strat, size):
         assert late == [], late                           # every bucket was announced by its marker, none at the wait
 
 
-def _guard_worker(rank, world, port, q):
+def _guard_worker(rank, world, port, q, backend, check_late):
     import torch.distributed as dist
     from dsnt.model import build_mpii_pose_model
     from dsnt import parallel, synthetic, optim
     from dsnt.guard import NanGuard
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = _init(rank, world, port, backend)
     try:
-        dev = torch.device('cuda:0')
         m = build_mpii_pose_model(base='hg1', output_strat='dsnt', reg='js')
         synthetic.fill_state_dict(m, seed=0)
         m.to(dev).train()
@@ -104,8 +122,13 @@ def _guard_worker(rank, world, port, q):
             loss = m.forward_loss(m(x), t, k)
             if poison is not None:
                 loss = loss * poison
-            guard.check(loss)
+            if not check_late:
+                guard.check(loss)                # train.py:360: right after forward_loss
             opt.zero_grad()
+            if check_late:
+                # ... or enqueued while backward is under way (here: from a hook on the loss, i.e. after the first launches
+                # of backward): the flag goes out in the reducer's wait(), behind the last bucket, so it is still exchanged
+                loss.register_hook(lambda g: (guard.check(loss), g)[1])
             loss.backward()
             opt.step()
             torch.cuda.synchronize()
@@ -128,8 +151,9 @@ def _guard_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_a_nonfinite_loss_on_one_rank_stops_the_update_on_every_rank():
-    """train.py:360-371 under data parallelism: the guard's device flag is exchanged (MAX) beside the first gradient bucket,
+@pytest.mark.parametrize('check_late', [False, True], ids=['check_before_backward', 'check_during_backward'])
+def test_a_nonfinite_loss_on_one_rank_stops_the_update_on_every_rank(check_late):
+    """train.py:360-371 under data parallelism: the guard's device flag is exchanged (MAX) behind the last gradient bucket,
     so a NaN loss on rank 1 makes BOTH ranks skip the whole optimiser update — their parameters stay bit-identical (a
     rank-local flag would let rank 0 apply the finite elements of the all-reduced gradient and the replicas diverge)."""
     import torch.multiprocessing as mp
@@ -139,7 +163,7 @@ def test_a_nonfinite_loss_on_one_rank_stops_the_update_on_every_rank():
     s.close()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q, _backend(), check_late)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

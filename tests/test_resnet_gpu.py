@@ -220,6 +220,7 @@ CASES = [
     ('resnet18', 0, 0, 128, 4, 'f32'),
     ('resnet18', 0, 0, 128, 4, 'bf16x6'),
     ('resnet34', 0, 0, 256, 2, 'bf16x6'),      # BASELINE config 1's model and crop size
+    ('resnet34', 0, 0, 256, 8, 'default'),     # BASELINE config 1 AS IS: batch 8, the production kernel selection (tests/test_model.py:39-63)
     ('resnet18', 2, 0, 64, 2, 'f32'),          # dilation surgery: strides removed, 3x3 convs dilated 2 and 4
     ('resnet18', 1, 1, 64, 2, 'bf16x6'),       # truncated + dilated
     ('resnet50', 0, 0, 256, 2, 'f32'),         # Bottleneck blocks (128 BN samples per channel at layer4)
@@ -232,7 +233,11 @@ def test_resnet_pose_model_vs_oracle(base, dilate, truncate, size, batch, mfma, 
     from dsnt.model import build_mpii_pose_model
     from dsnt_oracle import model as omodel
     import torch.nn as nn
-    monkeypatch.setenv('DSNT_MFMA', mfma)
+    if mfma == 'default':
+        monkeypatch.delenv('DSNT_MFMA', raising=False)
+        monkeypatch.delenv('DSNT_BF16X6_MIN_ROWS', raising=False)
+    else:
+        monkeypatch.setenv('DSNT_MFMA', mfma)
     if mfma == 'bf16x6':
         monkeypatch.setenv('DSNT_BF16X6_MIN_ROWS', '0')
     kw = dict(base=base, dilate=dilate, truncate=truncate, output_strat='dsnt', reg='js')
