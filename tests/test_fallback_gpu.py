@@ -3,13 +3,14 @@
 One train step (hg2 + DSNT + JS at batch 32 / 256 px = BASELINE config 3; hg8 at batch 16 = config 5's per-GPU half) in
 separate processes — the library reads DSNT_OFF / DSNT_X once per process —:
   * default  vs  DSNT_OFF=conv3s+gemm1+wgrad3+wgrad1       (round 3: the 3x3 persistent kernel, streaming 1x1, halo weight gradients)
-  * default  vs  DSNT_OFF=bwd1+fwd1+stem4+stem4w           (round 4: the one-pass 1x1 backward / forward, the stem kernels)
-  * default  vs  DSNT_X=share_grads=0,defer_res=0          (round 4: shared / continued gradients back to copies and donations)
+  * default  vs  DSNT_OFF=bwd1+stem4w                      (round 4, backward only: the one-pass 1x1 backward, the stem's weight gradient)
+  * default  vs  DSNT_X=share_grads=0,defer_res=0          (round 4, backward only: shared / continued gradients back to copies and donations)
+  * default  vs  DSNT_OFF=fwd1+stem4                       (round 4, forward: the streaming 1x1 forward, the stem's halo kernel)
 must agree to fp32 rounding of another summation order: loss, coordinates, every parameter gradient, running statistics.
-On the SMOOTH network (DSNT_DEBUG_NO_RELU: no mask bit can flip between two summation orders) every parameter gradient
-agrees to 1e-4 relative L2; with the ReLUs on, the flip-tolerant bar of tests/test_model_gpu.py.  A wrong BatchNorm
-coefficient vector, a stale `Act.base` or a shared gradient read after it was accumulated into on ONE layer fails the
-smooth bar by orders of magnitude.  (Reference: /root/reference/src/dsnt/hourglass.py:30-50,155-177.)"""
+The backward-only switches leave the forward bit-identical, so on the real network every parameter gradient agrees to 1e-4
+relative L2: a wrong BatchNorm coefficient vector, a stale `Act.base` or a shared gradient read after it was accumulated
+into on ONE layer fails that by orders of magnitude.  The forward switches move last bits of every activation (max-pool
+arg-max ties and ReLU masks may flip): the bulk to 1e-4 on the smooth network, the flip-tolerant bar with the ReLUs on.  (Reference: /root/reference/src/dsnt/hourglass.py:30-50,155-177.)"""
 import os
 import subprocess
 import sys
@@ -96,44 +97,88 @@ def test_native_strided_data_gradient_agrees_with_zero_stuffing(tmp_path):
 
 
 _CACHE = {}
+VARIANTS = {'default': (None, None),
+            # backward-only switches: the forward list is the same, bit for bit — so are the ReLU masks and pool indices
+            'bwd_r4': ('bwd1+stem4w', None), 'copies': (None, 'share_grads=0,defer_res=0'),
+            # forward kernels: other roundings in the forward (statistics rows per workgroup instead of per tile, ...)
+            'fwd_r4': ('fwd1+stem4', None)}
 
 
 def _cached(tmp_path_factory, base, batch, smooth, variant):
     key = (base, batch, smooth, variant)
     if key not in _CACHE:
-        off, x = {'default': (None, None), 'off_r4': ('bwd1+fwd1+stem4+stem4w', None),
-                  'copies': (None, 'share_grads=0,defer_res=0')}[variant]
+        off, x = VARIANTS[variant]
         d = tmp_path_factory.mktemp('%s_b%d_%s_%s' % (base, batch, 'smooth' if smooth else 'relu', variant))
         _CACHE[key] = _run(d, 'run', off, base, batch, 256, x=x, smooth=smooth)
     return _CACHE[key]
 
 
-def _compare(new, old, smooth):
-    assert abs(new['loss'] - old['loss']) <= 2e-6 * abs(old['loss'])
-    assert (new['coords'] - old['coords']).abs().max().item() <= 5e-6
+def _errors(new, old):
     floor = 1e-3 * max(v.double().norm().item() for v in old['grads'].values())
-    worst = max(((new['grads'][n].double() - v.double()).norm().item() / max(v.double().norm().item(), floor), n)
-                for n, v in old['grads'].items())
-    assert worst[0] <= (1e-4 if smooth else 3e-2), worst
+    errs = sorted(((new['grads'][n].double() - v.double()).norm().item() / max(v.double().norm().item(), floor), n)
+                  for n, v in old['grads'].items())
     fn = torch.cat([v.reshape(-1) for v in new['grads'].values()]).double()
     fo = torch.cat([v.reshape(-1) for v in old['grads'].values()]).double()
-    cos = (fn @ fo / (fn.norm() * fo.norm())).item()
-    assert cos >= (1 - 1e-7 if smooth else 0.9999), cos
+    return errs, (fn @ fo / (fn.norm() * fo.norm())).item(), floor
+
+
+def _launches_ok(new, old, variant, stacks):
+    assert new['bwd1_launches'] >= 8 + 10 * stacks and new['fwd1_launches'] >= 8 + 10 * stacks and new['stem4_launches'] == 1
+    assert new['axpy_launches'] == 0 and new['base_launches'] > 0
+    if variant == 'bwd_r4':          # the switch reached the engine and the library
+        assert old['bwd1_launches'] == 0 and old['fwd1_launches'] == new['fwd1_launches']
+    elif variant == 'fwd_r4':
+        assert old['fwd1_launches'] == 0 and old['stem4_launches'] == 0 and old['bwd1_launches'] == new['bwd1_launches']
+    else:
+        assert old['axpy_launches'] >= stacks - 1 and old['base_launches'] == 0
+
+
+@pytest.mark.parametrize('base,batch', [('hg2', 32), ('hg8', 16)], ids=['hg2_b32', 'hg8_b16'])
+@pytest.mark.parametrize('variant', ['bwd_r4', 'copies'])
+def test_round4_backward_kernels_and_gradient_plumbing_agree_with_what_they_replace(tmp_path_factory, variant, base, batch):
+    """The one-pass 1x1 backward (31 launches per hg2 step, 13 with a folded BatchNorm apply; the stem's weight gradient) against
+    apply + data gradient + weight gradient as separate launches, and shared / continued gradients against copies and
+    donations — on the REAL network (ReLUs on) at full size: both sides run the same forward list, so loss, coordinates, ReLU
+    masks and pool indices are bit-identical and every parameter gradient has to agree to fp32 summation order: 1e-4
+    relative L2 (measured: median 1e-7 .. 7e-7, 99th percentile <= 6e-5).  The bias of a convolution DIRECTLY in front of
+    a BatchNorm (conv1 / conv2 of a Bottleneck, the stem, `fc`) has an exactly-zero true gradient: what is compared there
+    is the rounding noise of a sum over up to 524288 pixels, held to 1e-3 of the floor (= 1e-6 of the largest gradient norm;
+    measured <= 6.5e-4, at the stem's bias)."""
+    new = _cached(tmp_path_factory, base, batch, False, 'default')
+    old = _cached(tmp_path_factory, base, batch, False, variant)
+    _launches_ok(new, old, variant, int(base[2:]))
+    assert new['loss'] == old['loss'] and torch.equal(new['coords'], old['coords'])
     for n, v in old['running'].items():
-        assert (new['running'][n] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), n
+        assert torch.equal(new['running'][n], v), n
+    errs, cos, floor = _errors(new, old)
+    import re
+    zero_true = re.compile(r'(^|\.)(conv1|conv2)\.bias$|(^|\.)fc\.\d+\.0\.bias$')
+    bad = [(e, n) for e, n in errs if e > (1e-3 if zero_true.search(n) else 1e-4)]
+    assert not bad, bad[-5:]
+    assert all(old['grads'][n].double().norm().item() < floor for e, n in errs if zero_true.search(n) and e > 1e-4)
+    assert cos >= 1 - 1e-10, cos
 
 
 @pytest.mark.parametrize('smooth', [True, False], ids=['smooth', 'relu'])
 @pytest.mark.parametrize('base,batch', [('hg2', 32), ('hg8', 16)], ids=['hg2_b32', 'hg8_b16'])
-@pytest.mark.parametrize('variant', ['off_r4', 'copies'])
-def test_round4_kernels_and_gradient_plumbing_agree_with_what_they_replace(tmp_path_factory, variant, base, batch, smooth):
+def test_round4_forward_kernels_agree_with_what_they_replace(tmp_path_factory, base, batch, smooth):
+    """The streaming 1x1 forward and the stem's halo kernel against gemm1 / the tiled kernels.  Their statistics rows are summed
+    in another order, so every activation differs in its last bits and arg-max ties of the max-pools (and, with the ReLUs
+    on, mask bits) may fall the other way — the network is not smooth even without its ReLUs (tests/test_model_gpu.py: hg8).
+    Smooth: the bulk of the parameters agrees to 1e-4 (median; measured 3e-6), every one to 1e-2, flat cosine 1 - 1e-5;
+    ReLUs on: the flip-tolerant bar."""
     new = _cached(tmp_path_factory, base, batch, smooth, 'default')
-    old = _cached(tmp_path_factory, base, batch, smooth, variant)
-    stacks = int(base[2:])
-    assert new['bwd1_launches'] >= 8 + 10 * stacks and new['fwd1_launches'] >= 8 + 10 * stacks and new['stem4_launches'] == 1
-    if variant == 'off_r4':          # the switch reached the engine and the library
-        assert old['bwd1_launches'] == 0 and old['fwd1_launches'] == 0 and old['stem4_launches'] == 0
+    old = _cached(tmp_path_factory, base, batch, smooth, 'fwd_r4')
+    _launches_ok(new, old, 'fwd_r4', int(base[2:]))
+    assert abs(new['loss'] - old['loss']) <= 2e-6 * abs(old['loss'])
+    # (measured 2e-6 .. 5e-6 on hg2, 1.4e-5 through the eight stacks of hg8 with the ReLUs on; the north-star bar is 1e-4)
+    assert (new['coords'] - old['coords']).abs().max().item() <= (1e-5 if smooth else 3e-5)
+    errs, cos, _ = _errors(new, old)
+    if smooth:
+        assert errs[len(errs) // 2][0] <= 1e-4 and errs[-1][0] <= 1e-2, (errs[len(errs) // 2], errs[-1])
+        assert cos >= 1 - 1e-5, cos
     else:
-        assert new['axpy_launches'] == 0 and new['base_launches'] > 0
-        assert old['axpy_launches'] >= stacks - 1 and old['base_launches'] == 0
-    _compare(new, old, smooth)
+        assert errs[-1][0] <= 3e-2, errs[-1]          # measured 1.7e-2
+        assert cos >= 0.9995, cos                     # measured 1 - 5e-5 (hg2), 1 - 8e-5 (hg8)
+    for n, v in old['running'].items():
+        assert (new['running'][n] - v).abs().max().item() <= 1e-5 * max(1.0, v.abs().max().item()), n
