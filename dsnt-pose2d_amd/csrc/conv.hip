@@ -1118,6 +1118,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
     p.res1 = res1; p.res2 = res2; p.stats = stats_partial; p.in_relu = in_relu; p.wq = nullptr; p.wq_stride = 0;
     p.bnb_scale = p.bnb_shift = p.bnb_mean = p.bnb_invstd = nullptr; p.bnb_relu = 0;
     p.a_bound = p.w_bound = nullptr;
+    p.ap_y = p.ap_scale = p.ap_mean = p.ap_invstd = p.ap_coef = nullptr; p.ap_out = nullptr;
     if (g_bnb) {
         p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
         p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
@@ -1439,11 +1440,9 @@ static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
     size_t lds = (size_t)2 * (F16 ? 2 : 3) * (BM + BN) * PITCH6 * 2 + (size_t)2 * p.Cin * sizeof(float);   // tiles + BN vectors
     const size_t epi = (size_t)BM * (BN + 4) * 4;          // the epilogue's C tile lives in the same LDS
     if (epi > lds) lds = epi;
-    static size_t attr_lds = 0;
-    if (lds > 65536 && lds > attr_lds) {
-        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
+    if (lds > 65536) {
+        DSNT_SET_MAX_LDS((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, true, F16, 2>), lds);
+        DSNT_SET_MAX_LDS((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>), lds);
     }
     // two A-operand register stages (DA): four measured 2-5 % slower on every 1x1 shape of the hourglass (round 2)
     dim3 gr(p.mtiles * p.ntiles), bl(512);
@@ -1459,7 +1458,7 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
                           const float* res1, const float* res2, float* stats_partial,
                           const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* g_bnb, const dsnt_out_bounds* g_tail,
                           void* stream, const float* a_bound = nullptr, const float* w_bound = nullptr,
-                          bool stream_w = false) {
+                          bool stream_w = false, const dsnt_bn_bwd_apply* g_ap = nullptr, float* ap_out = nullptr) {
     if (int e = check_geom(g, "dsnt_conv_fwd_bf16x6")) return e;
     DSNT_REQUIRE(!g_bnb || (g_bnb->x && g_bnb->scale && g_bnb->shift && g_bnb->mean && g_bnb->invstd &&
                             stats_partial && !res1 && !res2 && !bias), DSNT_ERR_ARG,
@@ -1482,6 +1481,7 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     p.in_relu = in_relu;
     p.bnb_scale = p.bnb_shift = p.bnb_mean = p.bnb_invstd = nullptr; p.bnb_relu = 0;
     p.a_bound = p.w_bound = nullptr;
+    p.ap_y = p.ap_scale = p.ap_mean = p.ap_invstd = p.ap_coef = nullptr; p.ap_out = nullptr;
     if (g_bnb) {
         p.res1 = g_bnb->x; p.bnb_scale = g_bnb->scale; p.bnb_shift = g_bnb->shift;
         p.bnb_mean = g_bnb->mean; p.bnb_invstd = g_bnb->invstd; p.bnb_relu = g_bnb->relu;
@@ -1497,6 +1497,10 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     p.a_bound = a_bound; p.w_bound = w_bound;
     const bool share_chip = a_bound && (in_relu & DSNT_CONV_SHARE_CHIP) != 0;       // (fp16x3 entry points) leave room beside this launch
     if (a_bound) p.in_relu = in_relu & 1;
+    if (g_ap) {
+        p.ap_y = g_ap->y; p.ap_scale = g_ap->scale; p.ap_mean = g_ap->mean; p.ap_invstd = g_ap->invstd; p.ap_coef = g_ap->coef;
+        p.ap_out = ap_out;
+    }
     if (stream_w) {                  // 3x3, weights in the stream layout: the symmetric kernel (conv3s.hip)
         DSNT_REQUIRE(dsnt_conv3s_ok(p), DSNT_ERR_SHAPE, "dsnt_conv_fwd_f16x3_stream: launch not supported (dsnt_conv_fwd_stream_ok; "
                      "no second residual)");
@@ -1561,6 +1565,26 @@ extern "C" int dsnt_conv_fwd_f16x3_stream(const float* x, const void* w_planes, 
                           stats_partial, g, bnb, tail, stream, a_bound, w_bound, true);
 }
 extern "C" int dsnt_conv_fwd_stream_ok(const dsnt_conv_geom* g) { return dsnt_conv3s_geom_ok(g) ? 1 : 0; }
+
+// The data gradient of a 3x3 convolution whose OUTPUT feeds a train-mode BatchNorm, with that BatchNorm's backward folded into
+// the operand load (conv3s.hip MODE 4): instead of dL/dy the launch reads dz (the ReLU-masked, reduced gradient behind the
+// BatchNorm) and the BatchNorm's input ap->y and forms  dy = scale (dz - c0 - (y - mean) invstd c1)  on the fly; it also writes
+// dy to dy_out (what the weight gradient of the same convolution reads next).  bnb (required): the BatchNorm-backward epilogue
+// of the BatchNorm IN FRONT of the convolution, as in dsnt_conv_fwd_f16x3_stream.  a_bound: a bound of |dy|
+// (dsnt_bn_bwd_finalize_bound).
+extern "C" int dsnt_conv_dgrad_f16x3_stream_apply(const float* dz, const dsnt_bn_bwd_apply* ap, float* dy_out,
+                                                  const void* w_planes, int64_t plane_stride, const float* w_bound,
+                                                  const float* a_bound, float* dx_dz, float* stats_partial, int flags,
+                                                  const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
+                                                  const dsnt_out_bounds* tail, void* stream) {
+    DSNT_REQUIRE(a_bound && w_bound, DSNT_ERR_ARG, "dsnt_conv_dgrad_f16x3_stream_apply: the operand bounds (device scalars) are required");
+    DSNT_REQUIRE(ap && ap->y && ap->scale && ap->mean && ap->invstd && ap->coef && dy_out && bnb, DSNT_ERR_ARG,
+                 "dsnt_conv_dgrad_f16x3_stream_apply: needs a complete dsnt_bn_bwd_apply, dy_out and the BatchNorm-backward epilogue");
+    DSNT_REQUIRE(dsnt_aligned16(ap->y) && dsnt_aligned16(dy_out) && dy_out != dz, DSNT_ERR_ALIGN,
+                 "dsnt_conv_dgrad_f16x3_stream_apply: 16-byte alignment; dy_out must not alias dz (halo pixels are re-read by other workgroups)");
+    return conv_fwd6_impl(dz, w_planes, plane_stride, nullptr, dx_dz, nullptr, nullptr, flags & DSNT_CONV_SHARE_CHIP, nullptr, nullptr,
+                          stats_partial, g, bnb, tail, stream, a_bound, w_bound, true, ap, dy_out);
+}
 
 // max |src[i]| -> out[0] (bit pattern of a non-negative float: integer max is float max)
 __global__ void amax_kernel(const float4* __restrict__ src, unsigned* __restrict__ out, long n4) {

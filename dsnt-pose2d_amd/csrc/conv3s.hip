@@ -35,7 +35,13 @@ typedef unsigned c3_u32x4 __attribute__((ext_vector_type(4)));
 #define C3_ABUF (2 * C3_APL)
 #define C3_BP 80                            /* bytes per weight row and plane of a slot: 2 x 16 fp16 + 16 */
 
-// MODE: 0 no residual, 1 res1, 3 the BatchNorm-backward epilogue of a data-gradient launch (res1 = the BatchNorm input x)
+// MODE: 0 no residual, 1 res1, 3 the BatchNorm-backward epilogue of a data-gradient launch (res1 = the BatchNorm input x),
+// 4 = 3 with the BatchNorm backward of the layer BEHIND folded into the operand load (round 5): the A operand is not dL/dy but
+//     dL/dz (ReLU-masked, reduced) and y, two streams, and every element is formed as  dy = scale (dz - c0 - (y - mean) invstd c1)
+//     = P dz + R y + S  while it is staged (the separate dsnt_bn_act_bwd_apply pass in front of every 3x3 data gradient is gone);
+//     the 128 pixels of the patch itself (not the halo ring: each pixel of the image is interior to exactly one patch) are also
+//     written to p.ap_out — the materialised dL/dy the weight gradient reads afterwards.  The affine form carries the
+//     conditioning of a scale / shift BatchNorm forward (eps |mean| / std), like `fmaf(x, scale, shift)` everywhere else.
 // PW: the patch is 128 / PW rows of PW pixels — 4 x 32 (W % 32 == 0), or 8 x 16 for the 16-pixel-wide levels (a 32-pixel MFMA
 // tile then spans two patch rows: a few two-way LDS bank conflicts on the activation fragments, immaterial at that size)
 template <int CO, bool PRO, int MODE, int PW>
@@ -44,13 +50,15 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     constexpr int PH = 128 / PW, HW = PW + 2, HPX = (PH + 2) * HW, ITEMS = HPX * 4;
     static_assert(HPX <= C3_HPX, "halo buffer");
     constexpr int BPL = CO * C3_BP, BSLOT = 2 * BPL;
+    constexpr bool APPLY = MODE == 4, BNB = MODE >= 3;
+    static_assert(!(APPLY && PRO), "the folded BatchNorm backward replaces the prologue");
     constexpr int NJB = CO / 32;                // 16-byte weight units per thread and K-step pair
     constexpr int UPP = 4 * CO;                 // units per plane and pair
     const unsigned OOB = 0xF0000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char c3_smem[];
     unsigned char* As = c3_smem;                // [2 chunk buffers][2 planes][204 px][48]
     unsigned char* Bs = c3_smem + 2 * C3_ABUF;  // [2 slots][2 planes][CO][80]
-    float* SS = reinterpret_cast<float*>(Bs + 2 * BSLOT);          // PRO: [2][Cin] BN scale / shift x operand scale
+    float* SS = reinterpret_cast<float*>(Bs + 2 * BSLOT);          // PRO: [2][Cin] BN scale / shift x operand scale; APPLY: [3][Cin] P, R, S
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,10 +78,13 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res1 ? p.res1 : p.y), 0, ybytes, 0x00020000);
     const unsigned rowbytes = (unsigned)p.Cout * 4u;
+    const int xbytes = (int)((size_t)p.M * p.Cin * 4u);
+    const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(APPLY ? p.ap_y : p.x), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dor = __builtin_amdgcn_make_buffer_rsrc(APPLY ? p.ap_out : p.y, 0, APPLY ? xbytes : ybytes, 0x00020000);
 
     // ---- halo staging: item = tid + 256 j (< 816) -> halo pixel item >> 2, 4-channel quad item & 3
     const int kc = tid & 3;
-    unsigned aoffs[4], aok = 0;
+    unsigned aoffs[4], aok = 0;                 // aok bits 0-3: the halo pixel lies inside the image; bits 4-7 (APPLY): it is one of the patch's own
     auto set_tile = [&](const int vv) {         // global offsets of the tile with virtual index vv; returns its first pixel
         aok = 0;
         int img = 0, th = 0, tw = 0;
@@ -93,11 +104,26 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
             const bool in = live && px < HPX && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             aoffs[j] = in ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + kc * 4) * 4u : OOB;
             aok |= (in ? 1u : 0u) << j;
+            if (APPLY) aok |= ((in && hy >= 1 && hy <= PH && hx >= 1 && hx <= PW) ? 16u : 0u) << j;
         }
         return (img * p.H + th * PH) * p.W + tw * PW;
     };
-    c3_u32x4 ra[4];
+    // HALF (the two-stream mode): a chunk is staged in two halves (items j = 0, 1 and j = 2, 3) that follow one another through ONE
+    // register set — store a half, then issue the next half's loads — so that the second stream costs no registers: 2 items x 2
+    // streams = the 4 b128 registers of the one-stream schedule (which with both streams spilled: 256 VGPRs + 68 B of scratch)
+    constexpr bool HALF = APPLY;
+    c3_u32x4 ra[HALF ? 2 : 4], ra2[APPLY ? 2 : 1];
     const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
+    if (APPLY) {
+        for (int k = tid; k < p.Cin; k += 256) {
+            const float sc = p.ap_scale[k], is = p.ap_invstd[k], mu = p.ap_mean[k], c0 = p.ap_coef[k], c1 = p.ap_coef[p.Cin + k];
+            const float q = sc * is * c1;
+            SS[k] = sc;                                             // dy = P dz + (S - Q y)
+            SS[p.Cin + k] = -q;
+            SS[2 * p.Cin + k] = (float)((double)q * (double)mu - (double)sc * (double)c0);
+        }
+        __syncthreads();
+    }
     if (PRO) {
         for (int k = tid; k < p.Cin; k += 256) {
             SS[k] = p.in_scale[k] * sa;                             // the operand scale rides in the BN vectors
@@ -105,21 +131,29 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
         }
         __syncthreads();
     }
-    auto gloadA = [&](const int c) {
+    // h: 0 / 1 = items j = 2 h, 2 h + 1 (HALF); otherwise all four
+    auto gloadA = [&](const int c, const int h = 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoffs[j], c * 64, 0);
+        for (int j = 0; j < (HALF ? 2 : 4); ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoffs[HALF ? 2 * h + j : j], c * 64, 0);
+        if (APPLY) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ra2[j] = __builtin_amdgcn_raw_buffer_load_b128(x2r, aoffs[2 * h + j], c * 64, 0);
+        }
     };
-    auto storeA = [&](const int buf, const int c) {
+    auto storeA = [&](const int buf, const int c, const int h = 0) {
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRO) {
+        float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRO || APPLY) {
             sc = *reinterpret_cast<const float4*>(SS + c * 16 + kc * 4);
             sh = *reinterpret_cast<const float4*>(SS + p.Cin + c * 16 + kc * 4);
         }
+        if (APPLY) sq = *reinterpret_cast<const float4*>(SS + 2 * p.Cin + c * 16 + kc * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int jj = 0; jj < (HALF ? 2 : 4); ++jj) {
+            const int j = HALF ? 2 * h + jj : jj;
             if (tid + 256 * j >= ITEMS) continue;
-            float4 v = make_float4(__uint_as_float(ra[j].x), __uint_as_float(ra[j].y),
-                                   __uint_as_float(ra[j].z), __uint_as_float(ra[j].w));
+            float4 v = make_float4(__uint_as_float(ra[jj].x), __uint_as_float(ra[jj].y),
+                                   __uint_as_float(ra[jj].z), __uint_as_float(ra[jj].w));
             if (PRO) {
                 // BN FMAs; ReLU + zero padding (applied after BN + ReLU) as one median per element
                 const bool ok = (aok >> j) & 1u;
@@ -128,6 +162,17 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 v.y = __builtin_amdgcn_fmed3f(fmaf(v.y, sc.y, sh.y), lo, hi);
                 v.z = __builtin_amdgcn_fmed3f(fmaf(v.z, sc.z, sh.z), lo, hi);
                 v.w = __builtin_amdgcn_fmed3f(fmaf(v.w, sc.w, sh.w), lo, hi);
+            } else if (APPLY) {
+                // dy = P dz + (R y + S); a pixel outside the image is zero padding of dy (both loads returned zeros: mask S)
+                const bool ok = (aok >> j) & 1u;
+                v.x = fmaf(v.x, sc.x, fmaf(__uint_as_float(ra2[jj].x), sh.x, ok ? sq.x : 0.f));
+                v.y = fmaf(v.y, sc.y, fmaf(__uint_as_float(ra2[jj].y), sh.y, ok ? sq.y : 0.f));
+                v.z = fmaf(v.z, sc.z, fmaf(__uint_as_float(ra2[jj].z), sh.z, ok ? sq.z : 0.f));
+                v.w = fmaf(v.w, sc.w, fmaf(__uint_as_float(ra2[jj].w), sh.w, ok ? sq.w : 0.f));
+                // (no branch: a pixel of the halo ring gets an out-of-range offset and the store is dropped)
+                __builtin_amdgcn_raw_buffer_store_b128((c3_u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z),
+                                                                  __float_as_uint(v.w)}, dor, ((aok >> (4 + j)) & 1u) ? aoffs[j] : OOB, c * 64, 0);
+                v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
             } else {
                 v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
             }
@@ -236,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
             auto loadcol = [&](const int b) {
                 const int n = (wn * TN + b) * 32 + lr;
                 Col c = {0.f, 0.f, 0.f, 0.f, 0.f};
-                if (MODE == 3) { c.sc = p.bnb_scale[n]; c.sh = p.bnb_shift[n]; c.mu = p.bnb_mean[n]; c.is = p.bnb_invstd[n]; }
+                if (BNB) { c.sc = p.bnb_scale[n]; c.sh = p.bnb_shift[n]; c.mu = p.bnb_mean[n]; c.is = p.bnb_invstd[n]; }
                 else {
                     if (p.bias) c.cb = p.bias[n];
                     if (p.tail.amax_bn) { c.sc = p.tail.amax_scale[n]; c.sh = p.tail.amax_shift[n]; }
@@ -260,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 for (int e = 0; e < 16; ++e) {
                     const unsigned so = reg_off(e);
                     float val = acc[a][b][e] * osc;
-                    if (MODE == 3) {
+                    if (BNB) {
                         // val = dL/d relu(bn(x)); r = x: mask by the ReLU, accumulate the BatchNorm-backward sums
                         const float xv = r[e];
                         if (p.bnb_relu && fmaf(xv, col.sc, col.sh) <= 0.f) val = 0.f;
@@ -297,9 +342,15 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     // ---- prologue of the workgroup's FIRST tile
     int v = blockIdx.x;
     int m0 = set_tile(v), m0n = 0;
-    gloadA(0);
     gloadB();
-    storeA(0, 0);
+    if (HALF) {                                 // chunk 0 whole and the first half of chunk 1 (the loop's chain continues with its second)
+        gloadA(0, 0); storeA(0, 0, 0);
+        gloadA(0, 1); storeA(0, 0, 1);
+        gloadA(1, 0); storeA(1, 1, 0);
+    } else {
+        gloadA(0);
+        storeA(0, 0);
+    }
     storeB(0);
     gloadB();                                   // pair 1 travels
     unsigned bcur = 0, bnxt = BSLOT;
@@ -341,6 +392,24 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 // (Fetching four / five iterations ahead instead of two / three, the stores in the first half: 105 -> 108 us.)
                 if (!(C3_ABL & 8)) rd(F0, 2 * it + 2, bnxt);
                 if (!(C3_ABL & 2)) {
+                if (HALF) {
+                    // one register set, a chain of halves: buffer 1 (odd chunk; free from step 17 of the previous pair until
+                    // step 9) receives its halves at it = 8 of the previous pair and it = 2, buffer 0 (the next even chunk — or
+                    // chunk 0 of the next tile —; free after step 8) at it = 4 and it = 6; every half is fetched two iterations
+                    // before it is stored, right after the store that frees the registers
+                    const bool last = c2 + 2 >= nchunks;
+                    if (it == 2) storeA(1, c2 + 1, 1);
+                    if (it == 4) storeA(0, last ? 0 : c2 + 2, 0);
+                    if (it == 6) storeA(0, last ? 0 : c2 + 2, 1);
+                    if (it == 8) storeA(1, last ? 1 : c2 + 3, 0);
+                    if (it == 0) gloadA(c2 + 1, 1);
+                    if (it == 2) {
+                        if (last) m0n = set_tile(v + (int)gridDim.x);           // from here on the offsets are the next tile's
+                        gloadA(last ? 0 : c2 + 2, 0);
+                    }
+                    if (it == 4) gloadA(last ? 0 : c2 + 2, 1);
+                    if (it == 6) gloadA(last ? 1 : c2 + 3, 0);
+                } else {
                 if (it == 0) gloadA(c2 + 1);
                 if (it == 2) storeA(1, c2 + 1);
                 if (it == 4) {
@@ -349,20 +418,38 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 }
                 if (it == 7) storeA(0, c2 + 2 < nchunks ? c2 + 2 : 0);
                 }
+                }
                 mm(F1);
 #pragma unroll
                 for (int i = 0; i < 4 * TM; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                if (it == 0 || it == 4) {
+                if (HALF) {
+                    if (it == 2 || it == 4 || it == 6 || it == 8) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                        }
+                    }
+                    if (it == 0 || it == 2 || it == 4 || it == 6) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
+                    }
+                } else if (it == 0 || it == 4) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 }
-                if (it == 2 || it == 7) {
+                if (!HALF && (it == 2 || it == 7)) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -419,12 +506,13 @@ bool dsnt_conv3s_ok(const ConvP& p) {
     if (!p.a_bound || !p.w_bound || !p.wq) return false;
     if (p.res2) return false;
     if (p.bnb_scale && p.in_scale) return false;
+    if (p.ap_y && !(p.bnb_scale && p.ap_scale && p.ap_mean && p.ap_invstd && p.ap_coef && p.ap_out && !p.res2)) return false;
     return true;
 }
 
 template <int CO, bool PRO, int MODE, int PW>
 static void c3_launch_k(const ConvP& p, hipStream_t st, bool share) {
-    const int lds = 2 * C3_ABUF + 2 * 2 * CO * C3_BP + 1024;       // halo buffers, weight ring, BatchNorm vectors
+    const int lds = 2 * C3_ABUF + 2 * 2 * CO * C3_BP + (MODE == 4 ? 1536 : 1024);       // halo buffers, weight ring, BatchNorm vectors
     DSNT_SET_MAX_LDS((conv3s_kernel<CO, PRO, MODE, PW>), lds);
     const int cus = dsnt_device_cus();
     const int ntiles = p.N * (p.H / (128 / PW)) * (p.W / PW);
@@ -446,7 +534,8 @@ static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
 
 template <int CO>
 static void c3_launch(const ConvP& p, bool pro, hipStream_t st, bool share) {
-    if (p.bnb_scale) c3_launch_m<CO, false, 3>(p, st, share);
+    if (p.bnb_scale && p.ap_y) c3_launch_m<CO, false, 4>(p, st, share);
+    else if (p.bnb_scale) c3_launch_m<CO, false, 3>(p, st, share);
     else if (pro) {
         if (p.res1) c3_launch_m<CO, true, 1>(p, st, share);
         else c3_launch_m<CO, true, 0>(p, st, share);

@@ -69,6 +69,10 @@ struct ConvP {
     const float* a_bound; const float* w_bound;
     int N, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil;
     int M, K, mtiles, ntiles;
+    // optional (conv3s.hip MODE 4, data-gradient launches with the BatchNorm-backward epilogue): the A operand is formed while it is
+    // staged as  scale (x - c0 - (ap_y - mean) invstd c1)  — x = dL/dz of the BatchNorm behind this convolution, ap_y its input,
+    // ap_coef = [c0 | c1] — and the patch's own pixels of it are written to ap_out (the materialised dL/dy)
+    const float* ap_y; const float* ap_scale; const float* ap_mean; const float* ap_invstd; const float* ap_coef; float* ap_out;
     // optional: the operand bounds this launch leaves for the consumers of its output (bn_pro.h)
     OutBoundsP tail;
     // optional (pro.partial != null): the BatchNorm of the A operand is finalised in this launch's prologue — every

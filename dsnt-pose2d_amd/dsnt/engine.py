@@ -151,6 +151,9 @@ class Tape:
         # epilogue + weight gradient + (conv1 of a Bottleneck) the BatchNorm backward of the layer behind, each tensor read once
         self.bwd1 = 'bwd1' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
         self.fwd1 = 'fwd1' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')      # ... and their forward (csrc/fwd1.hip)
+        # round 5: the BatchNorm backward behind a 3x3 convolution folded into that convolution's data gradient (conv3s.hip MODE 4)
+        self.fold3 = 'fold3' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
+        self.fold3_rows = int(os.environ.get('DSNT_X_FOLD3_ROWS', '16384'))
         self.stem4 = 'stem4' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')    # the stem's forward (csrc/stem4.hip)
         self._f16_w_stream = {}
         # DSNT_CONV_SHARE_CHIP on the side lanes' launches of the two persistent kernels (3x3: 3/2 workgroups per CU; 1x1: half of
@@ -994,12 +997,21 @@ class Tape:
                      self.lib.dsnt_conv1x1_bwd_ok(C.byref(g)))
         # ... and without residual inputs (whose gradient IS dL/dy) it can also take over the BatchNorm backward of its consumer
         y.fold_ok = fuse1 and normed and res1 is None and res2 is None
+        # the same for a 3x3 convolution on the persistent fp16x3 kernel (conv2 of a Bottleneck: bn3's backward rides in the operand
+        # load of conv2's data gradient, csrc/conv3s.hip MODE 4), from DSNT_X_FOLD3_ROWS output rows
+        fold3_ok = bool(self.fold3 and self.bwd1 and normed and self.training and res1 is None and res2 is None and slot is not None and
+                        self.use_f16x3 and self.defer_reduce and p.R == 3 and p.S == 3 and p.stride == 1 and use16 and
+                        y.M >= self.fold3_rows and
+                        self.stream_ok(p, ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, p.dil * (p.R - 1) - p.pad, p.dil),
+                                       x.M, None))
+        y.fold_ok = y.fold_ok or fold3_ok
 
         def backward():
             gy = y.grad
             ap = y.pending_apply
             fused = fuse1 and self.dgrad_planes16 is not None
-            if ap is not None and (not fused or gy is not None):
+            fold3 = bool(fold3_ok and ap is not None and gy is None and self.dgrad_planes16 is not None and need_input_grad)
+            if ap is not None and (not fused or gy is not None) and not fold3:
                 self.materialize_apply(y)
                 ap, gy = None, y.grad
             assert gy is not None or ap is not None, 'no gradient reached conv output ' + name
@@ -1060,184 +1072,218 @@ class Tape:
                 if normed:
                     self._norm_backward(src, dz, reduced=(part, nsp), finalised=False, dz_amax=dz_amax)
             else:
-                # parameter gradients (flat arena, overwritten every step)
-                # the weight gradient feeds nothing downstream in backward: run it on its own lane so the
-                # data-gradient chain never waits for it
-                cur = self.lane
-                wl = cur
-                if self.wgrad_lane is not None:
-                    # DSNT_WGRAD_LANE_ROWS > 0: only the large main-lane convolutions whose dY nobody writes again (no
-                    # residual inputs: the gradient buffer is not donated onwards) — their weight gradients then fill the
-                    # chip while the main lane walks the launch-bound low-resolution levels
-                    if self.wgrad_lane_rows == 0 or (cur in self.wgrad_lane_from and (self.wgrad_lane_res or (res1 is None and res2 is None)) and
-                                                     g.N * g.Ho * g.Wo >= self.wgrad_lane_rows):
-                        wl = self.wgrad_lane
-                hold = wl != cur and self._release_left > 0
-                if hold:
-                    listed, self.bwd = self.bwd, self._held
-                self.sync_bwd(cur, wl)
-                self.lane = wl
-                if wl != cur:
-                    # gy may be donated onwards and accumulated into by a later launch of another lane: that writer waits
-                    # for the weight-gradient lane first (grad_target)
-                    self._wgrad_lane_reads.add(gy.data_ptr())
-                nws = self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g))
-                # DSNT_WGRAD_SHARE_CHIP: one workgroup per CU beside the chain — except for the first convolution of the
-                # network (no data gradient: it is the LAST launch of backward and has the chip to itself)
-                share = 2 if (wl != cur and self.wgrad_share and need_input_grad) else 0
-                # DSNT_WGRAD_NARROW for the hourglass stacks' 3x3 weight gradients: the lane has slack there (the 1x1 weight
-                # gradients left it), the stem's bucket is the tail of backward and keeps the wider plan
-                if share and self.wgrad_narrow in ('1', {0: '2'}.get(bucket, '3')):
-                    share |= 4
-                w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
-                if self.defer_reduce:
-                    # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
-                    # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
-                    # (... nor shared with an activation whose gradient is accumulated into later: `share_grads`)
-                    # (a RAW operand — conv1 of a torchvision BasicBlock, resnet.py — rides with the identity prologue: scale 1, shift 0)
-                    groupable = (w6 and (normed or self.share_grads) and wl == cur and not y.grad_shared and
-                                 0 < g.N * g.Ho * g.Wo <= self.group_rows)
-                    # ... or, WITH residual inputs (conv3 of the low-resolution Bottlenecks): dL/dy is not donated to them but
-                    # handed over as the `base` their own gradient continues out of place, and so stays intact as well
-                    residuals = [r for r in (res1, res2) if r is not None]
-                    defer_res = bool(groupable and residuals and self.share_grads and self.defer_res and all(
-                        r._grad is None and r.base is None and r.pending_apply is None and r.pending_add is None
-                        for r in residuals))
-                    grouped = groupable and (not residuals or defer_res)
-                    # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
-                    w16 = w6 and self.use_f16x3 and (normed or x_amax is not None) and y.grad_amax is not None
-                    ab = (self.f16_bn_bound_bwd(src) if normed else x_amax) if w16 else None
-                    splits = self.lib.dsnt_conv_wgrad_splits(C.byref(g))
-                    if w16 and not grouped:
-                        # dsnt_conv_wgrad_f16x3 cuts the pixels of a 3x3 convolution into its own slabs (halo kernel)
-                        nws = self.lib.dsnt_conv_wgrad_f16x3_ws_floats(C.byref(g), share)
-                        splits = self.lib.dsnt_conv_wgrad_f16x3_splits(C.byref(g), share)
-                    ws = self.empty(nws)         # lives until the bucket's reduction
-                    self._ws_ptrs.add(ws.data_ptr())
-                    if grouped:
-                        desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
-                        gsc, gsh = (sc, sh) if normed else self.identity_bn(x.C)
-                        if w16:
-                            nblk = self.lib.dsnt_conv_wgrad_desc_f16x3(_lib.ptr(x.buf), _lib.ptr(gsc), _lib.ptr(gsh), relu,
-                                                                       _lib.ptr(gy), _lib.ptr(ws), _lib.ptr(ab),
-                                                                       _lib.ptr(y.grad_amax), C.byref(g), desc)
+                # the BatchNorm backward of the layer behind a 3x3 convolution, left pending by that layer's own backward
+                # (`fold_ok`), rides in this convolution's data gradient (csrc/conv3s.hip MODE 4): the launch forms dL/dy from
+                # (dz, y) while it stages its operand and writes it out for the weight gradient, which therefore comes SECOND
+                if fold3:
+                    gy = y._grad = self.empty(y.N, y.H, y.W, y.C)
+                    y.grad_amax, y.pending_apply = ap['bound'], None
+
+                def emit_wgrad():
+                    # parameter gradients (flat arena, overwritten every step)
+                    # the weight gradient feeds nothing downstream in backward: run it on its own lane so the
+                    # data-gradient chain never waits for it
+                    cur = self.lane
+                    wl = cur
+                    if self.wgrad_lane is not None:
+                        # DSNT_WGRAD_LANE_ROWS > 0: only the large main-lane convolutions whose dY nobody writes again (no
+                        # residual inputs: the gradient buffer is not donated onwards) — their weight gradients then fill the
+                        # chip while the main lane walks the launch-bound low-resolution levels
+                        if self.wgrad_lane_rows == 0 or (cur in self.wgrad_lane_from and (self.wgrad_lane_res or (res1 is None and res2 is None)) and
+                                                         g.N * g.Ho * g.Wo >= self.wgrad_lane_rows):
+                            wl = self.wgrad_lane
+                    hold = wl != cur and self._release_left > 0
+                    if hold:
+                        listed, self.bwd = self.bwd, self._held
+                    self.sync_bwd(cur, wl)
+                    self.lane = wl
+                    if wl != cur:
+                        # gy may be donated onwards and accumulated into by a later launch of another lane: that writer waits
+                        # for the weight-gradient lane first (grad_target)
+                        self._wgrad_lane_reads.add(gy.data_ptr())
+                    nws = self.lib.dsnt_conv_wgrad_ws_floats(C.byref(g))
+                    # DSNT_WGRAD_SHARE_CHIP: one workgroup per CU beside the chain — except for the first convolution of the
+                    # network (no data gradient: it is the LAST launch of backward and has the chip to itself)
+                    share = 2 if (wl != cur and self.wgrad_share and need_input_grad) else 0
+                    # DSNT_WGRAD_NARROW for the hourglass stacks' 3x3 weight gradients: the lane has slack there (the 1x1 weight
+                    # gradients left it), the stem's bucket is the tail of backward and keeps the wider plan
+                    if share and self.wgrad_narrow in ('1', {0: '2'}.get(bucket, '3')):
+                        share |= 4
+                    w6 = self.use_bf16x6 and bool(self.lib.dsnt_conv_wgrad_bf16x6_ok(C.byref(g)))
+                    if self.defer_reduce:
+                        # deferred to the bucket's grouped launch: x, gy and the BN vectors are written once per
+                        # step and gy is not donated onwards (no residual inputs), so they are intact at the flush
+                        # (... nor shared with an activation whose gradient is accumulated into later: `share_grads`)
+                        # (a RAW operand — conv1 of a torchvision BasicBlock, resnet.py — rides with the identity prologue: scale 1, shift 0)
+                        groupable = (w6 and (normed or self.share_grads) and wl == cur and not y.grad_shared and
+                                     0 < g.N * g.Ho * g.Wo <= self.group_rows)
+                        # ... or, WITH residual inputs (conv3 of the low-resolution Bottlenecks): dL/dy is not donated to them but
+                        # handed over as the `base` their own gradient continues out of place, and so stays intact as well
+                        residuals = [r for r in (res1, res2) if r is not None]
+                        defer_res = bool(groupable and residuals and self.share_grads and self.defer_res and all(
+                            r._grad is None and r.base is None and r.pending_apply is None and r.pending_add is None
+                            for r in residuals))
+                        grouped = groupable and (not residuals or defer_res)
+                        # fp16x3: both operand bounds exist (A: train-mode BN parameters, dY: one bn-backward apply wrote it)
+                        w16 = w6 and self.use_f16x3 and (normed or x_amax is not None) and y.grad_amax is not None
+                        ab = (self.f16_bn_bound_bwd(src) if normed else x_amax) if w16 else None
+                        splits = self.lib.dsnt_conv_wgrad_splits(C.byref(g))
+                        if w16 and not grouped:
+                            # dsnt_conv_wgrad_f16x3 cuts the pixels of a 3x3 convolution into its own slabs (halo kernel)
+                            nws = self.lib.dsnt_conv_wgrad_f16x3_ws_floats(C.byref(g), share)
+                            splits = self.lib.dsnt_conv_wgrad_f16x3_splits(C.byref(g), share)
+                        ws = self.empty(nws)         # lives until the bucket's reduction
+                        self._ws_ptrs.add(ws.data_ptr())
+                        if grouped:
+                            desc = C.create_string_buffer(self.lib.dsnt_conv_wgrad_desc_bytes())
+                            gsc, gsh = (sc, sh) if normed else self.identity_bn(x.C)
+                            if w16:
+                                nblk = self.lib.dsnt_conv_wgrad_desc_f16x3(_lib.ptr(x.buf), _lib.ptr(gsc), _lib.ptr(gsh), relu,
+                                                                           _lib.ptr(gy), _lib.ptr(ws), _lib.ptr(ab),
+                                                                           _lib.ptr(y.grad_amax), C.byref(g), desc)
+                            else:
+                                nblk = self.lib.dsnt_conv_wgrad_desc(_lib.ptr(x.buf), _lib.ptr(gsc), _lib.ptr(gsh), relu,
+                                                                     _lib.ptr(gy), _lib.ptr(ws), C.byref(g), desc)
+                            if nblk <= 0:
+                                raise RuntimeError('dsnt_conv_wgrad_desc failed: %s' % self.lib.dsnt_last_error().decode())
+                            self._pending_group.append((desc.raw, nblk))
+                            if w16:
+                                self._pending_group_uses.append(dict(kind='wgrad', name=name, x=x.buf, sc=sc if normed else None,
+                                                                     sh=sh if normed else None, relu=relu,
+                                                                     a_bound=ab, g=gy, g_bound=y.grad_amax))
+                        elif w16:
+                            e = self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, share, ab, y.grad_amax, g)
+                            self.f16_uses.append((e, dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
+                                                          g=gy, g_bound=y.grad_amax)))
                         else:
-                            nblk = self.lib.dsnt_conv_wgrad_desc(_lib.ptr(x.buf), _lib.ptr(gsc), _lib.ptr(gsh), relu,
-                                                                 _lib.ptr(gy), _lib.ptr(ws), C.byref(g), desc)
-                        if nblk <= 0:
-                            raise RuntimeError('dsnt_conv_wgrad_desc failed: %s' % self.lib.dsnt_last_error().decode())
-                        self._pending_group.append((desc.raw, nblk))
-                        if w16:
-                            self._pending_group_uses.append(dict(kind='wgrad', name=name, x=x.buf, sc=sc if normed else None,
-                                                                 sh=sh if normed else None, relu=relu,
-                                                                 a_bound=ab, g=gy, g_bound=y.grad_amax))
-                    elif w16:
-                        e = self.b('dsnt_conv_wgrad_f16x3', x.buf, sc, sh, relu, gy, ws, None, None, share, ab, y.grad_amax, g)
-                        self.f16_uses.append((e, dict(kind='wgrad', name=name, x=x.buf, sc=sc, sh=sh, relu=relu, a_bound=ab,
-                                                      g=gy, g_bound=y.grad_amax)))
+                            self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
+                                   None, None, share if w6 else 0, g)
+                        if p.post_reduce is not None:
+                            self._post_reduce.append(p.post_reduce)
+                        self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
+                                                     splits, p.Cout * g.R * g.S * g.Cin, p.Cout, 0])
                     else:
+                        ws = self.scratch('wgrad', nws)
                         self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
-                               None, None, share if w6 else 0, g)
-                    if p.post_reduce is not None:
-                        self._post_reduce.append(p.post_reduce)
-                    self._pending_reduce.append([ws.data_ptr(), p.gw.data_ptr(), p.gb.data_ptr() if p.gb is not None else 0,
-                                                 splits, p.Cout * g.R * g.S * g.Cin, p.Cout, 0])
+                               p.gw, p.gb, 0, g)
+                        if p.post_reduce is not None:      # the stem's space-to-depth gradient -> the parameter's 7x7 layout
+                            self.b(p.post_reduce[0], *p.post_reduce[1])
+                    self.lane = cur
+                    if hold:
+                        self.bwd = listed
+                    return wl, defer_res
+
+                def emit_dgrad():
+                    if not need_input_grad:
+                        return
+                    if True:
+                        nw = p.w.numel()
+                        pad_d = p.dil * (p.R - 1) - p.pad
+                        assert pad_d >= 0, 'data gradient needs pad <= dil * (R - 1)'
+                        native = p.stride != 1 and slot is not None and self.lib.dsnt_conv_dgrad_strided_ok(C.byref(g))
+                        if p.stride == 1:
+                            gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
+                        elif native:
+                            # strided convolution (ResNet stage transitions): dsnt_conv_dgrad_strided computes the pixels of dX
+                            # phase by phase straight from dY (csrc/dgrad_up.hip)
+                            gd = None
+                        else:
+                            # ... or, for the shapes that kernel refuses: the stride-1 data gradient of dY with stride-1
+                            # zeros stuffed between the pixels
+                            Hs = x.H + 2 * p.pad - p.dil * (p.R - 1)
+                            Ws = x.W + 2 * p.pad - p.dil * (p.S - 1)
+                            stuffed = self.scratch('stuffed', x.N * Hs * Ws * p.Cout).view(-1)[:x.N * Hs * Ws * p.Cout]
+                            self.b('dsnt_zero_insert', gy, stuffed, x.N, g.Ho, g.Wo, p.Cout, Hs, Ws, p.stride)
+                            gy_d = stuffed
+                            gd = ConvGeom(x.N, Hs, Ws, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
+                        if slot is not None:
+                            wd = self.dgrad_f32[slot:slot + nw]
+                            wq, wq_stride = self.dgrad_planes[slot:slot + nw], self.dgrad_total
+                            d6 = gd is not None and self._use6(gd)
+                        else:       # stand-alone use without a parameter arena
+                            wd = self.scratch('wdgrad', nw)
+                            self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
+                            d6 = self._use6(gd) and nw % 8 == 0
+                            if d6:
+                                wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
+                                self.b('dsnt_split_bf16x3', wd, wq, nw)
+
+                        gsrc = gy if (p.stride == 1 or native) else gy_d
+
+                        g_amax = y.grad_amax if (self.use_f16x3 and p.stride == 1) else None
+                        d16 = d6 and g_amax is not None and slot is not None and self.dgrad_planes16 is not None
+                        if d16:
+                            wq16 = self.dgrad_planes16[slot:slot + nw]
+                            wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
+                            # (the data gradient's filter is [Cin][3][3][Cout]: its "Cout" is this convolution's Cin)
+                            d_stream = self.stream_ok(p, gd, x.M, None)
+                            self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total] +
+                                                     ([p.Cin, p.Cout] if d_stream else [0, 0]))
+
+                        def dgrad(out, res, part=None, bnb=None, tail=None):
+                            if native:
+                                self.b('dsnt_conv_dgrad_strided', gy, wd, out, res, part, g, bnb, tail)
+                            elif d16:
+                                e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
+                                           self.dgrad_total, wbd, g_amax, None, out, None,
+                                           None, 2 if ((d_stream or p.R == 1) and self.lane != 0 and self.conv_share) else 0, res, None, part, gd, bnb, tail)
+                                self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
+                            elif d6:
+                                self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
+                                       part, gd, bnb, tail)
+                            else:
+                                self.b('dsnt_conv_fwd_ex', gsrc, wd, None, out, None, None, 0, res, None, part, gd, bnb, tail)
+                        if normed:
+                            # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
+                            # data-gradient epilogue; only finalise + apply remain as separate launches
+                            # (fold: the 1x1 convolution that produced x forms this BatchNorm's dx in its own backward — dz then has
+                            # to outlive this op's launches, and its maximum is what the bound of dx is made from)
+                            fold = not native and self.fold_ok(src)
+                            dz = self.empty(x.M * x.C) if fold else self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
+                            if native:
+                                tiles = self.lib.dsnt_conv_dgrad_strided_tiles(C.byref(g))
+                            else:
+                                bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
+                                tiles = (x.M + bm - 1) // bm
+                            part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
+                            bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
+                                                _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
+                            tl, dz_amax = None, None
+                            if fold:
+                                tl, dz_amax = BnTail(), self.amax_slot()
+                                tl.amax = dz_amax.data_ptr()
+                            if fold3:
+                                assert d16 and d_stream and not native
+                                n2 = ap['n']
+                                aps = BnBwdApply(_lib.ptr(y.buf), _lib.ptr(n2.scale), _lib.ptr(n2.mean), _lib.ptr(n2.invstd), _lib.ptr(ap['coef']))
+                                shr = 2 if (self.lane != 0 and self.conv_share) else 0
+                                e = self.b('dsnt_conv_dgrad_f16x3_stream_apply', ap['dz'], aps, gy, wq16, self.dgrad_total, wbd, ap['bound'],
+                                           dz, part, shr, gd, bnb, tl)
+                                nb = 4 * y.buf.numel()          # (the tensor named inside the struct)
+                                self.bytes_bwd += nb
+                                self.bytes_by_name['dsnt_conv_dgrad_f16x3_stream_apply'] = self.bytes_by_name.get('dsnt_conv_dgrad_f16x3_stream_apply', 0) + nb
+                                self.f16_uses.append((e, dict(kind='dgrad', name=name, w=wd, w_bound=wbd, g_bound=ap['bound'],
+                                                              g_apply=dict(dz=ap['dz'], y=y.buf, scale=n2.scale, mean=n2.mean,
+                                                                           invstd=n2.invstd, coef=ap['coef']))))
+                            else:
+                                dgrad(dz, None, part, bnb, tl)
+                            self._norm_backward(src, dz, reduced=(part, tiles), dz_amax=dz_amax)
+                        else:
+                            # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
+                            buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16, base_ok=True)
+                            base = self.take_base()         # (x's gradient continues one it does not own: the residual operand)
+                            tl = None
+                            if x.grad_amax is not None:
+                                tl = BnTail()
+                                tl.amax = x.grad_amax.data_ptr()
+                            dgrad(buf, base if base is not None else (buf if acc else None), tail=tl)
+
+                if fold3:
+                    emit_dgrad()
+                    wl, defer_res = emit_wgrad()
                 else:
-                    ws = self.scratch('wgrad', nws)
-                    self.b('dsnt_conv_wgrad_bf16x6' if w6 else 'dsnt_conv_wgrad', x.buf, sc, sh, relu, gy, ws,
-                           p.gw, p.gb, 0, g)
-                    if p.post_reduce is not None:      # the stem's space-to-depth gradient -> the parameter's 7x7 layout
-                        self.b(p.post_reduce[0], *p.post_reduce[1])
-                self.lane = cur
-                if hold:
-                    self.bwd = listed
-                if need_input_grad:
-                    nw = p.w.numel()
-                    pad_d = p.dil * (p.R - 1) - p.pad
-                    assert pad_d >= 0, 'data gradient needs pad <= dil * (R - 1)'
-                    native = p.stride != 1 and slot is not None and self.lib.dsnt_conv_dgrad_strided_ok(C.byref(g))
-                    if p.stride == 1:
-                        gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
-                    elif native:
-                        # strided convolution (ResNet stage transitions): dsnt_conv_dgrad_strided computes the pixels of dX
-                        # phase by phase straight from dY (csrc/dgrad_up.hip)
-                        gd = None
-                    else:
-                        # ... or, for the shapes that kernel refuses: the stride-1 data gradient of dY with stride-1
-                        # zeros stuffed between the pixels
-                        Hs = x.H + 2 * p.pad - p.dil * (p.R - 1)
-                        Ws = x.W + 2 * p.pad - p.dil * (p.S - 1)
-                        stuffed = self.scratch('stuffed', x.N * Hs * Ws * p.Cout).view(-1)[:x.N * Hs * Ws * p.Cout]
-                        self.b('dsnt_zero_insert', gy, stuffed, x.N, g.Ho, g.Wo, p.Cout, Hs, Ws, p.stride)
-                        gy_d = stuffed
-                        gd = ConvGeom(x.N, Hs, Ws, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
-                    if slot is not None:
-                        wd = self.dgrad_f32[slot:slot + nw]
-                        wq, wq_stride = self.dgrad_planes[slot:slot + nw], self.dgrad_total
-                        d6 = gd is not None and self._use6(gd)
-                    else:       # stand-alone use without a parameter arena
-                        wd = self.scratch('wdgrad', nw)
-                        self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
-                        d6 = self._use6(gd) and nw % 8 == 0
-                        if d6:
-                            wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
-                            self.b('dsnt_split_bf16x3', wd, wq, nw)
-
-                    gsrc = gy if (p.stride == 1 or native) else gy_d
-
-                    g_amax = y.grad_amax if (self.use_f16x3 and p.stride == 1) else None
-                    d16 = d6 and g_amax is not None and slot is not None and self.dgrad_planes16 is not None
-                    if d16:
-                        wq16 = self.dgrad_planes16[slot:slot + nw]
-                        wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
-                        # (the data gradient's filter is [Cin][3][3][Cout]: its "Cout" is this convolution's Cin)
-                        d_stream = self.stream_ok(p, gd, x.M, None)
-                        self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total] +
-                                                 ([p.Cin, p.Cout] if d_stream else [0, 0]))
-
-                    def dgrad(out, res, part=None, bnb=None, tail=None):
-                        if native:
-                            self.b('dsnt_conv_dgrad_strided', gy, wd, out, res, part, g, bnb, tail)
-                        elif d16:
-                            e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
-                                       self.dgrad_total, wbd, g_amax, None, out, None,
-                                       None, 2 if ((d_stream or p.R == 1) and self.lane != 0 and self.conv_share) else 0, res, None, part, gd, bnb, tail)
-                            self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
-                        elif d6:
-                            self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
-                                   part, gd, bnb, tail)
-                        else:
-                            self.b('dsnt_conv_fwd_ex', gsrc, wd, None, out, None, None, 0, res, None, part, gd, bnb, tail)
-                    if normed:
-                        # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
-                        # data-gradient epilogue; only finalise + apply remain as separate launches
-                        # (fold: the 1x1 convolution that produced x forms this BatchNorm's dx in its own backward — dz then has
-                        # to outlive this op's launches, and its maximum is what the bound of dx is made from)
-                        fold = not native and self.fold_ok(src)
-                        dz = self.empty(x.M * x.C) if fold else self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
-                        if native:
-                            tiles = self.lib.dsnt_conv_dgrad_strided_tiles(C.byref(g))
-                        else:
-                            bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
-                            tiles = (x.M + bm - 1) // bm
-                        part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
-                        bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
-                                            _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
-                        tl, dz_amax = None, None
-                        if fold:
-                            tl, dz_amax = BnTail(), self.amax_slot()
-                            tl.amax = dz_amax.data_ptr()
-                        dgrad(dz, None, part, bnb, tl)
-                        self._norm_backward(src, dz, reduced=(part, tiles), dz_amax=dz_amax)
-                    else:
-                        # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
-                        buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16, base_ok=True)
-                        base = self.take_base()         # (x's gradient continues one it does not own: the residual operand)
-                        tl = None
-                        if x.grad_amax is not None:
-                            tl = BnTail()
-                            tl.amax = x.grad_amax.data_ptr()
-                        dgrad(buf, base if base is not None else (buf if acc else None), tail=tl)
+                    wl, defer_res = emit_wgrad()
+                    emit_dgrad()
             # identity branches last: gy is dead after the launches above (the weight-gradient lane
             # must have read it before anyone accumulates into the donated buffer)
             if res1 is not None or res2 is not None:

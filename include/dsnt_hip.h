@@ -412,6 +412,23 @@ int dsnt_conv1x1_bwd_f16x3(const dsnt_bn_bwd_epilogue* xs, const float* dy, cons
                            const void* wd_planes, int64_t plane_stride, const float* w_bound, const float* a_bound,
                            const float* g_bound, float* dz_out, float* stats_partial, float* ws, float* dz_amax,
                            int flags, const dsnt_conv_geom* g, void* stream);
+/* Data gradient of a 3x3 / stride 1 / pad 1 convolution whose OUTPUT y feeds a train-mode BatchNorm (conv2 of a Bottleneck,
+ * /root/reference/src/dsnt/hourglass.py:36-40: bn3 behind conv2), with that BatchNorm's backward folded into the operand load
+ * (csrc/conv3s.hip MODE 4): replaces dsnt_bn_act_bwd_apply(dz, y, ...) -> dy followed by dsnt_conv_fwd_f16x3_stream(dy, ...).
+ *   dz      [N,H,W,C]  dL/d relu(bn(y)), ReLU-masked, its two BatchNorm sums already reduced into ap->coef = [c0 | c1]
+ *   ap      the BatchNorm behind the convolution: y, scale (= gamma invstd), mean, invstd, coef (struct below)
+ *   dy_out  [N,H,W,C]  receives dL/dy = scale (dz - c0 - (y - mean) invstd c1) (every pixel once); must not alias dz
+ *   a_bound a bound of |dL/dy| (dsnt_bn_bwd_finalize_bound); w_planes / plane_stride / w_bound: the data-gradient filter in
+ *           STREAM layout, as for dsnt_conv_fwd_f16x3_stream
+ *   dx_dz, stats_partial, bnb (required), tail: the launch's output — the gradient behind the BatchNorm IN FRONT of the
+ *           convolution, masked and with its two sums per 128-pixel patch — exactly as dsnt_conv_fwd_f16x3_stream with bnb
+ *   flags   DSNT_CONV_SHARE_CHIP or 0
+ * Needs dsnt_conv_fwd_stream_ok(g); DSNT_ERR_SHAPE otherwise.  dsnt_version() >= 112. */
+int dsnt_conv_dgrad_f16x3_stream_apply(const float* dz, const dsnt_bn_bwd_apply* ap, float* dy_out,
+                                       const void* w_planes, int64_t plane_stride, const float* w_bound,
+                                       const float* a_bound, float* dx_dz, float* stats_partial, int flags,
+                                       const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
+                                       const dsnt_out_bounds* tail, void* stream);
 
 /* ----------------------------------------------------- heat-map matching ("gauss" output strategy)
  * Rows = (image, joint) maps of h x w floats, target = normalised coordinates [rows][2].

@@ -853,6 +853,96 @@ def test_conv3_stream_kernel(case, mode):
         assert (st1[:, 1].double().sum(0) - (cols * cols).sum(0)).abs().max().item() <= 1e-4 * (cols * cols).sum(0).max().item()
 
 
+@pytest.mark.parametrize('case', [c for c in STREAM_CASES if c[3] in (64, 128)])
+@pytest.mark.parametrize('relu,big_mean', [(1, False), (0, False), (1, True)])
+def test_conv3_stream_data_gradient_with_the_batchnorm_backward_folded_in(case, relu, big_mean):
+    """dsnt_conv_dgrad_f16x3_stream_apply (csrc/conv3s.hip MODE 4: the BatchNorm backward of the layer BEHIND a 3x3 convolution
+    formed in the operand load of that convolution's data gradient; /root/reference/src/dsnt/hourglass.py:36-40) against the
+    two launches it replaces — dsnt_bn_act_bwd_apply, then dsnt_conv_fwd_f16x3_stream on its output:
+      * dy_out (every pixel exactly once, halo pixels never) equals the apply kernel's dy to fp32 rounding of the affine
+        form P dz + R y + S (its conditioning is a scale / shift BatchNorm's: eps |mean| / std — `big_mean` puts the
+        BatchNorm input at mean 20 std);
+      * the launch's own output (masked dz of the BatchNorm in front, its two sums per patch, max |dz|) equals the
+        two-launch path's to the same rounding carried through the convolution;
+      * DSNT_CONV_SHARE_CHIP changes no bit."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call, BnBwdEpilogue, BnBwdApply
+    N, H, W, Cin, Cout = case            # of the data-gradient launch: Cin = channels of dL/dy, Cout = channels of dL/dx
+    dev = torch.device('cuda:0')
+    tag = 's4' + '_'.join(map(str, case)) + str(relu) + str(big_mean)
+    g = _geom(N, H, W, Cin, Cout, 3, 3, 1, 1, 1)
+    M = N * H * W
+    w = synthetic.tensor(tag + 'w', (Cout, Cin, 3, 3), seed=1, scale=(2.0 / (Cin * 9)) ** 0.5)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    n = wd.numel()
+    strm = torch.empty(2 * n, dtype=torch.float16, device=dev)
+    wb = torch.zeros(64, device=dev)
+    table = torch.tensor([[wd.data_ptr(), strm.data_ptr(), wb.data_ptr(), n, n, Cout, Cin]], dtype=torch.int64).to(dev)
+    call('dsnt_f16_prep_weights', ptr(table), 1, 7)
+    # the BatchNorm behind the convolution: its input y, its vectors, the reduced coefficients; dz behind it (ReLU-masked)
+    mu = synthetic.tensor(tag + 'mu', (Cin,), seed=2, scale=20.0 if big_mean else 0.5).to(dev)
+    std = (synthetic.tensor(tag + 'sd', (Cin,), seed=3, kind='uniform').abs() + 0.5).to(dev)
+    yin = (_nhwc(synthetic.tensor(tag + 'y', (N, Cin, H, W), seed=4)).to(dev) * std + mu).contiguous()
+    dz = _nhwc(synthetic.tensor(tag + 'dz', (N, Cin, H, W), seed=5)).to(dev)
+    dz = (dz * (_nhwc(synthetic.tensor(tag + 'mk', (N, Cin, H, W), seed=6)).to(dev) > 0)).contiguous()
+    invstd = (1.0 / std).contiguous()
+    gamma = (synthetic.tensor(tag + 'ga', (Cin,), seed=7, kind='uniform') + 0.3).to(dev)
+    scale = (gamma * invstd).contiguous()
+    shift = torch.zeros(Cin, device=dev)
+    xhat = (yin.view(M, Cin) - mu) * invstd
+    coef = torch.cat([dz.view(M, Cin).mean(0), (dz.view(M, Cin) * xhat).mean(0)]).contiguous()
+    # the BatchNorm in front of the convolution (the epilogue)
+    xin = _nhwc(synthetic.tensor(tag + 'xin', (N, Cout, H, W), seed=8)).to(dev)
+    mean = synthetic.tensor(tag + 'm', (Cout,), seed=9, scale=0.2).to(dev)
+    istd = (synthetic.tensor(tag + 'i', (Cout,), seed=10, kind='uniform').abs() + 0.5).to(dev)
+    bsc = (synthetic.tensor(tag + 'bs', (Cout,), seed=11, kind='uniform') + 0.2).to(dev)
+    bsh = synthetic.tensor(tag + 'bh', (Cout,), seed=12, scale=0.3).to(dev)
+    bnb = BnBwdEpilogue(ptr(xin), ptr(bsc), ptr(bsh), ptr(mean), ptr(istd), relu)
+    tiles = M // 128
+    # reference: the apply launch, then the stream kernel on its output
+    dy = torch.full((N, H, W, Cin), float('nan'), device=dev)
+    call('dsnt_bn_act_bwd_apply', ptr(dz), ptr(yin), ptr(scale), ptr(shift), ptr(mu), ptr(invstd), ptr(coef), 0, ptr(dy), 0, M, Cin)
+    dy64 = (scale.double() * (dz.view(M, Cin).double() - coef[:Cin].double() -
+                              (yin.view(M, Cin).double() - mu.double()) * invstd.double() * coef[Cin:].double())).view(N, H, W, Cin)
+    ab = torch.zeros(64, device=dev)
+    ab[5] = float(dy64.abs().max()) * 2.5
+    outs = []
+    for fold, flags in ((False, 0), (True, 0), (True, 2)):
+        out = torch.full((N, H, W, Cout), float('nan'), device=dev)
+        stats = torch.full((tiles, 2, Cout), float('nan'), device=dev)
+        amax = torch.zeros(64, device=dev)
+        tail = _lib.BnTail()
+        tail.amax = amax.data_ptr()
+        dyo = torch.full((N, H, W, Cin), float('nan'), device=dev)
+        if fold:
+            ap = BnBwdApply(ptr(yin), ptr(scale), ptr(mu), ptr(invstd), ptr(coef))
+            call('dsnt_conv_dgrad_f16x3_stream_apply', ptr(dz), C.byref(ap), ptr(dyo), ptr(strm), n, ptr(wb), ptr(ab), ptr(out),
+                 ptr(stats), flags, C.byref(g), C.byref(bnb), C.byref(tail))
+        else:
+            call('dsnt_conv_fwd_f16x3_stream', ptr(dy), ptr(strm), n, ptr(wb), ptr(ab), None, ptr(out), None, None, 0, None, None,
+                 ptr(stats), C.byref(g), C.byref(bnb), C.byref(tail))
+        outs.append((out, stats, amax, dyo))
+    torch.cuda.synchronize()
+    (o0, s0, a0, _), (o1, s1, a1, d1), (o2, s2, a2, d2) = outs
+    assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(a1.max(), a2.max())      # the share flag changes no bit
+    assert not bool(torch.isnan(d1).any()) and not bool(torch.isnan(o1).any()) and not bool(torch.isnan(s1).any())
+    # dy_out against fp64, held to the apply kernel's own distance (x 4) plus the affine form's conditioning
+    sc_dy = float(dy64.abs().max())
+    e_ref, e_new = float((dy.double() - dy64).abs().max()), float((d1.double() - dy64).abs().max())
+    cond = float((mu.abs() * invstd).max())
+    assert e_new <= max(4 * e_ref, 2e-7 * (1 + cond) * sc_dy), (e_new, e_ref, cond)
+    # the convolution's output: same mask, values to the rounding of dy carried through 9 Cin products
+    so = float(o0.abs().max())
+    tol = (4e-7 * (1 + cond)) * so
+    assert (o0 - o1).abs().max().item() <= tol, ((o0 - o1).abs().max().item(), tol)
+    if relu:
+        assert float((o1 == 0).float().mean()) > 0.2 and float(((o0 == 0) != (o1 == 0)).float().mean()) <= 1e-5
+    assert abs(a0.max().item() - a1.max().item()) <= tol
+    for k in range(2):
+        b0, b1 = s0[:, k].double().sum(0), s1[:, k].double().sum(0)
+        assert (b0 - b1).abs().max().item() <= 4e-6 * (1 + cond) * max(1.0, s0[:, k].double().abs().sum(0).max().item())
+
+
 def test_share_chip_flag_of_the_streaming_1x1_kernel_changes_no_bit():
     """DSNT_CONV_SHARE_CHIP (bit 1 of in_relu) on dsnt_conv_fwd_f16x3_ex: the streaming 1x1 kernel (>= 65536 rows) starts half as
     many persistent workgroups; output, statistics partials and amax slot content are bit-identical."""
