@@ -28,6 +28,9 @@
 #include <stdlib.h>
 
 typedef unsigned c3_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef C3_ABL4
+#define C3_ABL4 0       /* ablation builds of MODE 4 (timing only, wrong results): 1 no dL/dy store, 2 no second-stream loads */
+#endif
 
 #define C3_HPX 204                          /* halo pixels of a 4 x 32 patch (6 x 34); an 8 x 16 patch needs 10 x 18 = 180 */
 #define C3_AP 48                            /* bytes per halo pixel and plane: 16 fp16 + 16 (conflict-free ds_read_b128) */
@@ -84,9 +87,11 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
 
     // ---- halo staging: item = tid + 256 j (< 816) -> halo pixel item >> 2, 4-channel quad item & 3
     const int kc = tid & 3;
-    unsigned aoffs[4], aok = 0;                 // aok bits 0-3: the halo pixel lies inside the image; bits 4-7 (APPLY): it is one of the patch's own
+    // aok bits 0-3: the halo pixel (item j) lies inside the image; bits 4-7 (APPLY): it is one of the patch's own.  `aok` belongs to
+    // the items being STORED, `aokn` to the tile whose offsets are in aoffs (they differ for a few iterations around a tile change)
+    unsigned aoffs[4], aok = 0, aokn = 0;
     auto set_tile = [&](const int vv) {         // global offsets of the tile with virtual index vv; returns its first pixel
-        aok = 0;
+        aokn = 0;
         int img = 0, th = 0, tw = 0;
         const bool live = vv < ntiles;
         if (live) {
@@ -103,16 +108,25 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
             const int ih = th * PH - 1 + hy, iw = tw * PW - 1 + hx;
             const bool in = live && px < HPX && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
             aoffs[j] = in ? (unsigned)(((img * p.H + ih) * p.W + iw) * p.Cin + kc * 4) * 4u : OOB;
-            aok |= (in ? 1u : 0u) << j;
-            if (APPLY) aok |= ((in && hy >= 1 && hy <= PH && hx >= 1 && hx <= PW) ? 16u : 0u) << j;
+            aokn |= (in ? 1u : 0u) << j;
+            if (APPLY) aokn |= ((in && hy >= 1 && hy <= PH && hx >= 1 && hx <= PW) ? 16u : 0u) << j;
         }
         return (img * p.H + th * PH) * p.W + tw * PW;
     };
-    // HALF (the two-stream mode): a chunk is staged in two halves (items j = 0, 1 and j = 2, 3) that follow one another through ONE
-    // register set — store a half, then issue the next half's loads — so that the second stream costs no registers: 2 items x 2
-    // streams = the 4 b128 registers of the one-stream schedule (which with both streams spilled: 256 VGPRs + 68 B of scratch)
-    constexpr bool HALF = APPLY;
-    c3_u32x4 ra[HALF ? 2 : 4], ra2[APPLY ? 2 : 1];
+    // Halo staging of the two-stream mode (MODE 4), ROLLING: a chunk is 4 items per thread (item j = halo pixel (tid >> 2) + 64 j,
+    // 4 channels); instead of fetching a whole chunk at once and storing it two iterations later, ONE item is fetched and ONE
+    // stored per iteration, each item LEAD iterations after its fetch, through a ring of NSLOT register sets (item j <-> set
+    // j % NSLOT): two streams, LEAD 2, two sets of two b128 registers — the 16 registers of the one-stream schedule (with both
+    // streams fetched a chunk at a time the kernel spilled: 256 VGPRs + 68 B of scratch).  For ONE stream the same pipeline
+    // (LEAD 4, C3_STAGE_ROLL=1) is 1.5 % SLOWER than the chunk-at-a-time schedule (64 x 64, batch 32: forward 107.2 vs 105.7 us,
+    // data gradient 113.0 vs 111.4 — same box, round 5): the fetches are not what the kernel waits for; what a stream costs is
+    // its instructions (a second stream: +9.5 us, the dL/dy stores: +8.6 us of 110; profiles/r05_conv3s_fold_ablation.txt).
+#ifndef C3_STAGE_ROLL
+#define C3_STAGE_ROLL 0
+#endif
+    constexpr bool ROLL = APPLY || C3_STAGE_ROLL;
+    constexpr int NSLOT = APPLY ? 2 : 4, LEAD = APPLY ? 2 : 4;
+    c3_u32x4 ra[NSLOT], ra2[APPLY ? NSLOT : 1];
     const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
     if (APPLY) {
         for (int k = tid; k < p.Cin; k += 256) {
@@ -131,57 +145,61 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
         }
         __syncthreads();
     }
-    // h: 0 / 1 = items j = 2 h, 2 h + 1 (HALF); otherwise all four
-    auto gloadA = [&](const int c, const int h = 0) {
-#pragma unroll
-        for (int j = 0; j < (HALF ? 2 : 4); ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, aoffs[HALF ? 2 * h + j : j], c * 64, 0);
-        if (APPLY) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) ra2[j] = __builtin_amdgcn_raw_buffer_load_b128(x2r, aoffs[2 * h + j], c * 64, 0);
-        }
+    auto load1 = [&](c3_u32x4& a, c3_u32x4& b, const int c, const int j) {
+        a = __builtin_amdgcn_raw_buffer_load_b128(xr, aoffs[j], c * 64, 0);
+        if (APPLY) b = (C3_ABL4 & 2) ? a : __builtin_amdgcn_raw_buffer_load_b128(x2r, aoffs[j], c * 64, 0);
     };
-    auto storeA = [&](const int buf, const int c, const int h = 0) {
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 sq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRO || APPLY) {
-            sc = *reinterpret_cast<const float4*>(SS + c * 16 + kc * 4);
-            sh = *reinterpret_cast<const float4*>(SS + p.Cin + c * 16 + kc * 4);
-        }
-        if (APPLY) sq = *reinterpret_cast<const float4*>(SS + 2 * p.Cin + c * 16 + kc * 4);
-#pragma unroll
-        for (int jj = 0; jj < (HALF ? 2 : 4); ++jj) {
-            const int j = HALF ? 2 * h + jj : jj;
-            if (tid + 256 * j >= ITEMS) continue;
-            float4 v = make_float4(__uint_as_float(ra[jj].x), __uint_as_float(ra[jj].y),
-                                   __uint_as_float(ra[jj].z), __uint_as_float(ra[jj].w));
-            if (PRO) {
-                // BN FMAs; ReLU + zero padding (applied after BN + ReLU) as one median per element
-                const bool ok = (aok >> j) & 1u;
-                const float lo = ok ? lo_valid : 0.f, hi = ok ? __builtin_inff() : 0.f;
-                v.x = __builtin_amdgcn_fmed3f(fmaf(v.x, sc.x, sh.x), lo, hi);
-                v.y = __builtin_amdgcn_fmed3f(fmaf(v.y, sc.y, sh.y), lo, hi);
-                v.z = __builtin_amdgcn_fmed3f(fmaf(v.z, sc.z, sh.z), lo, hi);
-                v.w = __builtin_amdgcn_fmed3f(fmaf(v.w, sc.w, sh.w), lo, hi);
-            } else if (APPLY) {
-                // dy = P dz + (R y + S); a pixel outside the image is zero padding of dy (both loads returned zeros: mask S)
-                const bool ok = (aok >> j) & 1u;
-                v.x = fmaf(v.x, sc.x, fmaf(__uint_as_float(ra2[jj].x), sh.x, ok ? sq.x : 0.f));
-                v.y = fmaf(v.y, sc.y, fmaf(__uint_as_float(ra2[jj].y), sh.y, ok ? sq.y : 0.f));
-                v.z = fmaf(v.z, sc.z, fmaf(__uint_as_float(ra2[jj].z), sh.z, ok ? sq.z : 0.f));
-                v.w = fmaf(v.w, sc.w, fmaf(__uint_as_float(ra2[jj].w), sh.w, ok ? sq.w : 0.f));
-                // (no branch: a pixel of the halo ring gets an out-of-range offset and the store is dropped)
+    // item j of chunk c: transform (BatchNorm + ReLU prologue / folded BatchNorm backward / operand scale), split, two 8-byte LDS
+    // stores; okb = the aok bits of the tile the item belongs to
+    auto store1 = [&](const c3_u32x4 a, const c3_u32x4 b, const int buf, const int c, const int j, const unsigned okb) {
+        if (tid + 256 * j >= ITEMS) return;
+        float4 v = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+        if (PRO) {
+            const float4 sc = *reinterpret_cast<const float4*>(SS + c * 16 + kc * 4);
+            const float4 sh = *reinterpret_cast<const float4*>(SS + p.Cin + c * 16 + kc * 4);
+            // BN FMAs; ReLU + zero padding (applied after BN + ReLU) as one median per element
+            const bool ok = (okb >> j) & 1u;
+            const float lo = ok ? lo_valid : 0.f, hi = ok ? __builtin_inff() : 0.f;
+            v.x = __builtin_amdgcn_fmed3f(fmaf(v.x, sc.x, sh.x), lo, hi);
+            v.y = __builtin_amdgcn_fmed3f(fmaf(v.y, sc.y, sh.y), lo, hi);
+            v.z = __builtin_amdgcn_fmed3f(fmaf(v.z, sc.z, sh.z), lo, hi);
+            v.w = __builtin_amdgcn_fmed3f(fmaf(v.w, sc.w, sh.w), lo, hi);
+        } else if (APPLY) {
+            const float4 sc = *reinterpret_cast<const float4*>(SS + c * 16 + kc * 4);
+            const float4 sh = *reinterpret_cast<const float4*>(SS + p.Cin + c * 16 + kc * 4);
+            const float4 sq = *reinterpret_cast<const float4*>(SS + 2 * p.Cin + c * 16 + kc * 4);
+            // dy = P dz + (R y + S); a pixel outside the image is zero padding of dy (both loads returned zeros: mask S)
+            const bool ok = (okb >> j) & 1u;
+            v.x = fmaf(v.x, sc.x, fmaf(__uint_as_float(b.x), sh.x, ok ? sq.x : 0.f));
+            v.y = fmaf(v.y, sc.y, fmaf(__uint_as_float(b.y), sh.y, ok ? sq.y : 0.f));
+            v.z = fmaf(v.z, sc.z, fmaf(__uint_as_float(b.z), sh.z, ok ? sq.z : 0.f));
+            v.w = fmaf(v.w, sc.w, fmaf(__uint_as_float(b.w), sh.w, ok ? sq.w : 0.f));
+            // (no branch: a pixel of the halo ring gets an out-of-range offset and the store is dropped.  The offsets of a tile
+            // are stable from its first fetch to its last store: set_tile comes after the last store of the previous tile's items)
+            if (!(C3_ABL4 & 1))
                 __builtin_amdgcn_raw_buffer_store_b128((c3_u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z),
-                                                                  __float_as_uint(v.w)}, dor, ((aok >> (4 + j)) & 1u) ? aoffs[j] : OOB, c * 64, 0);
-                v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
-            } else {
-                v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
-            }
-            uint2 q1, q2;
-            split4h(v, q1, q2);
-            unsigned char* dst = As + buf * C3_ABUF + ((tid >> 2) + 64 * j) * C3_AP + kc * 8;
-            *reinterpret_cast<uint2*>(dst) = q1;
-            *reinterpret_cast<uint2*>(dst + C3_APL) = q2;
+                                                                  __float_as_uint(v.w)}, dor, ((okb >> (4 + j)) & 1u) ? aoffs[j] : OOB, c * 64, 0);
+            v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
+        } else {
+            v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
         }
+        uint2 q1, q2;
+        split4h(v, q1, q2);
+        unsigned char* dst = As + buf * C3_ABUF + ((tid >> 2) + 64 * j) * C3_AP + kc * 8;
+        *reinterpret_cast<uint2*>(dst) = q1;
+        *reinterpret_cast<uint2*>(dst + C3_APL) = q2;
+    };
+    // the ring: item j lives in register set j % NSLOT
+    auto ld = [&](const int c, const int j) { load1(ra[j % NSLOT], ra2[APPLY ? j % NSLOT : 0], c, j); };
+    auto st = [&](const int buf, const int c, const int j) { store1(ra[j % NSLOT], ra2[APPLY ? j % NSLOT : 0], buf, c, j, aok); };
+    // the old schedule: a chunk at a time
+    auto gloadA = [&](const int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ld(c, j);
+    };
+    auto storeA = [&](const int buf, const int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st(buf, c, j);
     };
 
     // ---- weight stream: pair gp = K-steps 2 gp, 2 gp + 1 = 2 x [CO][16] fp16 per plane, contiguous
@@ -342,11 +360,20 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     // ---- prologue of the workgroup's FIRST tile
     int v = blockIdx.x;
     int m0 = set_tile(v), m0n = 0;
+    aok = aokn;
     gloadB();
-    if (HALF) {                                 // chunk 0 whole and the first half of chunk 1 (the loop's chain continues with its second)
-        gloadA(0, 0); storeA(0, 0, 0);
-        gloadA(0, 1); storeA(0, 0, 1);
-        gloadA(1, 0); storeA(1, 1, 0);
+    if (ROLL) {
+        // chunk 0 whole and item 0 of chunk 1 through temporaries (one round trip); the next items of chunk 1 stay in flight in
+        // the ring, as the loop's schedule expects them at it = 0
+        c3_u32x4 t[5], t2[APPLY ? 5 : 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load1(t[j], t2[APPLY ? j : 0], 0, j);
+        load1(t[4], t2[APPLY ? 4 : 0], 1, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store1(t[j], t2[APPLY ? j : 0], 0, 0, j, aok);
+        store1(t[4], t2[APPLY ? 4 : 0], 1, 1, 0, aok);
+        if (LEAD == 4) { ld(1, 1); ld(1, 2); ld(1, 3); }
+        else { ld(1, 1); ld(1, 2); }
     } else {
         gloadA(0);
         storeA(0, 0);
@@ -386,35 +413,39 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(C3_ABL & 4)) __syncthreads();                // the other slot / chunk buffer is written; this slot is read
-                // second half: the MFMAs of step 2 it + 1 carry the fragment reads of step 2 it + 2 and the halo staging: chunk
-                // c2 + 1 (buffer 1: read last at step 17 of the previous trip, next at step 9) is fetched at it = 0 and stored at
-                // it = 2; chunk c2 + 2 — or chunk 0 of the next tile — (buffer 0: read last at step 8) at it = 4 / it = 7.
-                // (Fetching four / five iterations ahead instead of two / three, the stores in the first half: 105 -> 108 us.)
+                // second half: the MFMAs of step 2 it + 1 carry the fragment reads of step 2 it + 2 and the halo staging.  (The chunk-at-a-time
+                // schedule of the one-stream modes: chunk c2 + 1 — buffer 1: read last at step 17 of the previous trip, next at step 9 — is
+                // fetched whole at it = 0 and stored at it = 2; chunk c2 + 2, or chunk 0 of the next tile — buffer 0: read last at
+                // step 8 — at it = 4 / it = 7.  Fetching WHOLE chunks four / five iterations ahead instead, the stores in the
+                // first half: 105 -> 108 us.)
                 if (!(C3_ABL & 8)) rd(F0, 2 * it + 2, bnxt);
                 if (!(C3_ABL & 2)) {
-                if (HALF) {
-                    // one register set, a chain of halves: buffer 1 (odd chunk; free from step 17 of the previous pair until
-                    // step 9) receives its halves at it = 8 of the previous pair and it = 2, buffer 0 (the next even chunk — or
-                    // chunk 0 of the next tile —; free after step 8) at it = 4 and it = 6; every half is fetched two iterations
-                    // before it is stored, right after the store that frees the registers
+                if (ROLL) {
+                    // buffer 1 (the odd chunk c2 + 1: read from step 9, last read at step 17 of the previous pair) takes its items at
+                    // it = 8 of the previous pair and it = 0, 1, 2; buffer 0 (the next even chunk, or chunk 0 of the next tile: last
+                    // read at step 8) at it = 4 .. 7; the store comes first, the fetch of a later item re-uses its registers
                     const bool last = c2 + 2 >= nchunks;
-                    if (it == 2) storeA(1, c2 + 1, 1);
-                    if (it == 4) storeA(0, last ? 0 : c2 + 2, 0);
-                    if (it == 6) storeA(0, last ? 0 : c2 + 2, 1);
-                    if (it == 8) storeA(1, last ? 1 : c2 + 3, 0);
-                    if (it == 0) gloadA(c2 + 1, 1);
-                    if (it == 2) {
-                        if (last) m0n = set_tile(v + (int)gridDim.x);           // from here on the offsets are the next tile's
-                        gloadA(last ? 0 : c2 + 2, 0);
+                    const int cn0 = last ? 0 : c2 + 2, cn1 = last ? 1 : c2 + 3;
+                    if (it <= 2) st(1, c2 + 1, it + 1);
+                    else if (it >= 4 && it <= 7) st(0, cn0, it - 4);
+                    else if (it == 8) st(1, cn1, 0);
+                    if (it == 3 && last) aok = aokn;                  // from it = 4 on the stored items are the next tile's
+                    if (LEAD == 4) {
+                        if (it == 0 && last) m0n = set_tile(v + (int)gridDim.x);
+                        if (it <= 3) ld(cn0, it);
+                        else if (it <= 7) ld(cn1, it - 4);
+                    } else {
+                        if (it == 0) ld(c2 + 1, 3);
+                        if (it == 2 && last) m0n = set_tile(v + (int)gridDim.x);
+                        if (it >= 2 && it <= 5) ld(cn0, it - 2);
+                        else if (it >= 6) ld(cn1, it - 6);
                     }
-                    if (it == 4) gloadA(last ? 0 : c2 + 2, 1);
-                    if (it == 6) gloadA(last ? 1 : c2 + 3, 0);
                 } else {
                 if (it == 0) gloadA(c2 + 1);
                 if (it == 2) storeA(1, c2 + 1);
                 if (it == 4) {
                     if (c2 + 2 < nchunks) gloadA(c2 + 2);
-                    else { m0n = set_tile(v + (int)gridDim.x); gloadA(0); }      // the next tile's first chunk
+                    else { m0n = set_tile(v + (int)gridDim.x); aok = aokn; gloadA(0); }      // the next tile's first chunk
                 }
                 if (it == 7) storeA(0, c2 + 2 < nchunks ? c2 + 2 : 0);
                 }
@@ -425,37 +456,34 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                if (HALF) {
-                    if (it == 2 || it == 4 || it == 6 || it == 8) {
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-                        }
+                if (ROLL) {
+                    // behind the remaining MFMAs of the step: the item's fetch, then its transform + split and the two LDS stores
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, APPLY ? 2 : 1, 0);
+                    if (it != 3) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, PRO || APPLY ? 16 : 10, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, PRO || APPLY ? 16 : 10, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                        if (APPLY) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
                     }
-                    if (it == 0 || it == 2 || it == 4 || it == 6) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        }
-                    }
-                } else if (it == 0 || it == 4) {
+                } else {
+                if (it == 0 || it == 4) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 }
-                if (!HALF && (it == 2 || it == 7)) {
+                if (it == 2 || it == 7) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
                         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
                     }
+                }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned tsw = bcur; bcur = bnxt; bnxt = tsw;
