@@ -1080,6 +1080,7 @@ class Tape:
                     y.grad_amax, y.pending_apply = ap['bound'], None
 
                 def emit_wgrad():
+                    defer_res = False
                     # parameter gradients (flat arena, overwritten every step)
                     # the weight gradient feeds nothing downstream in backward: run it on its own lane so the
                     # data-gradient chain never waits for it

@@ -1,24 +1,41 @@
 #!/bin/bash
-# Round-end evidence (run on the GPU box from the repo root): rocprofv3 kernel stats of bench.py and of the bare
-# train loop, PMC passes (one counter group per pass) of the dominant 3x3 kernel and of the weight gradient.
-# Output: gpurun_out/prof_*  (copy the summaries into profiles/).
+# Per-round evidence (GPU box, repo root): tools/collect_profiles.sh <tag> [base] [batch] [reg]      (base: hg1 | hg2 | hg8 | resnet34 ...)
+# kernel stats + overlap + one-step timeline of the bare train loop (tools/train_loop.py), then the HBM traffic of a step
+# from the TCC counters (two --pmc passes).  Output under gpurun_out/<tag>_* (copy the summaries into profiles/).
+tag=${1:-r05}; base=${2:-hg2}; batch=${3:-32}; reg=${4:-js}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-set -x
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
-cp $(ls gpurun_out/prof_bench/*/*kernel_stats.csv | head -1) gpurun_out/prof_bench_kernel_stats.csv
-cp $(ls gpurun_out/prof_bench/*/*kernel_trace.csv | head -1) gpurun_out/prof_bench_kernel_trace.csv
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python3 tools/train_loop.py 8 > gpurun_out/prof_train.log 2>&1
-cp $(ls gpurun_out/prof_train/*/*kernel_stats.csv | head -1) gpurun_out/prof_train_kernel_stats.csv
-python3 tools/trace_overlap.py $(ls gpurun_out/prof_train/*/*kernel_trace.csv | head -1) 7 > gpurun_out/prof_train_overlap.txt
-rm -rf gpurun_out/prof_bench gpurun_out/prof_train
-for which in fwd16 wgrad16 fwd6 wgrad6; do
-  kern=conv3x3; [ $which = wgrad6 -o $which = wgrad16 ] && kern=wgrad
-  for spec in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "hit:TCC_HIT_sum TCC_MISS_sum" "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "lds:SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "g:GRBM_GUI_ACTIVE"; do
-    name=${spec%%:*}; ctrs=${spec#*:}
-    bash tools/pmc.sh pmc_${which}_$name $kern "$ctrs" -- python3 tools/one_kernel.py $which || exit 1
-    rm -rf gpurun_out/pmc_${which}_$name
-  done
-  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$which -- python3 tools/one_kernel.py $which > /dev/null 2>&1
-  grep -E "$kern" $(ls gpurun_out/ks_$which/*/*kernel_stats.csv | head -1) | head -3
-  rm -rf gpurun_out/ks_$which
+if [ "$2" != "pmc" ]; then
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -- python3 tools/train_loop.py 8 $batch $base $reg > gpurun_out/${tag}_prof_train.log 2>&1 || exit 1
+cp $(ls gpurun_out/prof_train/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_train_kernel_stats.csv
+python3 tools/prof_summary.py gpurun_out/${tag}_train_kernel_stats.csv 10 40 > gpurun_out/${tag}_train_summary.txt
+python3 tools/trace_overlap.py $(ls gpurun_out/prof_train/*/*kernel_trace.csv | head -1) 7 > gpurun_out/${tag}_train_overlap.txt
+python3 tools/step_timeline.py $(ls gpurun_out/prof_train/*/*kernel_trace.csv | head -1) > gpurun_out/${tag}_step_timeline.txt
+rm -rf gpurun_out/prof_train
+tail -1 gpurun_out/${tag}_prof_train.log
+steps=6
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/st_$c -- python3 tools/train_loop.py $steps $batch $base $reg > gpurun_out/st_$c.log 2>&1 || exit 1
 done
+python3 tools/step_traffic.py $steps "$base + DSNT (reg $reg), batch $batch" > gpurun_out/${tag}_step_traffic.txt
+rm -rf gpurun_out/st_FETCH_SIZE gpurun_out/st_WRITE_SIZE
+head -12 gpurun_out/${tag}_step_traffic.txt
+fi
+
+# PMC evidence of the 1x1 kernels and the dominant one (tools/collect_profiles.sh <tag> pmc): SQ issue accounting and HBM
+# traffic (FETCH_SIZE / WRITE_SIZE / L2 hit rate, one counter group per pass) of
+#   bwd1 (256 -> 128 with the folded BatchNorm backward, 128 -> 256 given), fwd1 (256 -> 128; 128 -> 256 + residual) and conv3s (3x3 128->128 @64)
+if [ "$2" = "pmc" ]; then
+  for spec in "b1a:bwd1_kernel:bwd1a:64 256 128 1" "b1b:bwd1_kernel:bwd1:64 128 256 1" "f1a:fwd1_kernel:fwd1:64 256 128 1" "f1b:fwd1_kernel:fwd1:64 128 256 1" "s4f:stem4_fwd_kernel:stem4:0 0 0 0" "s4w:stem4_wgrad_kernel:stem4w:0 0 0 0" "c3s:conv3s:fwd16s:64 128 128 3"; do
+    IFS=':' read name kern mode geo <<< "$spec"
+    bash tools/pmc_sweep.sh ${tag}_$name $kern $mode $geo > /dev/null || exit 1
+    python3 tools/pmc_account.py gpurun_out/pmcs_${tag}_$name.txt "$kern ($mode $geo, batch 32)" > gpurun_out/${tag}_pmc_$name.txt
+    for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+      bash tools/pmc.sh ${tag}_t_$name $kern "$c" -- python3 tools/one_kernel.py $mode $geo | grep -v "^rc=" >> gpurun_out/${tag}_pmc_$name.txt
+      rm -rf gpurun_out/${tag}_t_$name gpurun_out/${tag}_t_$name.log
+    done
+    timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python3 tools/one_kernel.py $mode $geo > /dev/null 2>&1
+    grep -E "$kern" $(ls gpurun_out/ks/*/*kernel_stats.csv | head -1) | head -2 >> gpurun_out/${tag}_pmc_$name.txt
+    rm -rf gpurun_out/ks
+  done
+  cat gpurun_out/${tag}_pmc_*.txt
+fi

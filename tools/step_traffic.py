@@ -1,4 +1,4 @@
-"""Sum the TCC FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles_r04.sh per kernel name: HBM traffic of one train step.
+"""Sum the TCC FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh per kernel name: HBM traffic of one train step.
 usage: step_traffic.py <timed steps> <label>   (reads gpurun_out/st_FETCH_SIZE, gpurun_out/st_WRITE_SIZE)"""
 import csv, glob, collections, re, sys
 steps = int(sys.argv[1]) + 2          # train_loop.py runs two warm-up steps
