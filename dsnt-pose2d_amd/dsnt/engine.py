@@ -172,6 +172,10 @@ class Tape:
         # on the dependency chain each; 15 per hg2 step, 63 per hg8 step) joins its bucket's grouped launch too: its dL/dy is not
         # donated to the residual input but becomes the `base` that input's gradient continues out of place (Act.base)
         self.defer_res = self._x.get('defer_res', '1') != '0'
+        self.flush_points = self._x.get('flush_points', '1') != '0'       # `flush_point` (A/B)
+        # the per-step preparation in two halves: what the FORWARD reads (arena planes, weight planes, BatchNorm bounds) and what only
+        # the backward reads (re-packed + split data-gradient weights); the main lane waits for the first half only (A/B: prep_split=0)
+        self.prep_split = self._x.get('prep_split', '1') != '0'
         self.cur_bucket = 0         # parameter bucket of the layers being traced (mark_bucket)
         self._wgrad_lane_reads = set()
         self._writer_base = None
@@ -383,6 +387,7 @@ class Tape:
             t = torch.tensor(self._eval_bn_rows, dtype=torch.int64).to(self.device)
             self._keep.append(t)
             self.f('dsnt_bn_eval_prep', t, len(self._eval_bn_rows))
+        fwd_half = len(self.fwd)                # everything from here on is read by the backward list only
         if self._dgrad_pack is not None:
             self.f('dsnt_conv_pack_dgrad_all', *self._dgrad_pack)
         if self._f16_dw_rows:
@@ -395,13 +400,21 @@ class Tape:
             self.fwd.insert(0, self.fwd.pop())      # main lane, first: every producer comes after it
         self.lane = saved_lane
         prep, self.fwd = self.fwd, saved
+        # (the fill_zero entry was moved to the front: the boundary index moves with it)
+        fwd_half = fwd_half + 1 if self._famax_used else fwd_half
+        relay = None
+        if side and self.prep_split and self.n_lanes > 3 and 0 < fwd_half < len(prep):
+            # the backward-only half keeps running on the side lane while the forward proceeds: an idle lane takes the dependency
+            # on the FIRST half here (a list entry records and waits at one position), the main lane waits for that lane below
+            relay = self.n_lanes - 1
+            prep.insert(fwd_half, (None, (side, relay, torch.cuda.Event()), 'sync', 0))
         del self.fwd[pos:pos + len(head)]
         self.fwd[pos:pos] = prep
         if side and prep:
             first = next((i for i in range(pos + len(prep), len(self.fwd))
                           if self.fwd[i][0] is not None and self.fwd[i][2] in self._PREP_CONSUMERS
                           and id(self.fwd[i]) not in self._prep_exempt), len(self.fwd))
-            self.fwd.insert(first, (None, (side, 0, torch.cuda.Event()), 'sync', 0))
+            self.fwd.insert(first, (None, (side if relay is None else relay, 0, torch.cuda.Event()), 'sync', 0))
 
     def _use6(self, g):
         return (self.use_bf16x6 and g.N * g.Ho * g.Wo >= self.bf16x6_min_rows and
@@ -574,6 +587,20 @@ class Tape:
                 self.bwd.append((None, k, 'bucket', self.lane))
                 self.lane = lane
             self.on_backward(mark)
+
+    def flush_point(self):
+        """Forward position behind which (in backward: before which) the weight-gradient slabs written so far are reduced and the
+        grouped low-resolution weight gradients launched, without closing the parameter bucket.  A ResNet is ONE bucket: all of its
+        grouped weight gradients (every convolution of <= 8192 rows: 337 us at batch 8) and its one slab reduction (128 us) used to
+        run behind the last data gradient, with nothing beside them; flushed after every stage they run on the weight-gradient
+        lane beside the next stage's launch-bound chain.  (On the hourglass the same cut inside the stem's bucket gains nothing:
+        profiles/r05_ab_switches.txt box B.)"""
+        if self.record and self.defer_reduce and self.flush_points:
+            def flush():
+                lane, self.lane = self.lane, self._flush_lane()
+                self.flush_wgrad()
+                self.lane = lane
+            self.on_backward(flush)
 
     def _compile(self, lst):
         """Record `lst` into a C launch list: (handle, bucket ids after each segment)."""

@@ -131,6 +131,7 @@ def trace_fcn(fcn, hm_conv, t, x, P):
     x = t.bn_act(x, P.bn(bn1), relu=True, name='stem_act')
     x = t.maxpool3s2(x, name='pool')
     for layer in list(fcn)[4:]:
+        t.flush_point()         # backward: this stage's grouped weight gradients + slab sums run beside the stage before it
         for block in layer:
             x = block.trace(t, x, P)
     return t.conv(x, P.conv(hm_conv), name='hm')

@@ -44,7 +44,15 @@ def test_forward_list_preparation_runs_beside_the_stem(tape):
                     'dsnt_f16_prep_weights']
     # the main lane runs the stem (its own one-launch weight preparation, the space-to-depth image, the convolution, the
     # BatchNorm + ReLU with statistics) BEFORE it waits for the side lane's preparation
-    first_sync = next(i for i, e in enumerate(fwd) if e[2] == 'sync' and e[1][0] == 1 and e[1][1] == 0)
+    # (round 5: the main lane waits for the FORWARD half of the preparation only — relayed through the idle lane 3, which took the
+    # dependency right behind that half; the backward-only half, the re-packed / split data-gradient weights, stays on lane 1)
+    relay = next(i for i, e in enumerate(fwd) if e[2] == 'sync' and e[1][0] == 1 and e[1][1] == 3)
+    side_before = [e[2] for e in fwd[:relay] if e[3] == 1 and e[0] is not None]
+    side_after = [e[2] for e in fwd[relay:] if e[3] == 1 and e[0] is not None][:2]
+    assert side_before == ['dsnt_split_bf16x3', 'dsnt_f16_prep_weights', 'dsnt_f16_prep_bn_bounds']
+    assert side_after == ['dsnt_conv_pack_dgrad_all', 'dsnt_f16_prep_weights']
+    first_sync = next(i for i, e in enumerate(fwd) if e[2] == 'sync' and e[1][0] == 3 and e[1][1] == 0)
+    assert relay < first_sync
     before = [e[2] for e in fwd[:first_sync] if e[3] == 0 and e[0] is not None]
     # (the stem convolution itself: the halo kernel of csrc/stem4.hip, one statistics row per workgroup)
     assert before[:5] == ['dsnt_fill_zero', 'dsnt_s2d_input', 'dsnt_s2d_weights_prep', 'dsnt_stem4_fwd_f16x3', 'dsnt_bn_finalize']
