@@ -209,14 +209,25 @@ SURVEY_CONV_ELEMS = {'hg1': 36.95e6, 'hg2': 55.93e6, 'hg8': 169.87e6}
 
 def measured_step_traffic(workload, batch):
     """HBM bytes per step as the TCC counters saw them: copied from the committed rocprofv3 --pmc passes of the bare train loop
-    (tools/step_traffic.sh -> profiles/r04_step_traffic*.txt), never measured by this run; None for other workloads / batches."""
+    (tools/collect_profiles.sh -> profiles/r05_<workload>_b<batch>_step_traffic.txt; the latest round that has the file wins),
+    never measured by this run; None for workloads / batches without a committed file."""
+    import glob
     import re
-    name = {('hg2_js', 32): 'r04_step_traffic.txt', ('hg8_js', 16): 'r04_hg8_b16_step_traffic.txt'}.get((workload, batch))
-    path = os.path.join(ROOT, 'profiles', name) if name else None
-    if not path or not os.path.exists(path):
+    tag = {'hg2_js': 'hg2', 'hg8_js': 'hg8', 'hg1': 'hg1', 'resnet34': 'resnet34'}.get(workload)
+    if tag is None:
         return None
-    mt = re.search(r'=\s*([0-9.]+) GB per step', open(path).read())
-    return {'gbytes': float(mt.group(1)), 'source': 'profiles/%s (FETCH_SIZE x 2 + WRITE_SIZE over every kernel of a step)' % name} if mt else None
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s_b%d_step_traffic.txt' % (tag, batch))), reverse=True)
+    legacy = {('hg2_js', 32): 'r04_step_traffic.txt', ('hg8_js', 16): 'r04_hg8_b16_step_traffic.txt'}.get((workload, batch))
+    if legacy:
+        cands.append(os.path.join(ROOT, 'profiles', legacy))
+    for path in cands:
+        if os.path.exists(path):
+            mt = re.search(r'=\s*([0-9.]+) GB per step', open(path).read())
+            if mt:
+                name = os.path.basename(path)
+                return {'gbytes': float(mt.group(1)),
+                        'source': 'profiles/%s (FETCH_SIZE x 2 + WRITE_SIZE over every kernel of a step)' % name}
+    return None
 
 
 def family_rooflines(batch, iters=20):
