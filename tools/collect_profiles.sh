@@ -21,11 +21,13 @@ rm -rf gpurun_out/st_FETCH_SIZE gpurun_out/st_WRITE_SIZE
 head -12 gpurun_out/${tag}_step_traffic.txt
 fi
 
-# PMC evidence of the 1x1 kernels and the dominant one (tools/collect_profiles.sh <tag> pmc): SQ issue accounting and HBM
+# PMC evidence of the 1x1 kernels and the dominant one (tools/collect_profiles.sh <tag> pmc ["c3s c3d c3f wg3" = a subset]): SQ issue accounting and HBM
 # traffic (FETCH_SIZE / WRITE_SIZE / L2 hit rate, one counter group per pass) of
 #   bwd1 (256 -> 128 with the folded BatchNorm backward, 128 -> 256 given), fwd1 (256 -> 128; 128 -> 256 + residual) and conv3s (3x3 128->128 @64)
 if [ "$2" = "pmc" ]; then
-  for spec in "b1a:bwd1_kernel:bwd1a:64 256 128 1" "b1b:bwd1_kernel:bwd1:64 128 256 1" "f1a:fwd1_kernel:fwd1:64 256 128 1" "f1b:fwd1_kernel:fwd1:64 128 256 1" "s4f:stem4_fwd_kernel:stem4:0 0 0 0" "s4w:stem4_wgrad_kernel:stem4w:0 0 0 0" "c3s:conv3s:fwd16s:64 128 128 3"; do
+  specs=("b1a:bwd1_kernel:bwd1a:64 256 128 1" "b1b:bwd1_kernel:bwd1:64 128 256 1" "f1a:fwd1_kernel:fwd1:64 256 128 1" "f1b:fwd1_kernel:fwd1:64 128 256 1" "s4f:stem4_fwd_kernel:stem4:0 0 0 0" "s4w:stem4_wgrad_kernel:stem4w:0 0 0 0" "c3s:conv3s:fwd16s:64 128 128 3" "c3d:conv3s:dgrad16s:64 128 128 3" "c3f:conv3s:fold3:64 128 128 3" "wg3:wgrad3_kernel:wgrad16:64 128 128 3")
+  if [ -n "$3" ]; then specs=(); for n in $3; do for sp in "b1a:bwd1_kernel:bwd1a:64 256 128 1" "c3s:conv3s:fwd16s:64 128 128 3" "c3d:conv3s:dgrad16s:64 128 128 3" "c3f:conv3s:fold3:64 128 128 3" "wg3:wgrad3_kernel:wgrad16:64 128 128 3"; do [ "${sp%%:*}" = "$n" ] && specs+=("$sp"); done; done; fi
+  for spec in "${specs[@]}"; do
     IFS=':' read name kern mode geo <<< "$spec"
     bash tools/pmc_sweep.sh ${tag}_$name $kern $mode $geo > /dev/null || exit 1
     python3 tools/pmc_account.py gpurun_out/pmcs_${tag}_$name.txt "$kern ($mode $geo, batch 32)" > gpurun_out/${tag}_pmc_$name.txt

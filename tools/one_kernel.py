@@ -68,6 +68,21 @@ if which.startswith('bwd1'):
     nsp1 = _lib.fn('dsnt_conv1x1_bwd_splits')(C.byref(g), 0)
     ws1 = torch.empty(_lib.fn('dsnt_conv1x1_bwd_ws_floats')(C.byref(g), 0), device=dev)
     part1, dzx1 = torch.empty(nsp1, 2, Cin, device=dev), torch.empty(B, H, H, Cin, device=dev)
+if which in ('dgrad16s', 'fold3'):
+    # the 3x3 data gradient on the persistent kernel with the BatchNorm-backward epilogue (conv3s MODE 3), and with the backward of
+    # the BatchNorm BEHIND the convolution folded into its operand load (MODE 4, dsnt_conv_dgrad_f16x3_stream_apply)
+    from dsnt._lib import BnBwdEpilogue, BnBwdApply, BnTail
+    mu3, is3 = torch.randn(Cout, device=dev) * 0.1, torch.rand(Cout, device=dev) + 0.5
+    bnb3 = BnBwdEpilogue(ptr(x), ptr(sc), ptr(sh), ptr(mu3), ptr(is3), 1)
+    coef3 = torch.randn(2, Cin, device=dev) * 1e-3
+    ap3 = BnBwdApply(ptr(y), ptr(sc), ptr(mu3), ptr(is3), ptr(coef3))
+    y.normal_()
+    dyo3, out3 = torch.empty(B, H, H, Cin, device=dev), torch.empty(B, H, H, Cout, device=dev)
+    stats3 = torch.empty(M // 128, 2, Cout, device=dev)
+    gb3 = torch.full((64,), float(gy.abs().max()) * 4.0, device=dev)
+    amax3 = torch.zeros(64, device=dev)
+    tail3 = BnTail()
+    tail3.amax = amax3.data_ptr()
 reps = int(os.environ.get('ONE_KERNEL_REPS', '5'))
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
 for it in range(reps):
@@ -78,6 +93,12 @@ for it in range(reps):
         _lib.fn('dsnt_conv_fwd_f16x3_ex')(ptr(x), ptr(planes16), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None, None, st)
     elif which == 'fwd16s':
         _lib.fn('dsnt_conv_fwd_f16x3_stream')(ptr(x), ptr(planes16s), w.numel(), ptr(wb), ptr(ab), ptr(b), ptr(y), ptr(sc), ptr(sh), 1, None, None, ptr(stats), C.byref(g), None, None, st)
+    elif which == 'dgrad16s':
+        assert _lib.fn('dsnt_conv_fwd_f16x3_stream')(ptr(gy), ptr(planes16s), w.numel(), ptr(wb), ptr(gb3), None, ptr(out3), None, None, 0, None, None,
+                                                     ptr(stats3), C.byref(g), C.byref(bnb3), C.byref(tail3), st) == 0
+    elif which == 'fold3':
+        assert _lib.fn('dsnt_conv_dgrad_f16x3_stream_apply')(ptr(gy), C.byref(ap3), ptr(dyo3), ptr(planes16s), w.numel(), ptr(wb), ptr(gb3), ptr(out3),
+                                                             ptr(stats3), 0, C.byref(g), C.byref(bnb3), C.byref(tail3), st) == 0
     elif which == 'wgrad16':
         _lib.fn('dsnt_conv_wgrad_f16x3')(ptr(x), ptr(sc), ptr(sh), 1, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g), st)
     elif which == 'wgrad6':
