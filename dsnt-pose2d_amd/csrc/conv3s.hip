@@ -113,16 +113,18 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
         }
         return (img * p.H + th * PH) * p.W + tw * PW;
     };
-    // Halo staging of the two-stream mode (MODE 4), ROLLING: a chunk is 4 items per thread (item j = halo pixel (tid >> 2) + 64 j,
-    // 4 channels); instead of fetching a whole chunk at once and storing it two iterations later, ONE item is fetched and ONE
-    // stored per iteration, each item LEAD iterations after its fetch, through a ring of NSLOT register sets (item j <-> set
-    // j % NSLOT): two streams, LEAD 2, two sets of two b128 registers — the 16 registers of the one-stream schedule (with both
-    // streams fetched a chunk at a time the kernel spilled: 256 VGPRs + 68 B of scratch).  For ONE stream the same pipeline
-    // (LEAD 4, C3_STAGE_ROLL=1) is 1.5 % SLOWER than the chunk-at-a-time schedule (64 x 64, batch 32: forward 107.2 vs 105.7 us,
-    // data gradient 113.0 vs 111.4 — same box, round 5): the fetches are not what the kernel waits for; what a stream costs is
-    // its instructions (a second stream: +9.5 us, the dL/dy stores: +8.6 us of 110; profiles/r05_conv3s_fold_ablation.txt).
+    // Halo staging, ROLLING (round 5): a chunk is 4 items per thread (item j = halo pixel (tid >> 2) + 64 j, 4 channels); instead of
+    // fetching a whole chunk at once and storing it two iterations later, ONE item is fetched and ONE stored per iteration, each
+    // item LEAD iterations after its fetch, through a ring of NSLOT register sets (item j <-> set j % NSLOT).  One stream: LEAD 4,
+    // four sets — the 16 registers of the chunk-at-a-time schedule; two streams (MODE 4): LEAD 2, two sets of two (with both streams
+    // fetched a chunk at a time the kernel spilled: 256 VGPRs + 68 B of scratch).  What it buys is issue overlap, and only together
+    // with the branch-free `store1` below: an item's ~50 VALU instructions (transform + split) are spread over the 12 MFMAs of its
+    // step by the scheduling groups — with the divergent per-item guard of rounds 3-4 every item sat in a basic block of its own and
+    // ran as a clump with the matrix pipe idle (then rolling was 1.5 % SLOWER than chunk-at-a-time; without the branch it is
+    // 1 % faster at 64 x 64, 5 % at 32 x 32, and -0.10 ms per hg2 step: profiles/r05_ab_switches.txt box E).
+    // -DC3_STAGE_ROLL=0: the chunk-at-a-time schedule of the one-stream modes (A/B).
 #ifndef C3_STAGE_ROLL
-#define C3_STAGE_ROLL 0
+#define C3_STAGE_ROLL 1
 #endif
     constexpr bool ROLL = APPLY || C3_STAGE_ROLL;
     constexpr int NSLOT = APPLY ? 2 : 4, LEAD = APPLY ? 2 : 4;
@@ -152,7 +154,13 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     // item j of chunk c: transform (BatchNorm + ReLU prologue / folded BatchNorm backward / operand scale), split, two 8-byte LDS
     // stores; okb = the aok bits of the tile the item belongs to
     auto store1 = [&](const c3_u32x4 a, const c3_u32x4 b, const int buf, const int c, const int j, const unsigned okb) {
-        if (tid + 256 * j >= ITEMS) return;
+        // NO branch on the thread index in here: a divergent `if (tid + 256 j < ITEMS)` costs nothing by itself, but it ends the
+        // basic block, and the ~50 VALU instructions of an item then cannot be scheduled between the MFMAs of the step — they run
+        // as one clump with the matrix pipe idle on both waves of the SIMD (round 5: the ISA of rounds 3-4 had every item behind
+        // such a branch).  Whole items are decided at compile time; the threads beyond the end of the LAST, partial item run the
+        // same instructions on zeros (their loads were out of range) and park the result in the pad bytes of a pixel row.
+        if (256 * j >= ITEMS) return;                           // (compile time: j is a constant after unrolling)
+        const bool active = (256 * j + 255 < ITEMS) || (tid + 256 * j < ITEMS);
         float4 v = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
         if (PRO) {
             const float4 sc = *reinterpret_cast<const float4*>(SS + c * 16 + kc * 4);
@@ -185,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
         }
         uint2 q1, q2;
         split4h(v, q1, q2);
-        unsigned char* dst = As + buf * C3_ABUF + ((tid >> 2) + 64 * j) * C3_AP + kc * 8;
+        // (the pad: bytes 32 .. 47 of a pixel's 48, never read)
+        unsigned char* dst = As + buf * C3_ABUF + (active ? ((tid >> 2) + 64 * j) * C3_AP + kc * 8 : (tid >> 2) * C3_AP + 32 + (kc & 1) * 8);
         *reinterpret_cast<uint2*>(dst) = q1;
         *reinterpret_cast<uint2*>(dst + C3_APL) = q2;
     };
@@ -451,24 +460,35 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 }
                 }
                 mm(F1);
+                if (ROLL) {
+                    // every MFMA of the step carries a fragment read (the first eight) and a few of the item's ~50 VALU instructions
+                    // (transform + split: left in one clump they run with the matrix pipe idle on BOTH waves of the SIMD, which
+                    // reach this point together); the item's fetch and its two LDS stores behind the last MFMAs
+                    constexpr int VPG = APPLY ? 6 : (PRO ? 5 : 4);
+#pragma unroll
+                    for (int i = 0; i < 4 * TM; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (it != 3) __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, APPLY ? 2 : 1, 0);
+                    if (it != 3) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (APPLY) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                    }
+                } else {
 #pragma unroll
                 for (int i = 0; i < 4 * TM; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                if (ROLL) {
-                    // behind the remaining MFMAs of the step: the item's fetch, then its transform + split and the two LDS stores
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, APPLY ? 2 : 1, 0);
-                    if (it != 3) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, PRO || APPLY ? 16 : 10, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, PRO || APPLY ? 16 : 10, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-                        if (APPLY) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-                    }
-                } else {
                 if (it == 0 || it == 4) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {

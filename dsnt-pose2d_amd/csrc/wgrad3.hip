@@ -142,7 +142,9 @@ __device__ __forceinline__ void wg3_body(const Wg3P& p, unsigned char* smem, con
         for (int i = 0; i < NPASS; ++i) {
             uint2 q1, q2;
             xform(R.v[i], sc[i], sh[i], lo, hi, q1, q2);
-            if (act[i]) {
+            // (no branch on the thread index where every thread has a unit — W 64 and 32: a divergent `if` ends the basic block and the
+            // transform + split of a row can then not be scheduled between the MFMAs of the step it is staged in; conv3s.hip, round 5)
+            if (UNITS % NTH == 0 || act[i]) {
                 *reinterpret_cast<uint2*>(base + alds[i]) = q1;
                 *reinterpret_cast<uint2*>(base + alds[i] + PLSZ) = q2;
             }
