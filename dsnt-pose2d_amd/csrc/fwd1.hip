@@ -24,19 +24,13 @@ struct Fwd1P {
     const unsigned short* wq; long wq_stride;           // [Cout][KK] fp16 planes (the forward layout: OHWI with R = S = 1)
     const float* a_bound; const float* w_bound;
     const float* bias; const float* res; float* y; float* stats;
-    // RES == 2 (a data-gradient launch): the BatchNorm-backward epilogue — res = the BatchNorm input x at the output position
-    const float* bnb_scale; const float* bnb_shift; const float* bnb_mean; const float* bnb_invstd; int bnb_relu;
     OutBoundsP ob;
     int M, Cout, nstages, spw;
 };
 
 // KK = input channels (the contraction), CW = 16-column tiles per wave, NWV = waves per workgroup (16 CW NWV output columns per
-// workgroup; blockIdx.y = column chunk), PRO: BatchNorm(+ReLU) on the operand, RES: 1 = one residual addend; 2 (round 5) = the launch is
-// the DATA GRADIENT of a 1x1 convolution in front of which a BatchNorm(+ReLU) sits (hourglass.py:33-35 seen from behind): the epilogue
-// masks the result by the ReLU of bn(x) — x arrives through the residual path — and the statistics are the BatchNorm backward's two
-// sums (sum dz, sum dz xhat) instead of (sum y, sum y^2).  The 16 x 16 level's 1x1 data gradients (8192 rows at batch 32, 4096 at
-// batch 16: below the one-pass backward's threshold) ran on the tiled kernel at 45 us each, 14 per hg2 step, on the dependency chain.
-template <int KK, int CW, int NWV, bool PRO, int RES>
+// workgroup; blockIdx.y = column chunk), PRO: BatchNorm(+ReLU) on the operand, RES: one residual addend
+template <int KK, int CW, int NWV, bool PRO, bool RES>
 __global__ __launch_bounds__(64 * NWV, 2) void fwd1_kernel(Fwd1P p) {
     constexpr int CC = 16 * CW * NWV;
     constexpr int NTHR = 64 * NWV;
@@ -146,17 +140,14 @@ __global__ __launch_bounds__(64 * NWV, 2) void fwd1_kernel(Fwd1P p) {
     if (PRO) {
         for (int k = tid; k < KK; k += NTHR) { vec[k] = p.in_scale[k] * sa; vec[KK + k] = p.in_shift[k] * sa; }
     }
-    float cb[CW], asc[CW], ash[CW], bmu[CW], bis[CW];
+    float cb[CW], asc[CW], ash[CW];
 #pragma unroll
     for (int cw = 0; cw < CW; ++cw) {
         const int c = col0 + c0 + 16 * cw + lc;
         cb[cw] = p.bias ? p.bias[c] : 0.f;
         asc[cw] = p.ob.amax_bn ? p.ob.amax_scale[c] : 0.f;
         ash[cw] = p.ob.amax_bn ? p.ob.amax_shift[c] : 0.f;
-        bmu[cw] = 0.f; bis[cw] = 0.f;
-        if (RES == 2) { asc[cw] = p.bnb_scale[c]; ash[cw] = p.bnb_shift[c]; bmu[cw] = p.bnb_mean[c]; bis[cw] = p.bnb_invstd[c]; }
     }
-    const bool bnb_relu = RES == 2 && p.bnb_relu != 0;
     const float am2lo = p.ob.amax_relu ? 0.f : -__builtin_inff();
     __syncthreads();
     transform(0);
@@ -199,17 +190,6 @@ __global__ __launch_bounds__(64 * NWV, 2) void fwd1_kernel(Fwd1P p) {
             for (int cw = 0; cw < CW; ++cw) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (RES == 2) {
-                        // v = dL/d relu(bn(x)); xv = x: mask by the ReLU, accumulate the BatchNorm-backward sums (conv3s.hip MODE 3)
-                        const float xv = rv[rt][cw][r];
-                        float v = acc[cw][r] * osc;
-                        if (bnb_relu && fmaf(xv, asc[cw], ash[cw]) <= 0.f) v = 0.f;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, obase + (unsigned)(cw * 64), (unsigned)(r * ld * 4), 0);
-                        am = fmaxf(am, fabsf(v));
-                        s1a[cw] += v;
-                        s2a[cw] = fmaf(v, (xv - bmu[cw]) * bis[cw], s2a[cw]);
-                        continue;
-                    }
                     float v = acc[cw][r] * osc + cb[cw];
                     if (RES) v += rv[rt][cw][r];
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, obase + (unsigned)(cw * 64), (unsigned)(r * ld * 4), 0);
@@ -286,7 +266,7 @@ Fwd1Plan dsnt_fwd1_plan(const dsnt_conv_geom* g, bool share) {
     return pl;
 }
 
-template <int KK, int CW, int NWV, bool PRO, int RES>
+template <int KK, int CW, int NWV, bool PRO, bool RES>
 static void f1_launch_k(const Fwd1Plan& pl, const Fwd1P& p, hipStream_t st) {
     DSNT_SET_MAX_LDS((fwd1_kernel<KK, CW, NWV, PRO, RES>), pl.lds);
     DSNT_LAUNCH((fwd1_kernel<KK, CW, NWV, PRO, RES>), dim3(pl.nwg, pl.chunks), dim3(64 * NWV), pl.lds, st, p);
@@ -294,9 +274,8 @@ static void f1_launch_k(const Fwd1Plan& pl, const Fwd1P& p, hipStream_t st) {
 template <int KK, int CW, int NWV>
 static void f1_launch_cfg(const Fwd1Plan& pl, const Fwd1P& p, hipStream_t st) {
     const bool pro = p.in_scale != nullptr, res = p.res != nullptr;
-    if (p.bnb_scale) f1_launch_k<KK, CW, NWV, false, 2>(pl, p, st);
-    else if (pro) { if (res) f1_launch_k<KK, CW, NWV, true, 1>(pl, p, st); else f1_launch_k<KK, CW, NWV, true, 0>(pl, p, st); }
-    else { if (res) f1_launch_k<KK, CW, NWV, false, 1>(pl, p, st); else f1_launch_k<KK, CW, NWV, false, 0>(pl, p, st); }
+    if (pro) { if (res) f1_launch_k<KK, CW, NWV, true, true>(pl, p, st); else f1_launch_k<KK, CW, NWV, true, false>(pl, p, st); }
+    else { if (res) f1_launch_k<KK, CW, NWV, false, true>(pl, p, st); else f1_launch_k<KK, CW, NWV, false, false>(pl, p, st); }
 }
 
 extern "C" int dsnt_conv1x1_fwd_ok(const dsnt_conv_geom* g) { return dsnt_fwd1_plan(g, false).ok; }
@@ -304,39 +283,10 @@ extern "C" int dsnt_conv1x1_fwd_stats_rows(const dsnt_conv_geom* g, int in_relu_
     return dsnt_fwd1_plan(g, (in_relu_flags & DSNT_CONV_SHARE_CHIP) != 0).nwg;
 }
 
-static int f1_entry(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
-                    const float* a_bound, const float* bias, float* y, const float* in_scale,
-                    const float* in_shift, int in_relu, const float* res1, float* stats_partial,
-                    const dsnt_conv_geom* g, const dsnt_out_bounds* tail, void* stream, const dsnt_bn_bwd_epilogue* bnb);
-
 extern "C" int dsnt_conv1x1_fwd_f16x3(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
                                       const float* a_bound, const float* bias, float* y, const float* in_scale,
                                       const float* in_shift, int in_relu, const float* res1, float* stats_partial,
                                       const dsnt_conv_geom* g, const dsnt_out_bounds* tail, void* stream) {
-    return f1_entry(x, w_planes, plane_stride, w_bound, a_bound, bias, y, in_scale, in_shift, in_relu, res1, stats_partial, g, tail,
-                    stream, nullptr);
-}
-
-// The DATA GRADIENT of a 1x1 convolution y = conv(relu?(bn(x))) on the same streaming kernel: dz[m][c] = (sum_n dY[m][n] W[n][c]) masked
-// by the ReLU of bn(x) (bnb, required: x, scale, shift, mean, invstd, relu), stats_partial (required) = one row per workgroup of
-// (sum dz, sum dz xhat) for dsnt_bn_bwd_finalize (rows = dsnt_conv1x1_fwd_stats_rows(g, flags)).  g is the geometry of THIS launch:
-// Cin = channels of dY, Cout = channels of dz; wd_planes = the data-gradient filter [Cout][Cin] (dsnt_conv_pack_dgrad_all) as two
-// fp16 planes; g_bound / w_bound: device bounds of |dY| / |W|; tail->amax (optional) receives max |dz|.
-extern "C" int dsnt_conv1x1_dgrad_f16x3(const float* dy, const void* wd_planes, int64_t plane_stride, const float* w_bound,
-                                        const float* g_bound, float* dz, float* stats_partial, int flags,
-                                        const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_out_bounds* tail,
-                                        void* stream) {
-    DSNT_REQUIRE(bnb && bnb->x && bnb->scale && bnb->shift && bnb->mean && bnb->invstd && stats_partial, DSNT_ERR_ARG,
-                 "dsnt_conv1x1_dgrad_f16x3: needs the BatchNorm-backward epilogue (x, scale, shift, mean, invstd) and stats_partial");
-    DSNT_REQUIRE(!tail || !tail->amax_bn, DSNT_ERR_ARG, "dsnt_conv1x1_dgrad_f16x3: dsnt_out_bounds.amax_bn does not apply to a data gradient");
-    return f1_entry(dy, wd_planes, plane_stride, w_bound, g_bound, nullptr, dz, nullptr, nullptr, flags & DSNT_CONV_SHARE_CHIP, bnb->x,
-                    stats_partial, g, tail, stream, bnb);
-}
-
-static int f1_entry(const float* x, const void* w_planes, int64_t plane_stride, const float* w_bound,
-                    const float* a_bound, const float* bias, float* y, const float* in_scale,
-                    const float* in_shift, int in_relu, const float* res1, float* stats_partial,
-                    const dsnt_conv_geom* g, const dsnt_out_bounds* tail, void* stream, const dsnt_bn_bwd_epilogue* bnb) {
     DSNT_REQUIRE(x && w_planes && w_bound && a_bound && y && g, DSNT_ERR_ARG, "dsnt_conv1x1_fwd_f16x3: bad argument");
     DSNT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), DSNT_ERR_ARG,
                  "dsnt_conv1x1_fwd_f16x3: in_scale/in_shift must be given together");
@@ -351,9 +301,6 @@ static int f1_entry(const float* x, const void* w_planes, int64_t plane_stride, 
     p.x = x; p.in_scale = in_scale; p.in_shift = in_shift; p.in_relu = in_relu & 1;
     p.wq = (const unsigned short*)w_planes; p.wq_stride = plane_stride; p.a_bound = a_bound; p.w_bound = w_bound;
     p.bias = bias; p.res = res1; p.y = y; p.stats = stats_partial;
-    if (bnb) {
-        p.bnb_scale = bnb->scale; p.bnb_shift = bnb->shift; p.bnb_mean = bnb->mean; p.bnb_invstd = bnb->invstd; p.bnb_relu = bnb->relu;
-    }
     p.M = g->N * g->H * g->W; p.Cout = g->Cout; p.nstages = pl.nstages; p.spw = pl.spw;
     hipStream_t st = (hipStream_t)stream;
     switch (pl.cfg) {

@@ -110,7 +110,6 @@ SIGNATURES = {
     'dsnt_conv_wgrad_f16x3': [P, P, P, I, P, P, P, P, I, P, P, GP, P],
     'dsnt_conv1x1_fwd_f16x3': [P, P, L, P, P, P, P, P, P, I, P, P, GP, TP, P],
     'dsnt_conv1x1_bwd_f16x3': [BP, P, AP, P, L, P, P, P, P, P, P, P, I, GP, P],
-    'dsnt_conv1x1_dgrad_f16x3': [P, P, L, P, P, P, P, I, GP, BP, TP, P],
     'dsnt_conv_dgrad_f16x3_stream_apply': [P, AP, P, P, L, P, P, P, P, I, GP, BP, TP, P],
     'dsnt_wgrad_reduce_all': [P, I, I, P],
     'dsnt_conv_wgrad_group': [P, I, I, P],

@@ -153,9 +153,6 @@ class Tape:
         self.fwd1 = 'fwd1' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')      # ... and their forward (csrc/fwd1.hip)
         # round 5: the BatchNorm backward behind a 3x3 convolution folded into that convolution's data gradient (conv3s.hip MODE 4)
         self.fold3 = 'fold3' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
-        # round 5: the 1x1 data gradients below the one-pass backward's threshold (the 16 x 16 level) on the streaming 1x1 kernel with a
-        # BatchNorm-backward epilogue (dsnt_conv1x1_dgrad_f16x3) instead of the tiled kernel
-        self.dgrad1 = 'dgrad1' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
         self.fold3_rows = int(os.environ.get('DSNT_X_FOLD3_ROWS', '16384'))
         self.stem4 = 'stem4' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')    # the stem's forward (csrc/stem4.hip)
         self._f16_w_stream = {}
@@ -1251,16 +1248,8 @@ class Tape:
                             self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total] +
                                                      ([p.Cin, p.Cout] if d_stream else [0, 0]))
 
-                        # a 1x1 data gradient behind a BatchNorm on the streaming kernel (csrc/fwd1.hip, RES 2): one statistics row per workgroup
-                        d1 = bool(d16 and normed and p.R == 1 and p.S == 1 and not native and self.fwd1 and self.dgrad1 and
-                                  self.lib.dsnt_conv1x1_fwd_ok(C.byref(gd)))
-                        d1_shr = 2 if (d1 and self.lane != 0 and self.conv_share) else 0
-
                         def dgrad(out, res, part=None, bnb=None, tail=None):
-                            if d1 and bnb is not None and res is None:
-                                e = self.b('dsnt_conv1x1_dgrad_f16x3', gsrc, wq16, self.dgrad_total, wbd, g_amax, out, part, d1_shr, gd, bnb, tail)
-                                self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
-                            elif native:
+                            if native:
                                 self.b('dsnt_conv_dgrad_strided', gy, wd, out, res, part, g, bnb, tail)
                             elif d16:
                                 e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
@@ -1281,8 +1270,6 @@ class Tape:
                             dz = self.empty(x.M * x.C) if fold else self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
                             if native:
                                 tiles = self.lib.dsnt_conv_dgrad_strided_tiles(C.byref(g))
-                            elif d1:
-                                tiles = self.lib.dsnt_conv1x1_fwd_stats_rows(C.byref(gd), d1_shr)
                             else:
                                 bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
                                 tiles = (x.M + bm - 1) // bm

@@ -367,19 +367,6 @@ int dsnt_conv1x1_fwd_f16x3(const float* x, const void* w_planes, int64_t plane_s
                            const float* a_bound, const float* bias, float* y, const float* in_scale,
                            const float* in_shift, int in_relu, const float* res1, float* stats_partial,
                            const dsnt_conv_geom* g, const dsnt_out_bounds* tail, void* stream);
-/* The DATA GRADIENT of the same 1x1 convolutions (cuDNN backward-data of /root/reference/src/dsnt/hourglass.py:20,25 at the levels
- * below the one-pass backward's row threshold — the 16 x 16 hourglass level) on the same streaming kernel, with the BatchNorm-backward
- * epilogue of the BatchNorm in front of the convolution (hourglass.py:33-35 seen from behind):
- *   dz[m][c] = (sum_n dy[m][n] W[n][c]) * [bn(x) > 0],  stats_partial[row] = (sum dz, sum dz xhat), ONE row per workgroup:
- *   dsnt_conv1x1_fwd_stats_rows(g, flags) rows for dsnt_bn_bwd_finalize.
- * g = the geometry of THIS launch (Cin = channels of dy, Cout = channels of dz; dsnt_conv1x1_fwd_ok(g) must hold); wd_planes = the
- * data-gradient filter [Cout][Cin] (dsnt_conv_pack_dgrad_all) as two fp16 planes (dsnt_f16_prep_weights); g_bound / w_bound: device
- * bounds of |dy| / |W|; bnb and stats_partial are required; tail->amax (optional) receives max |dz|; flags: DSNT_CONV_SHARE_CHIP or 0.
- * dsnt_version() >= 113. */
-int dsnt_conv1x1_dgrad_f16x3(const float* dy, const void* wd_planes, int64_t plane_stride, const float* w_bound,
-                             const float* g_bound, float* dz, float* stats_partial, int flags,
-                             const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb, const dsnt_out_bounds* tail,
-                             void* stream);
 /* The stem (hourglass.py:157 `self.conv1`, 7x7 / stride 2 / pad 3 on the image) in its space-to-depth form: a 4x4 / stride 1 /
  * pad 1 convolution of the 16-channel image dsnt_s2d_input leaves ([N][H/2+1][W/2+1][16]), 64 output channels, fp16x3 — on a halo
  * kernel of its own (csrc/stem4.hip: the 7 x 35 input halo of a 4 x 32 output patch staged once for all 16 taps, weights in

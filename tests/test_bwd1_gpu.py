@@ -239,90 +239,6 @@ def test_conv1x1_forward_on_the_lds_staged_streaming_kernel(case, pro, res):
     assert ((stats3.double().sum(0) - stats.double().sum(0)).abs() <= 1e-5 * stats.double().abs().sum(0) + 1e-6).all()
 
 
-DGRAD1_CASES = [
-    # N, H, W, channels of dY, channels of dz
-    (32, 16, 16, 128, 256),    # conv1 (256 -> 128) of the 16 x 16 Bottlenecks at batch 32: 8192 rows
-    (32, 16, 16, 256, 128),    # conv3 (128 -> 256)
-    (16, 16, 16, 128, 128),    # batch 16: 4096 rows (hg8's per-GPU half)
-    (5, 64, 64, 128, 256),     # a ragged workgroup split
-]
-
-
-@pytest.mark.parametrize('case', DGRAD1_CASES)
-@pytest.mark.parametrize('relu', [1, 0])
-def test_conv1x1_data_gradient_on_the_streaming_kernel(case, relu):
-    """dsnt_conv1x1_dgrad_f16x3 (csrc/fwd1.hip RES 2: the data gradient of a 1x1 convolution behind a BatchNorm + ReLU,
-    hourglass.py:20,25,33-35, at the levels below the one-pass backward's threshold) against fp64 and against the tiled kernel it
-    replaces there (dsnt_conv_fwd_f16x3_ex with the same dsnt_bn_bwd_epilogue): dz with the identical ReLU mask, the two
-    BatchNorm-backward sums (one row per workgroup, summed), max |dz|; bit-reproducible; the share flag changes no value."""
-    from dsnt import _lib
-    from dsnt._lib import ptr, call, ConvGeom, BnTail, BnBwdEpilogue
-    N, H, W, Cg, Cz = case
-    dev = torch.device('cuda:0')
-    tag = 'd1' + '_'.join(map(str, case))
-    M = N * H * W
-    g = ConvGeom(N, H, W, Cg, H, W, Cz, 1, 1, 1, 0, 1)
-    assert _lib.fn('dsnt_conv1x1_fwd_ok')(C.byref(g))
-    dy = synthetic.tensor(tag + 'g', (M, Cg), seed=1) * 1e-3
-    wdg = synthetic.tensor(tag + 'w', (Cz, Cg), seed=2) * 0.05            # the data-gradient filter [channels of dz][channels of dY]
-    x = synthetic.tensor(tag + 'x', (M, Cz), seed=3)
-    sc = synthetic.tensor(tag + 's', (Cz,), seed=4, kind='uniform') + 0.2
-    sh = synthetic.tensor(tag + 'h', (Cz,), seed=4, scale=0.3)
-    mu = synthetic.tensor(tag + 'm', (Cz,), seed=5, scale=0.2)
-    istd = synthetic.tensor(tag + 'i', (Cz,), seed=5, kind='uniform').abs() + 0.5
-    ref = dy.double() @ wdg.double().t()
-    if relu:
-        ref = ref * ((x * sc + sh) > 0).double()          # (the kernels evaluate the mask in fp32: fmaf(x, scale, shift) > 0)
-    xhat = (x.double() - mu.double()) * istd.double()
-    dyd, wd, xd, scd, shd, mud, isd = (t.to(dev) for t in (dy, wdg, x, sc, sh, mu, istd))
-    wb, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
-    call('dsnt_amax', ptr(wd), wd.numel(), ptr(wb))
-    call('dsnt_amax', ptr(dyd), dyd.numel(), ptr(gb))
-    planes = torch.empty(2 * wd.numel(), dtype=torch.float16, device=dev)
-    call('dsnt_split_f16x2', ptr(wd), ptr(planes), wd.numel(), wd.numel(), ptr(wb))
-    bnb = BnBwdEpilogue(ptr(xd), ptr(scd), ptr(shd), ptr(mud), ptr(isd), relu)
-
-    def run(flags, streaming=True):
-        dz = torch.full((M, Cz), float('nan'), device=dev)
-        amax = torch.zeros(64, device=dev)
-        tl = BnTail()
-        tl.amax = amax.data_ptr()
-        if streaming:
-            rows = _lib.fn('dsnt_conv1x1_fwd_stats_rows')(C.byref(g), flags)
-            stats = torch.full((rows, 2, Cz), float('nan'), device=dev)
-            call('dsnt_conv1x1_dgrad_f16x3', ptr(dyd), ptr(planes), wd.numel(), ptr(wb), ptr(gb), ptr(dz), ptr(stats), flags,
-                 C.byref(g), C.byref(bnb), C.byref(tl))
-        else:
-            rows = (M + 127) // 128
-            stats = torch.full((rows, 2, Cz), float('nan'), device=dev)
-            call('dsnt_conv_fwd_f16x3_ex', ptr(dyd), ptr(planes), wd.numel(), ptr(wb), ptr(gb), None, ptr(dz), None, None, 0, None, None,
-                 ptr(stats), C.byref(g), C.byref(bnb), C.byref(tl))
-        torch.cuda.synchronize()
-        return dz, stats, amax, rows
-
-    dz, stats, amax, rows = run(0)
-    assert 0 < rows <= 512 and bool(torch.isfinite(dz).all()) and bool(torch.isfinite(stats).all())
-    scale = ref.abs().max().item()
-    assert (dz.cpu().double() - ref).abs().max().item() <= 2e-6 * scale
-    s = stats.cpu().double().sum(0)
-    assert ((s[0] - ref.sum(0)).abs() <= 1e-5 * ref.abs().sum(0) + 1e-9).all()
-    assert ((s[1] - (ref * xhat).sum(0)).abs() <= 1e-5 * (ref * xhat).abs().sum(0) + 1e-9).all()
-    assert float(amax.max()) == float(dz.abs().max())
-    if relu:
-        assert 0.2 < float((dz == 0).float().mean()) < 0.8
-    # the tiled kernel on the same operands: same mask, values and sums to fp32 rounding of another summation order
-    dz0, stats0, amax0, _ = run(0, streaming=False)
-    assert torch.equal(dz == 0, dz0 == 0)
-    assert (dz - dz0).abs().max().item() <= 2e-6 * scale
-    assert ((stats.double().sum(0) - stats0.double().sum(0)).abs() <= 1e-5 * stats0.double().abs().sum(0) + 1e-9).all()
-    assert abs(float(amax.max()) - float(amax0.max())) <= 2e-6 * scale
-    dz2, stats2, _, _ = run(0)
-    assert torch.equal(dz, dz2) and torch.equal(stats, stats2)
-    dz3, stats3, _, rows3 = run(2)
-    assert torch.equal(dz, dz3) and rows3 <= rows
-    assert ((stats3.double().sum(0) - stats.double().sum(0)).abs() <= 1e-5 * stats.double().abs().sum(0) + 1e-9).all()
-
-
 STEM_CASES = [
     # N, Ho (= Wo): the space-to-depth image is [N][Ho + 1][Wo + 1][16]
     (2, 128),      # the 256-pixel input of every BASELINE configuration: 256 tiles

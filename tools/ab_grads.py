@@ -14,7 +14,7 @@ sys.path[:0] = [os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'dsnt-pose2d_amd
 import torch  # noqa: E402
 import test_fallback_gpu as tf  # noqa: E402
 
-NAMED = {'default': (None, None), 'fold3': ('fold3', None), 'dgrad1': ('dgrad1', None), 'bwd_r4': ('bwd1+stem4w', None), 'fwd_r4': ('fwd1+stem4', None), 'off_r3': ('conv3s+gemm1+wgrad3+wgrad1', None), 'off_r4': ('bwd1+fwd1+stem4+stem4w', None),
+NAMED = {'default': (None, None), 'fold3': ('fold3', None), 'bwd_r4': ('bwd1+stem4w', None), 'fwd_r4': ('fwd1+stem4', None), 'off_r3': ('conv3s+gemm1+wgrad3+wgrad1', None), 'off_r4': ('bwd1+fwd1+stem4+stem4w', None),
          'copies': (None, 'share_grads=0,defer_res=0')}
 
 
