@@ -17,8 +17,12 @@
 //     regular schedule of the last chunk pair — a tile has no prologue; the epilogue works from the MFMA result layout
 //     (a register = 2 pixels x 32 consecutive channels = two 128-byte runs; no LDS transposition), residual loads
 //     software-pipelined over the wave's tiles (as gemm1.hip).
-// Same K order (16-channel chunk, tap) and MFMA order as conv3x3_bf16x6_kernel<.., F16>: the convolution sums are
-// bit-identical to that kernel's; the per-tile column statistics are summed in another order.
+// Same K order (16-channel chunk, tap) and MFMA order as conv3x3_bf16x6_kernel<.., F16>: the convolution sums of the 32x32x16
+// form are bit-identical to that kernel's; the per-tile column statistics are summed in another order.
+// Round 5: Cout 128 on 4 x 32 patches (every 3x3 of the hourglass) runs on v_mfma_f32_16x16x32_f16 instead (MF16, C3Geo below): the
+// chip holds a higher clock under the 4-pass MFMA (MI355X_MICROARCH "DVFS give-back"), an MFMA covers both K-steps of a pair, and the
+// LDS image needs no padding (60 KB per workgroup instead of 80).  Same products, same (chunk, tap) order of the pairs; inside a pair
+// the two steps are one 32-deep dot product, so the sums agree with the 32x32x16 form to fp32 rounding, not bit for bit.
 // Contract: conv_fwd_bf16x6_kernel<..., F16> minus the second residual (dsnt_conv3s_ok).
 // Measured (DESIGN.md "round 3", profiles/r03_pmc_issue_accounting.txt): 3x3 128->128 @64x64, batch 32: 129 -> 104 us on one box
 // (matrix pipe 53 %, 1.15 PFLOP/s of fp16 MFMA at the ~1.9 GHz this load holds), -0.42 ms per hg2 step.  Built on the same pieces,
@@ -28,6 +32,10 @@
 #include <stdlib.h>
 
 typedef unsigned c3_u32x4 __attribute__((ext_vector_type(4)));
+typedef float c3_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef C3_MF16_DEFAULT
+#define C3_MF16_DEFAULT 1
+#endif
 #ifndef C3_ABL4
 #define C3_ABL4 0       /* ablation builds of MODE 4 (timing only, wrong results): 1 no dL/dy store, 2 no second-stream loads */
 #endif
@@ -37,6 +45,20 @@ typedef unsigned c3_u32x4 __attribute__((ext_vector_type(4)));
 #define C3_APL (C3_HPX * C3_AP)
 #define C3_ABUF (2 * C3_APL)
 #define C3_BP 80                            /* bytes per weight row and plane of a slot: 2 x 16 fp16 + 16 */
+// LDS geometry (device and host).  MF16 — Cout 128 on 4 x 32 patches, the hourglass's 3x3 — runs on v_mfma_f32_16x16x32_f16: an MFMA
+// then spans BOTH K-steps of a pair, a lane's 8 k-values are one 16-byte half of a pixel's (weight row's) 16-channel K-step, and the
+// layouts keep the halves in planes of their own, 16 bytes per pixel / row, dense: the 16 lanes of a k-group read 16 consecutive
+// 16-byte slots and the four k-groups sit a multiple of 256 bytes apart -> every ds_read_b128 is conflict-free without padding
+//   halo chunk buffer  [plane hi|lo][half][208 px][16 B]      (13 KB against 19 KB)
+//   ring slot          [plane hi|lo][k-group 0..3][CO][16 B]  (16 KB against 20 KB; k-group = 2 (K-step of the pair) + half)
+template <int CO, int PW, bool MF> struct C3Geo {
+    static constexpr bool MF16 = MF;
+    static_assert(!MF || (CO == 128 && PW == 32), "MF16 shape");
+    static constexpr int SUBPL = 208 * 16;
+    static constexpr int APL = MF16 ? 2 * SUBPL : C3_APL, ABUF = 2 * APL;
+    static constexpr int BPL = MF16 ? 4 * CO * 16 : CO * C3_BP, BSLOT = 2 * BPL;
+    static constexpr int lds(const int mode) { return 2 * ABUF + 2 * BSLOT + (mode == 4 ? 1536 : 1024); }   // halo buffers, weight ring, BatchNorm vectors
+};
 
 // MODE: 0 no residual, 1 res1, 3 the BatchNorm-backward epilogue of a data-gradient launch (res1 = the BatchNorm input x),
 // 4 = 3 with the BatchNorm backward of the layer BEHIND folded into the operand load (round 5): the A operand is not dL/dy but
@@ -47,12 +69,14 @@ typedef unsigned c3_u32x4 __attribute__((ext_vector_type(4)));
 //     conditioning of a scale / shift BatchNorm forward (eps |mean| / std), like `fmaf(x, scale, shift)` everywhere else.
 // PW: the patch is 128 / PW rows of PW pixels — 4 x 32 (W % 32 == 0), or 8 x 16 for the 16-pixel-wide levels (a 32-pixel MFMA
 // tile then spans two patch rows: a few two-way LDS bank conflicts on the activation fragments, immaterial at that size)
-template <int CO, bool PRO, int MODE, int PW>
+template <int CO, bool PRO, int MODE, int PW, bool MF>
 __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     constexpr int WN = CO / 64, WM = 4 / WN, TM = 4 / WM, TN = 2;
     constexpr int PH = 128 / PW, HW = PW + 2, HPX = (PH + 2) * HW, ITEMS = HPX * 4;
     static_assert(HPX <= C3_HPX, "halo buffer");
-    constexpr int BPL = CO * C3_BP, BSLOT = 2 * BPL;
+    typedef C3Geo<CO, PW, MF> G;
+    constexpr bool MF16 = G::MF16;
+    constexpr int SUBPL = G::SUBPL, APL = G::APL, ABUF = G::ABUF, BPL = G::BPL, BSLOT = G::BSLOT;
     constexpr bool APPLY = MODE == 4, BNB = MODE >= 3;
     static_assert(!(APPLY && PRO), "the folded BatchNorm backward replaces the prologue");
     constexpr int NJB = CO / 32;                // 16-byte weight units per thread and K-step pair
@@ -60,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     const unsigned OOB = 0xF0000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char c3_smem[];
     unsigned char* As = c3_smem;                // [2 chunk buffers][2 planes][204 px][48]
-    unsigned char* Bs = c3_smem + 2 * C3_ABUF;  // [2 slots][2 planes][CO][80]
+    unsigned char* Bs = c3_smem + 2 * ABUF;     // [2 slots][2 planes][CO][80]
     float* SS = reinterpret_cast<float*>(Bs + 2 * BSLOT);          // PRO: [2][Cin] BN scale / shift x operand scale; APPLY: [3][Cin] P, R, S
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -126,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
 #ifndef C3_STAGE_ROLL
 #define C3_STAGE_ROLL 1
 #endif
-    constexpr bool ROLL = APPLY || C3_STAGE_ROLL;
+    constexpr bool ROLL = APPLY || MF16 || C3_STAGE_ROLL;
     constexpr int NSLOT = APPLY ? 2 : 4, LEAD = APPLY ? 2 : 4;
     c3_u32x4 ra[NSLOT], ra2[APPLY ? NSLOT : 1];
     const float lo_valid = p.in_relu ? 0.f : -__builtin_inff();
@@ -194,9 +218,12 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
         uint2 q1, q2;
         split4h(v, q1, q2);
         // (the pad: bytes 32 .. 47 of a pixel's 48, never read)
-        unsigned char* dst = As + buf * C3_ABUF + (active ? ((tid >> 2) + 64 * j) * C3_AP + kc * 8 : (tid >> 2) * C3_AP + 32 + (kc & 1) * 8);
+        // (MF16: pixels 204 .. 207 of a half-plane)
+        unsigned char* dst = As + buf * ABUF +
+            (MF16 ? (kc >> 1) * SUBPL + (active ? (tid >> 2) + 64 * j : 204 + ((tid >> 2) & 3)) * 16 + (kc & 1) * 8
+                  : (active ? ((tid >> 2) + 64 * j) * C3_AP + kc * 8 : (tid >> 2) * C3_AP + 32 + (kc & 1) * 8));
         *reinterpret_cast<uint2*>(dst) = q1;
-        *reinterpret_cast<uint2*>(dst + C3_APL) = q2;
+        *reinterpret_cast<uint2*>(dst + APL) = q2;
     };
     // the ring: item j lives in register set j % NSLOT
     auto ld = [&](const int c, const int j) { load1(ra[j % NSLOT], ra2[APPLY ? j % NSLOT : 0], c, j); };
@@ -217,19 +244,27 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     for (int j = 0; j < NJB; ++j) {
         const int u = tid + 256 * j, pl = u / UPP, uu = u % UPP;
         bvoff[j] = (unsigned)((size_t)pl * p.wq_stride * 2u) + (unsigned)uu * 16u;
-        blds[j] = (unsigned)(pl * BPL + ((uu >> 1) % CO) * C3_BP + (uu / (2 * CO)) * 32 + (uu & 1) * 16);
+        // (stream order of a pair and plane: [K-step][CO][2 halves of 16 bytes])
+        blds[j] = MF16 ? (unsigned)(pl * BPL + (2 * (uu / (2 * CO)) + (uu & 1)) * (CO * 16) + ((uu >> 1) % CO) * 16)
+                       : (unsigned)(pl * BPL + ((uu >> 1) % CO) * C3_BP + (uu / (2 * CO)) * 32 + (uu & 1) * 16);
     }
     c3_u32x4 rb[NJB];
     int gp = 0;                                 // the pair the NEXT gloadB fetches
+    // (MF16 — CO 128, four units per thread: unit j = plane j >> 1, K-step j & 1 of the pair, weight row tid >> 1, half tid & 1:
+    // ONE offset register each way, the rest compile-time / scalar)
+    const unsigned wplane = (unsigned)((size_t)p.wq_stride * 2u);
     auto gloadB = [&]() {
         const unsigned so = (unsigned)gp * (unsigned)(CO * 64);
 #pragma unroll
-        for (int j = 0; j < NJB; ++j) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[j], so, 0);
+        for (int j = 0; j < NJB; ++j)
+            rb[j] = MF16 ? __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[0] + (j & 1) * 4096, so + (j >> 1) * wplane, 0)
+                         : __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[j], so, 0);
         gp = gp + 1 == npairs ? 0 : gp + 1;
     };
     auto storeB = [&](const unsigned slot) {
 #pragma unroll
-        for (int j = 0; j < NJB; ++j) *reinterpret_cast<c3_u32x4*>(Bs + slot + blds[j]) = rb[j];
+        for (int j = 0; j < NJB; ++j)
+            *reinterpret_cast<c3_u32x4*>(Bs + (slot + blds[MF16 ? 0 : j]) + (MF16 ? (j >> 1) * BPL + (j & 1) * 4096 : 0)) = rb[j];
     };
 
     // ---- fragments
@@ -246,12 +281,12 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     // local K-step s of a chunk pair (0..17; 18 = step 0 of the next pair): chunk buffer (s / 9) & 1, tap s % 9
     auto rd = [&](Frag& F, const int s, const unsigned slot) {
         const int t = s % 9, buf = (s / 9) & 1;
-        const int toff = buf * C3_ABUF + ((t / 3) * HW + (t % 3)) * C3_AP;
+        const int toff = buf * ABUF + ((t / 3) * HW + (t % 3)) * C3_AP;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
-                F.a[a][pl] = *reinterpret_cast<const f16x8*>(As + aoff[a] + toff + pl * C3_APL);
+                F.a[a][pl] = *reinterpret_cast<const f16x8*>(As + aoff[a] + toff + pl * APL);
 #pragma unroll
             for (int b = 0; b < TN; ++b)
                 F.b[b][pl] = *reinterpret_cast<const f16x8*>(Bs + slot + boff[b] + pl * BPL + (s & 1) * 32);
@@ -268,13 +303,69 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[a][0], F.b[b][0], acc[a][b], 0, 0, 0);
             }
     };
+
+    // ---- MF16: the same wave tile (2 patch rows x 64 channels) as 4 x 4 blocks of 16 pixels x 16 channels.  Fragment sets of
+    // 2 blocks x 2 planes: X / W = the activation rows of block rows 0-1 / 2-3, Y / Z = the weight rows of block columns 0-1 / 2-3.
+    // A lane's k-groups 0-1 belong to K-step 2 it (tap, chunk buffer of that step), 2-3 to step 2 it + 1: a per-lane select
+    // between two constants.  Quarter order X Y, X Z | barrier | W Y, W Z: each set is read once per pair (16 reads, as before),
+    // Z and W (this pair) in the first half, X and Y of the NEXT pair in the second — X is dead after the first half, Y after the
+    // third quarter — so all reads of pair it fall between the barriers of it - 1 and it, the epoch the ring and the staging
+    // schedule already keep that pair's slot and chunk buffers stable for
+    typedef f16x8 FSet[2][2];
+    FSet X, Y, Z, W;
+    c3_f32x4 acc16[MF16 ? 4 : 1][MF16 ? 4 : 1];
+    // (one address register per operand: block r of the wave tile is a compile-time offset away)
+    const bool khi = (lane & 32) != 0;
+    const unsigned a16base = (unsigned)(((wm * TM * HW + (lane & 15)) * 16) + ((lane >> 4) & 1) * SUBPL);
+    const unsigned b16base = (unsigned)((lane >> 4) * (CO * 16) + (wn * 64 + (lane & 15)) * 16);
+    auto a16off = [&](const int r) { return ((r >> 1) * HW + 16 * (r & 1)) * 16; };
+    auto b16off = [&](const int r) { return r * 256; };
+    auto ldA = [&](FSet& S, const int rbp, const int s0) {
+        const int t0 = s0 % 9, t1 = (s0 + 1) % 9;
+        const unsigned c0 = (unsigned)(((s0 / 9) & 1) * ABUF + ((t0 / 3) * HW + t0 % 3) * 16);
+        const unsigned c1 = (unsigned)((((s0 + 1) / 9) & 1) * ABUF + ((t1 / 3) * HW + t1 % 3) * 16);
+        const unsigned char* src = As + (a16base + (khi ? c1 : c0));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) S[i][pl] = *reinterpret_cast<const f16x8*>(src + (a16off(2 * rbp + i) + pl * APL));
+    };
+    auto ldB = [&](FSet& S, const int cbp, const unsigned slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) S[i][pl] = *reinterpret_cast<const f16x8*>(Bs + (slot + b16base) + (b16off(2 * cbp + i) + pl * BPL));
+    };
+    auto mmq = [&](const FSet& A, const FSet& B, const int rbp, const int cbp) {
+        // (term-major: the three MFMAs of a block are four MFMAs apart — a dependent 4-pass MFMA issued back to back waits for the
+        // result of the one before; each block still sums lo x hi, hi x lo, hi x hi in this order)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    c3_f32x4& c = acc16[MF16 ? 2 * rbp + i : 0][MF16 ? 2 * cbp + j : 0];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[i][t == 0], B[j][t == 1], c, 0, 0, 0);
+                }
+    };
+    // result element e (0..15) of the 32-pixel x 32-channel block (a, b) of the wave tile, for the epilogue
+    auto accv = [&](const int a, const int b, const int e) {
+        if constexpr (MF16) return acc16[2 * a + (e >> 3)][2 * b + ((e >> 2) & 1)][e & 3];
+        else return acc[a][b][e];
+    };
+    auto accz = [&](const int a, const int b, const int e) {
+        if constexpr (MF16) acc16[2 * a + (e >> 3)][2 * b + ((e >> 2) & 1)][e & 3] = 0.f;
+        else acc[a][b][e] = 0.f;
+    };
+
     auto zero = [&]() {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+                for (int e = 0; e < 16; ++e) accz(a, b, e);
     };
 
     const float am2lo = p.tail.amax_relu ? 0.f : -__builtin_inff();
@@ -283,15 +374,21 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     auto epilogue = [&](float* red, const int m0) {
         // ---- epilogue from the C layout: register e of a 32 x 32 tile = pixels (e&3) + 8 (e>>2) + 4 lh of patch row
         // wm TM + a, channel lr of column tile wn TN + b.  `bnxt` (the slot just consumed) is free: statistics scratch.
+        // MF16: the 32 x 32 block is four 16 x 16 results (a lane: 16 channels lane & 15 of pixels 4 (lane >> 4) + r — a store
+        // would write four 64-byte runs, and two instructions share every 128-byte line).  v_permlane16_swap of the two column
+        // blocks' registers (odd 16-lane rows of one <-> even rows of the other) turns them into the 32 x 32 shape: element e =
+        // pixel 16 (e>>3) + 4 ((e>>2)&1) + (e&3) + 8 lh, channel lr — two full lines per store, one channel column per lane.
         {
-            constexpr int T = TM * TN, NR = 16;
+            constexpr int T = TM * TN, NR = 16, NC = 1;
+            const int lc = lr, lq = lh;
             float rbuf[2][NR];
             auto tile_off = [&](const int i) {       // i = b * TM + a
                 const int a = i % TM, b = i / TM;
-                return (unsigned)((m0 + (wm * TM + a) * (PW == 32 ? 1 : 2) * p.W + 4 * lh) * p.Cout + (wn * TN + b) * 32 + lr) * 4u;
+                return (unsigned)((m0 + (wm * TM + a) * (PW == 32 ? 1 : 2) * p.W + (MF16 ? 8 : 4) * lq) * p.Cout + (wn * TN + b) * 32 + lc) * 4u;
             };
             // register e -> pixel (e&3) + 8 (e>>2) + 4 lh of the 32-pixel tile; PW 16: pixels 16.. are the next patch row
             auto reg_off = [&](const int e) {
+                if (MF16) return (unsigned)((e & 3) + 4 * ((e >> 2) & 1) + 16 * (e >> 3)) * rowbytes;
                 return PW == 32 ? (unsigned)((e & 3) + 8 * (e >> 2)) * rowbytes
                                 : (unsigned)((e >> 3) * p.W + (e & 3) + 8 * ((e >> 2) & 1)) * rowbytes;
             };
@@ -305,8 +402,8 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 }
             };
             struct Col { float cb, sc, sh, mu, is; };
-            auto loadcol = [&](const int b) {
-                const int n = (wn * TN + b) * 32 + lr;
+            auto loadcol = [&](const int b, const int h) {
+                const int n = (wn * TN + b) * 32 + 16 * h + lc;
                 Col c = {0.f, 0.f, 0.f, 0.f, 0.f};
                 if (BNB) { c.sc = p.bnb_scale[n]; c.sh = p.bnb_shift[n]; c.mu = p.bnb_mean[n]; c.is = p.bnb_invstd[n]; }
                 else {
@@ -315,30 +412,48 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 }
                 return c;
             };
-            Col col = loadcol(0), coln = col;
+            Col cols[NC], colsn[NC];
+#pragma unroll
+            for (int h = 0; h < NC; ++h) { cols[h] = loadcol(0, h); colsn[h] = cols[h]; }
             loadres(rbuf[0], 0);
-            float s1 = 0.f, s2 = 0.f;
+            float s1[NC], s2[NC];
+#pragma unroll
+            for (int h = 0; h < NC; ++h) { s1[h] = 0.f; s2[h] = 0.f; }
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 const int a = i % TM, b = i / TM;
                 if (i + 1 < T) {
                     loadres(rbuf[(i + 1) & 1], i + 1);
-                    if ((i + 1) % TM == 0) coln = loadcol((i + 1) / TM);
+                    if ((i + 1) % TM == 0) {
+#pragma unroll
+                        for (int h = 0; h < NC; ++h) colsn[h] = loadcol((i + 1) / TM, h);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MF16) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        c3_f32x4& c0 = acc16[2 * a + (q >> 2)][2 * b], & c1 = acc16[2 * a + (q >> 2)][2 * b + 1];
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0[q & 3]), __float_as_uint(c1[q & 3]), false, false);
+                        c0[q & 3] = __uint_as_float(sw[0]);
+                        c1[q & 3] = __uint_as_float(sw[1]);
+                    }
+                }
                 const float (&r)[NR] = rbuf[i & 1];
                 const unsigned o0 = tile_off(i);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const unsigned so = reg_off(e);
-                    float val = acc[a][b][e] * osc;
+                    const int h = 0;
+                    const Col& col = cols[h];
+                    float val = accv(a, b, e) * osc;
                     if (BNB) {
                         // val = dL/d relu(bn(x)); r = x: mask by the ReLU, accumulate the BatchNorm-backward sums
                         const float xv = r[e];
                         if (p.bnb_relu && fmaf(xv, col.sc, col.sh) <= 0.f) val = 0.f;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), yr, o0, so, 0);
-                        s1 += val;
-                        s2 = fmaf(val, (xv - col.mu) * col.is, s2);
+                        s1[h] += val;
+                        s2[h] = fmaf(val, (xv - col.mu) * col.is, s2[h]);
                         am = fmaxf(am, fabsf(val));          // max |dz| (p.tail.amax: the bound of a folded BatchNorm backward)
                     } else {
                         val += col.cb;
@@ -346,22 +461,25 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), yr, o0, so, 0);
                         am = fmaxf(am, fabsf(val));
                         if (p.tail.amax_bn) am2 = fmaxf(am2, fabsf(fmaxf(fmaf(val, col.sc, col.sh), am2lo)));
-                        s1 += val;
-                        s2 = fmaf(val, val, s2);
+                        s1[h] += val;
+                        s2[h] = fmaf(val, val, s2[h]);
                     }
-                    acc[a][b][e] = 0.f;
+                    accz(a, b, e);
                 }
                 if (a == TM - 1) {
-                    if (p.stats) {
-                        s1 += __shfl_xor(s1, 32, 64);
-                        s2 += __shfl_xor(s2, 32, 64);
-                        if (lh == 0) {
-                            red[(wm * CO + (wn * TN + b) * 32 + lr) * 2 + 0] = s1;
-                            red[(wm * CO + (wn * TN + b) * 32 + lr) * 2 + 1] = s2;
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) {
+                        if (p.stats) {
+                            s1[h] += __shfl_xor(s1[h], 32, 64);
+                            s2[h] += __shfl_xor(s2[h], 32, 64);
+                            if (lq == 0) {
+                                red[(wm * CO + (wn * TN + b) * 32 + 16 * h + lc) * 2 + 0] = s1[h];
+                                red[(wm * CO + (wn * TN + b) * 32 + 16 * h + lc) * 2 + 1] = s2[h];
+                            }
                         }
+                        s1[h] = 0.f; s2[h] = 0.f;
+                        cols[h] = colsn[h];
                     }
-                    s1 = 0.f; s2 = 0.f;
-                    col = coln;
                 }
             }
         }
@@ -392,13 +510,17 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     unsigned bcur = 0, bnxt = BSLOT;
     __syncthreads();
     Frag F0, F1;
-    rd(F0, 0, bcur);
+    if (MF16) { ldA(X, 0, 0); ldB(Y, 0, bcur); }
+    else rd(F0, 0, bcur);
     zero();
 
 #ifndef C3_ABL
 #define C3_ABL 0        /* ablation builds (timing only, wrong results): 1 no weight stream, 2 no halo staging, 4 no barrier, 8 no fragment reads */
 #endif
-    if (C3_ABL & 8) rd(F1, 1, bcur);
+    if (C3_ABL & 8) {
+        if (MF16) { ldB(Z, 1, bcur); ldA(W, 1, 0); }
+        else rd(F1, 1, bcur);
+    }
     for (; v < ntiles; v += gridDim.x) {
         for (int c2 = 0; c2 < nchunks; c2 += 2) {
 #pragma unroll
@@ -406,6 +528,24 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 // first half: the MFMAs of step 2 it carry the fragment reads of step 2 it + 1, the copy of the pair after this
                 // one into the other slot (its last readers passed the previous barrier) and the fetch of the one after that
                 __builtin_amdgcn_sched_barrier(0);
+                if (MF16) {
+                    if (!(C3_ABL & 8)) { ldB(Z, 1, bcur); ldA(W, 1, 2 * it); }
+                    if (!(C3_ABL & 1)) { storeB(bnxt); gloadB(); }
+                    mmq(X, Y, 0, 0);
+                    mmq(X, Z, 0, 1);
+                    // the eight fragment reads behind the first eight MFMAs (Z is due at the 13th), then a weight unit every third
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NJB; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                } else {
                 if (!(C3_ABL & 8)) rd(F1, 2 * it + 1, bcur);
                 if (!(C3_ABL & 1)) { storeB(bnxt); gloadB(); }
                 mm(F0);
@@ -420,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(C3_ABL & 4)) __syncthreads();                // the other slot / chunk buffer is written; this slot is read
                 // second half: the MFMAs of step 2 it + 1 carry the fragment reads of step 2 it + 2 and the halo staging.  (The chunk-at-a-time
@@ -427,7 +568,8 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 // fetched whole at it = 0 and stored at it = 2; chunk c2 + 2, or chunk 0 of the next tile — buffer 0: read last at
                 // step 8 — at it = 4 / it = 7.  Fetching WHOLE chunks four / five iterations ahead instead, the stores in the
                 // first half: 105 -> 108 us.)
-                if (!(C3_ABL & 8)) rd(F0, 2 * it + 2, bnxt);
+                if (MF16) { if (!(C3_ABL & 8)) ldA(X, 0, 2 * it + 2); }
+                else if (!(C3_ABL & 8)) rd(F0, 2 * it + 2, bnxt);
                 if (!(C3_ABL & 2)) {
                 if (ROLL) {
                     // buffer 1 (the odd chunk c2 + 1: read from step 9, last read at step 17 of the previous pair) takes its items at
@@ -459,8 +601,32 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 if (it == 7) storeA(0, c2 + 2 < nchunks ? c2 + 2 : 0);
                 }
                 }
+                if (MF16) {
+                    mmq(W, Y, 1, 0);
+                    if (!(C3_ABL & 8)) ldB(Y, 0, bnxt);
+                    mmq(W, Z, 1, 1);
+                    // 24 MFMAs in pairs: the reads of X (next pair) behind the first four pairs, of Y behind pairs 7-10 (Y is
+                    // this pair's operand through the first 12 MFMAs), the item's VALU spread over all of them
+                    // 24 MFMAs: the reads of X (next pair) behind MFMAs 1-4, of Y behind 13-16 — Y is this pair's operand through
+                    // the 12th, and the next pair's first MFMA wants it 8 MFMAs after the last read —, the item's VALU spread over
+                    // the first 20, its fetch and stores at the end
+                    // (the item's BatchNorm vectors are LDS reads too — NSS of them: asked for right behind X, or the item's VALU
+                    // waits for them in one clump)
+                    constexpr int NSS = APPLY ? 3 : (PRO ? 2 : 0), VS = NSS ? 8 : 0, VPG = APPLY ? 6 : (PRO ? 4 : 1);
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i < 4 || (i >= 12 && i < 16) || (it != 3 && i >= 4 && i < 4 + NSS)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (it != 3 && i >= VS && i < 22) __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+                        if (it != 3 && i == 20 && APPLY) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                        if (it != 3 && i == 22) __builtin_amdgcn_sched_group_barrier(0x020, APPLY ? 2 : 1, 0);
+                        if (it != 3 && i == 23) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+                    }
+                } else {
                 mm(F1);
-                if (ROLL) {
+                }
+                if (MF16) {
+                } else if (ROLL) {
                     // every MFMA of the step carries a fragment read (the first eight) and a few of the item's ~50 VALU instructions
                     // (transform + split: left in one clump they run with the matrix pipe idle on BOTH waves of the SIMD, which
                     // reach this point together); the item's fetch and its two LDS stores behind the last MFMAs
@@ -558,10 +724,21 @@ bool dsnt_conv3s_ok(const ConvP& p) {
     return true;
 }
 
-template <int CO, bool PRO, int MODE, int PW>
+// which launches of the Cout-128, 4 x 32-patch shape take the 16x16x32 form: bit 0 forward (MODE 0 / 1), 1 the data gradient with the
+// BatchNorm-backward epilogue (MODE 3), 2 the same with the folded BatchNorm backward (MODE 4).  DSNT_X_C3_MF16=<mask>: A/B and the
+// tests of the other modes.  Default: forward only — alone (batch 32, 64 x 64, one box): forward 97-99 us against 103-108, MODE 3
+// 102 against 113, MODE 4 130 against 128; in the hg2 / hg8 steps none of the masks moves the step beyond the run-to-run spread
+// (profiles/r05_ab_switches.txt box J), so the default is the set that is faster alone and never slower in the step.
+static int c3_mf16_modes() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("DSNT_X_C3_MF16"); m = e ? atoi(e) : C3_MF16_DEFAULT; }
+    return m;
+}
+
+template <int CO, bool PRO, int MODE, int PW, bool MF>
 static void c3_launch_k(const ConvP& p, hipStream_t st, bool share) {
-    const int lds = 2 * C3_ABUF + 2 * 2 * CO * C3_BP + (MODE == 4 ? 1536 : 1024);       // halo buffers, weight ring, BatchNorm vectors
-    DSNT_SET_MAX_LDS((conv3s_kernel<CO, PRO, MODE, PW>), lds);
+    const int lds = C3Geo<CO, PW, MF>::lds(MODE);
+    DSNT_SET_MAX_LDS((conv3s_kernel<CO, PRO, MODE, PW, MF>), lds);
     const int cus = dsnt_device_cus();
     const int ntiles = p.N * (p.H / (128 / PW)) * (p.W / PW);
     int grid = 2 * cus;                         // two workgroups per CU (LDS), persistent over the tiles
@@ -571,13 +748,17 @@ static void c3_launch_k(const ConvP& p, hipStream_t st, bool share) {
     // lane's 1x1 kernel yields half of the CUs — gemm1.hip — this one's share no longer matters: 128 .. 512 workgroups within 0.03 ms).
     if (share) grid = cus + cus / 2;
     if (grid > ntiles) grid = ntiles;
-    DSNT_LAUNCH((conv3s_kernel<CO, PRO, MODE, PW>), dim3(grid), dim3(256), lds, st, p, ntiles);
+    DSNT_LAUNCH((conv3s_kernel<CO, PRO, MODE, PW, MF>), dim3(grid), dim3(256), lds, st, p, ntiles);
 }
 
 template <int CO, bool PRO, int MODE>
 static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
-    if (p.W % 32 == 0 && p.H % 4 == 0) c3_launch_k<CO, PRO, MODE, 32>(p, st, share);
-    else c3_launch_k<CO, PRO, MODE, 16>(p, st, share);
+    if (p.W % 32 == 0 && p.H % 4 == 0) {
+        if constexpr (CO == 128) {
+            if (c3_mf16_modes() & (MODE == 4 ? 4 : MODE == 3 ? 2 : 1)) return c3_launch_k<CO, PRO, MODE, 32, true>(p, st, share);
+        }
+        c3_launch_k<CO, PRO, MODE, 32, false>(p, st, share);
+    } else c3_launch_k<CO, PRO, MODE, 16, false>(p, st, share);
 }
 
 template <int CO>

@@ -2,6 +2,7 @@
 blocks), called through the C ABI.  fp32 MFMA is an exact-f32 fmaf chain, so forward values are
 held to 2e-5 relative to the output scale (accumulation-order differences only)."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -758,8 +759,8 @@ STREAM_CASES = [
 def test_conv3_stream_kernel(case, mode):
     """dsnt_conv_fwd_f16x3_stream (persistent symmetric 3x3 kernel, weights in stream order) against
     dsnt_conv_fwd_f16x3_ex on the same operands: the stream planes are the plain planes permuted; without a residual the
-    outputs are bit-identical (same K order, same MFMA order, same epilogue arithmetic); with one they agree to an ulp of
-    the sum; per-patch statistics add up to the same column sums; the BatchNorm-backward epilogue masks identically; and
+    outputs of the 32x32x16 form are bit-identical (same K order, same MFMA order, same epilogue arithmetic), those of the
+    16x16x32 form (Cout 128, 4 x 32 patches) agree to fp32 rounding of the sum; with a residual to an ulp of the sum; per-patch statistics add up to the same column sums; the BatchNorm-backward epilogue masks identically; and
     the result holds the fp32 bar against torch fp64."""
     from dsnt import _lib
     from dsnt._lib import ptr, call, BnBwdEpilogue
@@ -828,10 +829,15 @@ def test_conv3_stream_kernel(case, mode):
     (y0, st0, am0), (y1, st1, am1) = outs
     assert not bool(torch.isnan(y1).any()) and not bool(torch.isnan(st1).any())
     scale = y0.abs().max().item()
-    if mode in ('plain', 'pro', 'bnb') and H % 8 == 0:       # (H % 8 != 0: _ex runs the implicit-GEMM kernel, K order (tap, channel))
+    # Cout 128 on 32-pixel-wide patches runs on v_mfma_f32_16x16x32_f16 (csrc/conv3s.hip MF16): an MFMA sums BOTH K-steps of a
+    # pair, so the same products are added in another association — fp32 rounding of the 1152..3456-term sums, not bit identity
+    mf16 = Cout == 128 and W % 32 == 0 and H % 4 == 0
+    if mode in ('plain', 'pro', 'bnb') and H % 8 == 0 and not mf16:   # (H % 8 != 0: _ex runs the implicit-GEMM kernel, K order (tap, channel))
         assert torch.equal(y0, y1)
     else:
-        assert (y0 - y1).abs().max().item() <= (2.5e-7 if H % 8 == 0 else 2e-6) * scale
+        assert (y0 - y1).abs().max().item() <= (5e-7 if H % 8 == 0 else 2e-6) * scale
+        if mode == 'bnb':        # the ReLU mask comes from the residual operand, not from the sums: the same zeros
+            assert torch.equal(y0 == 0, y1 == 0)
     if mode == 'bnb':
         assert float((y1 == 0).float().mean()) > (0.2 if relu else -1.0)
     else:
@@ -851,6 +857,19 @@ def test_conv3_stream_kernel(case, mode):
         cols = y1.double().reshape(M, Cout)
         assert (st1[:, 0].double().sum(0) - cols.sum(0)).abs().max().item() <= 1e-4 * max(1.0, cols.sum(0).abs().max().item())
         assert (st1[:, 1].double().sum(0) - (cols * cols).sum(0)).abs().max().item() <= 1e-4 * (cols * cols).sum(0).max().item()
+
+
+def test_conv3_stream_kernel_16x16x32_form_in_every_mode():
+    """The 16x16x32 MFMA form of csrc/conv3s.hip is the default for the forward launches only; DSNT_X_C3_MF16=7 puts the
+    data-gradient modes (BatchNorm-backward epilogue, folded BatchNorm backward) on it too.  The switch is read once per
+    process, so the stream tests run again in a child with it set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, DSNT_X_C3_MF16='7')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-p', 'no:cacheprovider',
+                        '-k', 'test_conv3_stream_kernel[ or folded_in'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
 
 
 @pytest.mark.parametrize('case', [c for c in STREAM_CASES if c[3] in (64, 128)])
