@@ -36,6 +36,9 @@ typedef float c3_f32x4 __attribute__((ext_vector_type(4)));
 #ifndef C3_MF16_DEFAULT
 #define C3_MF16_DEFAULT 1
 #endif
+#ifndef C3_ABL
+#define C3_ABL 0        /* ablation builds (timing only, wrong results): 1 no weight stream, 2 no halo staging, 4 no barrier, 8 no fragment reads, 16 no epilogue stores */
+#endif
 #ifndef C3_ABL4
 #define C3_ABL4 0       /* ablation builds of MODE 4 (timing only, wrong results): 1 no dL/dy store, 2 no second-stream loads */
 #endif
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                     }
                 }
                 const float (&r)[NR] = rbuf[i & 1];
-                const unsigned o0 = tile_off(i);
+                const unsigned o0 = (C3_ABL & 16) ? OOB : tile_off(i);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const unsigned so = reg_off(e);
@@ -514,9 +517,6 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     else rd(F0, 0, bcur);
     zero();
 
-#ifndef C3_ABL
-#define C3_ABL 0        /* ablation builds (timing only, wrong results): 1 no weight stream, 2 no halo staging, 4 no barrier, 8 no fragment reads */
-#endif
     if (C3_ABL & 8) {
         if (MF16) { ldB(Z, 1, bcur); ldA(W, 1, 0); }
         else rd(F1, 1, bcur);
