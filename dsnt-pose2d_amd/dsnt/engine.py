@@ -1477,12 +1477,14 @@ class Tape:
             self.on_backward(backward)
         return out
 
-    def to_planar(self, x, C_logical, name=''):
+    def to_planar(self, x, C_logical, name='', out=None, gin=None):
         """NHWC activation -> logical NCHW tensor [N, C, H, W] (model surface); returns the tensor.
-        In backward the incoming NCHW gradient is transposed into x.grad (first writer)."""
-        out = self.empty(x.N, C_logical, x.H, x.W)
+        In backward the incoming NCHW gradient is transposed into x.grad (first writer).
+        out / gin: the caller's buffers (slices of one slab when a model has several outputs of one shape)."""
+        out = self.empty(x.N, C_logical, x.H, x.W) if out is None else out
         x.uses += 1
-        gin = self.empty(x.N, C_logical, x.H, x.W) if self.record else None
+        if gin is None:
+            gin = self.empty(x.N, C_logical, x.H, x.W) if self.record else None
         self.f('dsnt_nhwc_to_nchw', x.buf, out, x.N, C_logical, x.H * x.W, x.C)
         if self.record:
             def backward():

@@ -10,6 +10,8 @@ calls them.  Instead the module tree is traced into forward/backward kernel laun
 `nn.Parameter`s become strided views of it with their logical OIHW shapes), and gradients land
 in a matching flat arena that the fused optimiser and the RCCL all-reduce consume directly.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -219,8 +221,18 @@ class Program:
         outs = [outs] if single else list(outs)
         self.out_channels = root.out_channels
         self.outs, self.gins = [], []
-        for o in outs:
-            t, g = tape.to_planar(o, self.out_channels)
+        # several outputs of one shape (the stacks' heat-maps) live in ONE slab [S, N, C, H, W], and so do their incoming
+        # gradients: the model surface hands out one clone + views, and backward takes one gradient tensor — the heads and the
+        # loss of all stacks are then one launch each instead of one per stack (eight stacks: ~60 small launches and as many
+        # host-bound autograd nodes between the two launch lists, GPU idle; tools/head_section.py)
+        self.out_slab = self.gin_slab = None
+        if not single and len(outs) > 1 and len({(o.N, o.H, o.W) for o in outs}) == 1 and os.environ.get('DSNT_STACKED_OUTPUTS', '1') != '0':
+            o = outs[0]
+            self.out_slab = tape.empty(len(outs), o.N, self.out_channels, o.H, o.W)
+            self.gin_slab = tape.empty(len(outs), o.N, self.out_channels, o.H, o.W) if record else None
+        for i, o in enumerate(outs):
+            t, g = tape.to_planar(o, self.out_channels, out=None if self.out_slab is None else self.out_slab[i],
+                                  gin=None if self.gin_slab is None else self.gin_slab[i])
             self.outs.append(t)
             self.gins.append(g)
         self.input_grad = input_grad and record
@@ -236,6 +248,16 @@ class Program:
                 tape.b('dsnt_nhwc_to_nchw', x.grad, self.gx, N, Cc, H * W, x.C)
         self.n_fwd = sum(1 for e in tape.fwd if e[0] is not None)
         self.n_bwd = sum(1 for e in tape.bwd if e[0] is not None)
+
+
+class StackedOutputs(list):
+    """The outputs of a model with several same-shape outputs: a list of per-output tensors (views of `stacked`, what the
+    reference's `model(x)` returns — model.py:299-307 appends one tensor per stack), plus the slab [S, N, C, H, W] itself for
+    consumers that work on all of them at once (dsnt.model's fused heads)."""
+
+    def __init__(self, stacked):
+        super().__init__(stacked.unbind(0))
+        self.stacked = stacked
 
 
 class _Run(Function):
@@ -255,6 +277,8 @@ class _Run(Function):
             if p.owner == t:            # (not p.token: a forward that does not record bumps the token without taking ownership)
                 p.in_flight, p.owner = False, None
         weakref.finalize(ctx, release)
+        if prog.out_slab is not None:
+            return (prog.out_slab.clone(),)
         return tuple(o.clone() for o in prog.outs)
 
     @staticmethod
@@ -267,11 +291,17 @@ class _Run(Function):
                 prog.in_flight, prog.owner = False, None
             raise RuntimeError('dsnt: the saved activations of this forward were overwritten by a '
                                'later forward of the same shape; run backward before forwarding again')
-        for g, gin in zip(gouts, prog.gins):
-            if g is None:
-                gin.zero_()
+        if prog.gin_slab is not None:
+            if gouts[0] is None:
+                prog.gin_slab.zero_()
             else:
-                gin.copy_(g)
+                prog.gin_slab.copy_(gouts[0])
+        else:
+            for g, gin in zip(gouts, prog.gins):
+                if g is None:
+                    gin.zero_()
+                else:
+                    gin.copy_(g)
         prog.tape.run(prog.tape.bwd, runner.bucket_hook, probe=runner.probe)
         if runner.before_publish is not None:
             runner.before_publish()
@@ -349,7 +379,9 @@ class Runner:
                 prog.in_nchw.copy_(x)
                 prog.token += 1
                 prog.tape.run(prog.tape.fwd, probe=self.probe)
-                outs = tuple(o.clone() for o in prog.outs)
+                outs = (prog.out_slab.clone(),) if prog.out_slab is not None else tuple(o.clone() for o in prog.outs)
+        if prog.out_slab is not None:
+            return StackedOutputs(outs[0])
         return outs[0] if prog.single else list(outs)
 
 

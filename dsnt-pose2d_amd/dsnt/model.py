@@ -89,6 +89,17 @@ class HourglassHumanPoseModel(HumanPoseModel):
         if self.output_strat == 'gauss':
             self.heatmaps_array = hg_outs
             return hg_outs
+        self._fused_all = None
+        stacked = getattr(hg_outs, 'stacked', None)
+        if self.output_strat == 'dsnt' and self.preact == 'softmax' and stacked is not None and stacked.dim() == 5:
+            # every stack's head in ONE launch on the slab the hourglass hands out ([S, N, J, H, W]; rows = S N J)
+            S = stacked.size(0)
+            x4 = stacked.reshape(-1, stacked.size(-3), stacked.size(-2), stacked.size(-1))
+            hm, coords = dnn.head_forward(x4)
+            out = list(coords.view(S, -1, coords.size(-2), 2).unbind(0))
+            self.heatmaps_array = list(hm.view(stacked.shape).unbind(0))
+            self._fused_all = (x4, hm, coords, out)
+            return out
         if self.output_strat == 'dsnt':
             self.heatmaps_array = []
             for x in hg_outs:
@@ -118,6 +129,24 @@ class HourglassHumanPoseModel(HumanPoseModel):
         if self.output_strat == 'dsnt' or self.output_strat == 'fc':
             total_loss = 0
             denom2 = None            # the masked-average denominator: one tiny launch shared by all stacks
+            fa = getattr(self, '_fused_all', None)
+            if fa is not None and len(out_vars) == len(fa[3]) and all(a is b for a, b in zip(out_vars, fa[3])):
+                # the stacks' losses in ONE launch: sum_s masked_average_s = (sum over all rows) / (one stack's denominator)
+                x4, hm, coords, out = fa
+                S, rows = len(out), coords.numel() // 2 // len(out)
+                sigma = 2.0 * self.hm_sigma / hm.size(-1)
+                m_ = None if mask_var is None else mask_var.to(torch.float32).expand(out[0].shape[:-1])
+                denom2 = dnn.mask_denominator(m_, rows, hm.device)
+                t_all = target_var.to(torch.float32).expand_as(out[0]).unsqueeze(0).expand(S, *out[0].shape).reshape(coords.shape)
+                m_all = None if m_ is None else m_.unsqueeze(0).expand(S, *m_.shape).reshape(coords.shape[:-1])
+                return dnn.head_loss(x4, hm.detach(), coords.detach(), t_all, m_all, self.reg, sigma, self.reg_coeff, denom2)
+            if fa is not None:
+                # the caller took the outputs apart: per-stack losses on views of the fused head's tensors
+                x4, hm, coords, out = fa
+                S = len(out)
+                x5, hm5 = x4.view(S, -1, *x4.shape[1:]), hm.view(S, -1, *hm.shape[1:])
+                for s_, o in enumerate(out):
+                    self._fused[id(o)] = (x5[s_], hm5[s_], o)
             for i, out_var in enumerate(out_vars):
                 fused = self._fused.get(id(out_var))
                 if fused is not None and fused[2] is out_var:

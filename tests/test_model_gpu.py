@@ -617,6 +617,41 @@ def test_finalisation_in_the_consumers_prologue_gives_the_same_step(monkeypatch)
     assert b0[0] == b1[0] and torch.equal(b0[1], b1[1]) and torch.equal(b0[2], b1[2])
 
 
+def test_the_stacks_heads_and_losses_in_one_launch_each_give_the_same_step(monkeypatch):
+    """The stacks' heat-maps leave the hourglass in one slab (dsnt.hourglass.StackedOutputs) and `forward` / `forward_loss` run the
+    DSNT head and the loss of ALL stacks as one launch each; DSNT_STACKED_OUTPUTS=0 is the per-stack path of rounds 1-4 (one
+    output tensor, one head, one loss node per stack — model.py:299-307 / 273-297 of the reference, literally).  Same
+    coordinates and gradients bit for bit (the per-row arithmetic is the same kernels'), the loss to fp32 rounding (one sum over
+    all rows instead of a sum of per-stack sums).  A caller that takes the list apart — the loss of the last stack only, or the
+    stacks in another order — falls back to per-stack losses on views of the same tensors."""
+    from dsnt.model import build_mpii_pose_model
+    from dsnt.hourglass import StackedOutputs
+
+    def step(stacked, pick):
+        monkeypatch.setenv('DSNT_STACKED_OUTPUTS', stacked)
+        m = build_mpii_pose_model(base='hg2', output_strat='dsnt', reg='js')
+        synthetic.fill_state_dict(m, seed=0)
+        m.cuda().train()
+        x, t, k = synthetic.batch(4, size=128, seed=1, mask_p=0.9)
+        for p in m.parameters():
+            p.grad = None
+        hg_out = m.forward_part1(x.to(DEV))
+        assert isinstance(hg_out, list) and len(hg_out) == 2 and isinstance(hg_out, StackedOutputs) == (stacked == '1')
+        out = m.forward_part2(hg_out)
+        assert isinstance(out, list) and len(out) == 2 and out[0].shape == (4, 16, 2)
+        assert len(m.heatmaps_array) == 2 and m.heatmaps_array[0].shape == (4, 16, 32, 32)
+        loss = m.forward_loss(pick(out), t.to(DEV), k.to(DEV))
+        loss.backward()
+        return (loss.item(), torch.stack([o.detach() for o in out]).clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone(),
+                torch.stack([h.detach() for h in m.heatmaps_array]).clone())
+
+    for pick, exact in ((lambda o: o, False), (lambda o: [o[1]], True), (lambda o: [o[1], o[0]], True)):
+        a, b = step('0', pick), step('1', pick)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+        assert abs(a[0] - b[0]) <= (0.0 if exact else 2e-7) * abs(a[0]), (a[0], b[0])
+        assert torch.equal(a[2], b[2]), (a[2] - b[2]).abs().max().item()
+
+
 def test_optimizer_kernels():
     """Flat RMSprop / SGD-momentum kernels vs torch.optim on identical gradients (train.py:314-326)."""
     from dsnt._lib import ptr, call
