@@ -33,8 +33,12 @@
 
 typedef unsigned c3_u32x4 __attribute__((ext_vector_type(4)));
 typedef float c3_f32x4 __attribute__((ext_vector_type(4)));
+typedef int c3_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef C3_MF16_DEFAULT
 #define C3_MF16_DEFAULT 1
+#endif
+#ifndef C3_DMA
+#define C3_DMA 1        /* 0: the MF16 form keeps the weight stream in registers (global -> VGPR -> ds_write), two ring slots (A/B) */
 #endif
 #ifndef C3_ABL
 #define C3_ABL 0        /* ablation builds (timing only, wrong results): 1 no weight stream, 2 no halo staging, 4 no barrier, 8 no fragment reads, 16 no epilogue stores */
@@ -60,7 +64,14 @@ template <int CO, int PW, bool MF> struct C3Geo {
     static constexpr int SUBPL = 208 * 16;
     static constexpr int APL = MF16 ? 2 * SUBPL : C3_APL, ABUF = 2 * APL;
     static constexpr int BPL = MF16 ? 4 * CO * 16 : CO * C3_BP, BSLOT = 2 * BPL;
-    static constexpr int lds(const int mode) { return 2 * ABUF + 2 * BSLOT + (mode == 4 ? 1536 : 1024); }   // halo buffers, weight ring, BatchNorm vectors
+    // DMA (MF16, one-stream modes): the weight pairs go global -> LDS directly (buffer_load_dwordx4 ... lds: a wave-instruction writes
+    // 64 lanes x 16 B = one k-group's 64 rows, contiguous in the layout above), three pairs ahead into a THREE-slot ring — no VGPR round
+    // trip (16 registers), no ds_write; the statistics scratch then has 2 KB of its own (no ring slot is ever free)
+    static constexpr bool dma(const int mode) { return MF16 && C3_DMA && mode != 4; }
+    static constexpr int nslots(const int mode) { return dma(mode) ? 3 : 2; }
+    static constexpr int red_bytes(const int mode) { return dma(mode) ? 2048 : 0; }
+    // halo buffers, weight ring, (statistics scratch,) BatchNorm vectors
+    static constexpr int lds(const int mode) { return 2 * ABUF + nslots(mode) * BSLOT + red_bytes(mode) + (mode == 4 ? 1536 : 1024); }
 };
 
 // MODE: 0 no residual, 1 res1, 3 the BatchNorm-backward epilogue of a data-gradient launch (res1 = the BatchNorm input x),
@@ -87,8 +98,10 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     const unsigned OOB = 0xF0000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char c3_smem[];
     unsigned char* As = c3_smem;                // [2 chunk buffers][2 planes][204 px][48]
-    unsigned char* Bs = c3_smem + 2 * ABUF;     // [2 slots][2 planes][CO][80]
-    float* SS = reinterpret_cast<float*>(Bs + 2 * BSLOT);          // PRO: [2][Cin] BN scale / shift x operand scale; APPLY: [3][Cin] P, R, S
+    constexpr bool DMA = G::dma(MODE);
+    unsigned char* Bs = c3_smem + 2 * ABUF;     // [2 slots][2 planes][CO][80]  (MF16: C3Geo; DMA: 3 slots)
+    float* RED = reinterpret_cast<float*>(Bs + G::nslots(MODE) * BSLOT);      // DMA: the epilogue's statistics scratch [WM][CO][2]
+    float* SS = reinterpret_cast<float*>(Bs + G::nslots(MODE) * BSLOT + G::red_bytes(MODE));   // PRO: [2][Cin] BN scale / shift x operand scale; APPLY: [3][Cin] P, R, S
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -268,6 +281,41 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
 #pragma unroll
         for (int j = 0; j < NJB; ++j)
             *reinterpret_cast<c3_u32x4*>(Bs + (slot + blds[MF16 ? 0 : j]) + (MF16 ? (j >> 1) * BPL + (j & 1) * 4096 : 0)) = rb[j];
+    };
+
+    // DMA: wave w copies unit blocks 4 w .. 4 w + 3 of a pair (16 blocks of 64 rows x 16 B): block = plane (w >> 1), k-group 2 (w & 1) + (j >> 1),
+    // row half j & 1.  LDS destination = M0 (wave-uniform) + lane x 16; global source = lane x 32 (VGPR) + a scalar offset (the stream
+    // keeps a weight row's two halves side by side: [K-step][row][2 x 16 B]).  hipcc does not count these loads: the waits are
+    // placed by hand (`dma_wait`), by the guide's rule — the wait before a barrier, the reads after it.
+    const c3_i32x4 wrs = {(int)(unsigned)(size_t)p.wq, (int)((unsigned)((size_t)p.wq >> 32) & 0xffffu),
+                          (int)(((size_t)p.wq_stride + (size_t)p.Cout * p.K) * 2u), 0x00020000};
+    const unsigned dma_voff = (unsigned)lane * 32u;
+    const unsigned dma_lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Bs
+                              + (unsigned)((wave >> 1) * BPL + (wave & 1) * 2 * (CO * 16));
+    const unsigned dma_g0 = (unsigned)(wave >> 1) * wplane + (unsigned)(wave & 1) * 4096u;
+    auto dmaB = [&](const unsigned slot) {
+        // the four pieces: LDS + 1024 j, stream + {0, 2048, 16, 2064}; M0 is written in the statement that uses it and restored (the
+        // compiler owns it); an SALU instruction between every write of M0 and the load that reads it
+        const unsigned so = (unsigned)gp * (unsigned)(CO * 64) + dma_g0, la = dma_lds0 + slot;
+        unsigned keep, t;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %2\n\t"
+                     "s_add_u32 %1, %3, 0x800\n\t"
+                     "buffer_load_dwordx4 %4, %5, %3 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %5, %1 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_add_u32 %1, %3, 16\n\t"
+                     "buffer_load_dwordx4 %4, %5, %1 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "s_add_u32 %1, %3, 0x810\n\t"
+                     "buffer_load_dwordx4 %4, %5, %1 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(t)
+                     : "s"(la), "s"(so), "v"(dma_voff), "s"(wrs)
+                     : "scc");
+        gp = gp + 1 == npairs ? 0 : gp + 1;
     };
 
     // ---- fragments
@@ -491,7 +539,8 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     int v = blockIdx.x;
     int m0 = set_tile(v), m0n = 0;
     aok = aokn;
-    gloadB();
+    if (DMA) { dmaB(0); dmaB(BSLOT); dmaB(2 * BSLOT); }     // pairs 0, 1, 2
+    else gloadB();
     if (ROLL) {
         // chunk 0 whole and item 0 of chunk 1 through temporaries (one round trip); the next items of chunk 1 stay in flight in
         // the ring, as the loop's schedule expects them at it = 0
@@ -508,9 +557,12 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
         gloadA(0);
         storeA(0, 0);
     }
-    storeB(0);
-    gloadB();                                   // pair 1 travels
-    unsigned bcur = 0, bnxt = BSLOT;
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)");
+    else {
+        storeB(0);
+        gloadB();                               // pair 1 travels
+    }
+    unsigned bcur = 0, bnxt = BSLOT, bnn = 2 * BSLOT;     // (bnn: the third slot of the DMA ring)
     __syncthreads();
     Frag F0, F1;
     if (MF16) { ldA(X, 0, 0); ldB(Y, 0, bcur); }
@@ -530,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (MF16) {
                     if (!(C3_ABL & 8)) { ldB(Z, 1, bcur); ldA(W, 1, 2 * it); }
-                    if (!(C3_ABL & 1)) { storeB(bnxt); gloadB(); }
+                    if (!(C3_ABL & 1) && !DMA) { storeB(bnxt); gloadB(); }
                     mmq(X, Y, 0, 0);
                     mmq(X, Z, 0, 1);
                     // the eight fragment reads behind the first eight MFMAs (Z is due at the 13th), then a weight unit every third
@@ -562,6 +614,18 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (DMA && !(C3_ABL & 1)) {
+                    // the pair whose fragments are read behind this barrier was asked for two iterations ago: younger, and allowed
+                    // to be in flight, are the halo fetch issued right behind it, the four pieces of the previous iteration's pair and
+                    // that iteration's fetch (iteration 8 of a chunk pair fetches nothing).  The first two iterations of a tile
+                    // have nothing to wait for (prologue / the wait before the epilogue retired everything) — and must not wait:
+                    // the epilogue's stores are in the same queue
+                    if (it >= 2 || c2 != 0) {
+                        if (C3_ABL & 2) asm volatile("s_waitcnt vmcnt(4)");
+                        else if (it <= 1) asm volatile("s_waitcnt vmcnt(5)");
+                        else asm volatile("s_waitcnt vmcnt(6)");
+                    }
+                }
                 if (!(C3_ABL & 4)) __syncthreads();                // the other slot / chunk buffer is written; this slot is read
                 // second half: the MFMAs of step 2 it + 1 carry the fragment reads of step 2 it + 2 and the halo staging.  (The chunk-at-a-time
                 // schedule of the one-stream modes: chunk c2 + 1 — buffer 1: read last at step 17 of the previous trip, next at step 9 — is
@@ -581,6 +645,13 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                     else if (it >= 4 && it <= 7) st(0, cn0, it - 4);
                     else if (it == 8) st(1, cn1, 0);
                     if (it == 3 && last) aok = aokn;                  // from it = 4 on the stored items are the next tile's
+                    // DMA: this pair's slot has been read for the last time (Z, before the barrier): the pair three ahead goes
+                    // there.  Between the item's store and the next item's fetch: hipcc's own count in front of the store does not
+                    // know the four pieces — `vmcnt(3)` for the three younger fetches then means "all but the youngest three
+                    // operations", i.e. it also retires every fetch older than the last piece; with the fetch BEHIND the pieces that
+                    // is the fetch of two iterations ago (a lead of two left of the four), with the fetch in front of them it
+                    // would be the previous iteration's
+                    if (DMA && !(C3_ABL & 1)) dmaB(bcur);
                     if (LEAD == 4) {
                         if (it == 0 && last) m0n = set_tile(v + (int)gridDim.x);
                         if (it <= 3) ld(cn0, it);
@@ -601,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 if (it == 7) storeA(0, c2 + 2 < nchunks ? c2 + 2 : 0);
                 }
                 }
+                if ((C3_ABL & 2) && DMA && !(C3_ABL & 1)) dmaB(bcur);
                 if (MF16) {
                     mmq(W, Y, 1, 0);
                     if (!(C3_ABL & 8)) ldB(Y, 0, bnxt);
@@ -672,11 +744,15 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const unsigned tsw = bcur; bcur = bnxt; bnxt = tsw;
+                if (DMA) { const unsigned tsw = bcur; bcur = bnxt; bnxt = bnn; bnn = tsw; }
+                else { const unsigned tsw = bcur; bcur = bnxt; bnxt = tsw; }
             }
         }
 
-        epilogue(reinterpret_cast<float*>(Bs + bnxt), m0);      // `bnxt` (the slot just consumed) is free: statistics scratch [WM][CO][2]
+        // (DMA: every piece in flight is retired here — behind the epilogue its stores would stand in the queue before them)
+        if (DMA) asm volatile("s_waitcnt vmcnt(0)");
+        float* red = DMA ? RED : reinterpret_cast<float*>(Bs + bnxt);      // `bnxt` (the slot just consumed) is free: statistics scratch [WM][CO][2]
+        epilogue(red, m0);
         if (p.stats) {
             int tile;
             xcd_remap(v, ntiles, tile);
@@ -685,7 +761,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 const int which = u & 1, c = u >> 1;
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < WM; ++w) s += reinterpret_cast<const float*>(Bs + bnxt)[(w * CO + c) * 2 + which];
+                for (int w = 0; w < WM; ++w) s += red[(w * CO + c) * 2 + which];
                 tail_store(p.stats + ((size_t)tile * 2 + which) * p.Cout + c, s);
             }
             __syncthreads();                    // the next pair is stored over `red`
@@ -694,6 +770,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     }
     if (p.tail.amax) amax_commit(am, p.tail.amax);
     if (p.tail.amax_bn) amax_commit(am2, p.tail.amax_bn, 1);
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)");       // (nothing may still be writing this workgroup's LDS when it ends)
 }
 
 static int c3_enabled = -1;

@@ -859,6 +859,45 @@ def test_conv3_stream_kernel(case, mode):
         assert (st1[:, 1].double().sum(0) - (cols * cols).sum(0)).abs().max().item() <= 1e-4 * (cols * cols).sum(0).max().item()
 
 
+@pytest.mark.parametrize('case', [(20, 64, 64, 128, 128), (6, 32, 32, 64, 128)])
+def test_conv3_stream_kernel_with_the_weight_ring_filled_by_lds_dma_is_reproducible(case):
+    """The 16x16x32 form streams its weights global -> LDS directly (buffer_load ... lds, csrc/conv3s.hip `dmaB`), with hand-counted
+    s_waitcnt vmcnt in front of the barriers — loads hipcc does not track.  A misplaced wait is a race, and a race shows as
+    launches that disagree: 12 launches over 2560 patches (five tiles per persistent workgroup, the ring wrapping through every tile
+    change) / 48 patches (fewer tiles than workgroups), all bit-identical, and equal to the fp64 convolution to the fp32 bar."""
+    from dsnt import _lib
+    from dsnt._lib import ptr, call
+    N, H, W, Cin, Cout = case
+    dev = torch.device('cuda:0')
+    g = _geom(N, H, W, Cin, Cout, 3, 3, 1, 1, 1)
+    x = synthetic.tensor('dmax', (N, Cin, H, W), seed=2)
+    w = synthetic.tensor('dmaw', (Cout, Cin, 3, 3), seed=2, scale=(2.0 / (Cin * 9)) ** 0.5)
+    xd = _nhwc(x).to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    n = wd.numel()
+    strm = torch.empty(2 * n, dtype=torch.float16, device=dev)
+    wb = torch.zeros(64, device=dev)
+    table = torch.tensor([[wd.data_ptr(), strm.data_ptr(), wb.data_ptr(), n, n, Cout, Cin]], dtype=torch.int64).to(dev)
+    call('dsnt_f16_prep_weights', ptr(table), 1, 7)
+    ab = torch.zeros(64, device=dev)
+    ab[5] = x.abs().max().item() * 2.0
+    outs = []
+    for _ in range(12):
+        y = torch.full((N, H, W, Cout), float('nan'), device=dev)
+        stats = torch.full((N * H * W // 128, 2, Cout), float('nan'), device=dev)
+        call('dsnt_conv_fwd_f16x3_stream', ptr(xd), ptr(strm), n, ptr(wb), ptr(ab), None, ptr(y), None, None, 0, None, None,
+             ptr(stats), C.byref(g), None, None)
+        outs.append((y, stats))
+    torch.cuda.synchronize()
+    for y, st in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(st, outs[0][1])
+    y64 = F.conv2d(x.double(), w.double(), None, padding=1)
+    y32 = F.conv2d(x, w, None, padding=1)
+    got = outs[0][0].cpu().permute(0, 3, 1, 2).double()
+    err16, err32 = (got - y64).abs().max().item(), (y32.double() - y64).abs().max().item()
+    assert err16 <= max(4 * err32, 2e-6 * y64.abs().max().item()), (err16, err32)
+
+
 def test_conv3_stream_kernel_16x16x32_form_in_every_mode():
     """The 16x16x32 MFMA form of csrc/conv3s.hip is the default for the forward launches only; DSNT_X_C3_MF16=7 puts the
     data-gradient modes (BatchNorm-backward epilogue, folded BatchNorm backward) on it too.  The switch is read once per
