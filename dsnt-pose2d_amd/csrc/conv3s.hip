@@ -37,6 +37,9 @@ typedef int c3_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef C3_MF16_DEFAULT
 #define C3_MF16_DEFAULT 1
 #endif
+#ifndef C3_SPLIT_TILES_DEFAULT
+#define C3_SPLIT_TILES_DEFAULT 128
+#endif
 #ifndef C3_DMA
 #define C3_DMA 1        /* 0: the MF16 form keeps the weight stream in registers (global -> VGPR -> ds_write), two ring slots (A/B) */
 #endif
@@ -83,8 +86,16 @@ template <int CO, int PW, bool MF> struct C3Geo {
 //     conditioning of a scale / shift BatchNorm forward (eps |mean| / std), like `fmaf(x, scale, shift)` everywhere else.
 // PW: the patch is 128 / PW rows of PW pixels — 4 x 32 (W % 32 == 0), or 8 x 16 for the 16-pixel-wide levels (a 32-pixel MFMA
 // tile then spans two patch rows: a few two-way LDS bank conflicts on the activation fragments, immaterial at that size)
-template <int CO, bool PRO, int MODE, int PW, bool MF>
+// SP (round 5): a 128-column convolution with too few patches to fill the chip (the 16 x 16 and 32 x 32 levels of the 8-stack net at batch
+// 16: 32 / 128 patches on 512 slots) runs as TWO 64-column halves per patch — CO = 64 code, the weight stream and every column index
+// offset by 64 x (blockIdx & 1): twice the workgroups, half the MFMAs per K-step and workgroup; both stage the same halo.  Every
+// output is the same sum in the same order as in the unsplit 32x32x16 kernel (bit-identical).
+template <int CO, bool PRO, int MODE, int PW, bool MF, bool SP>
 __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
+    static_assert(!SP || (CO == 64 && !MF && MODE != 4), "column split: 64-column code, one-stream modes");
+    constexpr int COG = SP ? 2 * CO : CO;          // columns of a weight row block in the stream
+    const int choff = SP ? CO * (int)(blockIdx.x & 1) : 0;
+    const int vstep = SP ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     constexpr int WN = CO / 64, WM = 4 / WN, TM = 4 / WM, TN = 2;
     constexpr int PH = 128 / PW, HW = PW + 2, HPX = (PH + 2) * HW, ITEMS = HPX * 4;
     static_assert(HPX <= C3_HPX, "halo buffer");
@@ -259,7 +270,8 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
 #pragma unroll
     for (int j = 0; j < NJB; ++j) {
         const int u = tid + 256 * j, pl = u / UPP, uu = u % UPP;
-        bvoff[j] = (unsigned)((size_t)pl * p.wq_stride * 2u) + (unsigned)uu * 16u;
+        bvoff[j] = (unsigned)((size_t)pl * p.wq_stride * 2u) +
+                   (SP ? (unsigned)((uu / (2 * CO)) * (COG * 32) + choff * 32 + (uu % (2 * CO)) * 16) : (unsigned)uu * 16u);
         // (stream order of a pair and plane: [K-step][CO][2 halves of 16 bytes])
         blds[j] = MF16 ? (unsigned)(pl * BPL + (2 * (uu / (2 * CO)) + (uu & 1)) * (CO * 16) + ((uu >> 1) % CO) * 16)
                        : (unsigned)(pl * BPL + ((uu >> 1) % CO) * C3_BP + (uu / (2 * CO)) * 32 + (uu & 1) * 16);
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
     // ONE offset register each way, the rest compile-time / scalar)
     const unsigned wplane = (unsigned)((size_t)p.wq_stride * 2u);
     auto gloadB = [&]() {
-        const unsigned so = (unsigned)gp * (unsigned)(CO * 64);
+        const unsigned so = (unsigned)gp * (unsigned)(COG * 64);
 #pragma unroll
         for (int j = 0; j < NJB; ++j)
             rb[j] = MF16 ? __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[0] + (j & 1) * 4096, so + (j >> 1) * wplane, 0)
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
             float rbuf[2][NR];
             auto tile_off = [&](const int i) {       // i = b * TM + a
                 const int a = i % TM, b = i / TM;
-                return (unsigned)((m0 + (wm * TM + a) * (PW == 32 ? 1 : 2) * p.W + (MF16 ? 8 : 4) * lq) * p.Cout + (wn * TN + b) * 32 + lc) * 4u;
+                return (unsigned)((m0 + (wm * TM + a) * (PW == 32 ? 1 : 2) * p.W + (MF16 ? 8 : 4) * lq) * p.Cout + choff + (wn * TN + b) * 32 + lc) * 4u;
             };
             // register e -> pixel (e&3) + 8 (e>>2) + 4 lh of the 32-pixel tile; PW 16: pixels 16.. are the next patch row
             auto reg_off = [&](const int e) {
@@ -454,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
             };
             struct Col { float cb, sc, sh, mu, is; };
             auto loadcol = [&](const int b, const int h) {
-                const int n = (wn * TN + b) * 32 + 16 * h + lc;
+                const int n = choff + (wn * TN + b) * 32 + 16 * h + lc;
                 Col c = {0.f, 0.f, 0.f, 0.f, 0.f};
                 if (BNB) { c.sc = p.bnb_scale[n]; c.sh = p.bnb_shift[n]; c.mu = p.bnb_mean[n]; c.is = p.bnb_invstd[n]; }
                 else {
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
         }
     };
     // ---- prologue of the workgroup's FIRST tile
-    int v = blockIdx.x;
+    int v = SP ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
     int m0 = set_tile(v), m0n = 0;
     aok = aokn;
     if (DMA) { dmaB(0); dmaB(BSLOT); dmaB(2 * BSLOT); }     // pairs 0, 1, 2
@@ -573,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
         if (MF16) { ldB(Z, 1, bcur); ldA(W, 1, 0); }
         else rd(F1, 1, bcur);
     }
-    for (; v < ntiles; v += gridDim.x) {
+    for (; v < ntiles; v += vstep) {
         for (int c2 = 0; c2 < nchunks; c2 += 2) {
 #pragma unroll
             for (int it = 0; it < 9; ++it) {
@@ -653,12 +665,12 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                     // would be the previous iteration's
                     if (DMA && !(C3_ABL & 1)) dmaB(bcur);
                     if (LEAD == 4) {
-                        if (it == 0 && last) m0n = set_tile(v + (int)gridDim.x);
+                        if (it == 0 && last) m0n = set_tile(v + vstep);
                         if (it <= 3) ld(cn0, it);
                         else if (it <= 7) ld(cn1, it - 4);
                     } else {
                         if (it == 0) ld(c2 + 1, 3);
-                        if (it == 2 && last) m0n = set_tile(v + (int)gridDim.x);
+                        if (it == 2 && last) m0n = set_tile(v + vstep);
                         if (it >= 2 && it <= 5) ld(cn0, it - 2);
                         else if (it >= 6) ld(cn1, it - 6);
                     }
@@ -667,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 if (it == 2) storeA(1, c2 + 1);
                 if (it == 4) {
                     if (c2 + 2 < nchunks) gloadA(c2 + 2);
-                    else { m0n = set_tile(v + (int)gridDim.x); aok = aokn; gloadA(0); }      // the next tile's first chunk
+                    else { m0n = set_tile(v + vstep); aok = aokn; gloadA(0); }      // the next tile's first chunk
                 }
                 if (it == 7) storeA(0, c2 + 2 < nchunks ? c2 + 2 : 0);
                 }
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_kernel(ConvP p, int ntiles) {
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < WM; ++w) s += red[(w * CO + c) * 2 + which];
-                tail_store(p.stats + ((size_t)tile * 2 + which) * p.Cout + c, s);
+                tail_store(p.stats + ((size_t)tile * 2 + which) * p.Cout + choff + c, s);
             }
             __syncthreads();                    // the next pair is stored over `red`
         }
@@ -812,10 +824,10 @@ static int c3_mf16_modes() {
     return m;
 }
 
-template <int CO, bool PRO, int MODE, int PW, bool MF>
+template <int CO, bool PRO, int MODE, int PW, bool MF, bool SP = false>
 static void c3_launch_k(const ConvP& p, hipStream_t st, bool share) {
     const int lds = C3Geo<CO, PW, MF>::lds(MODE);
-    DSNT_SET_MAX_LDS((conv3s_kernel<CO, PRO, MODE, PW, MF>), lds);
+    DSNT_SET_MAX_LDS((conv3s_kernel<CO, PRO, MODE, PW, MF, SP>), lds);
     const int cus = dsnt_device_cus();
     const int ntiles = p.N * (p.H / (128 / PW)) * (p.W / PW);
     int grid = 2 * cus;                         // two workgroups per CU (LDS), persistent over the tiles
@@ -825,11 +837,27 @@ static void c3_launch_k(const ConvP& p, hipStream_t st, bool share) {
     // lane's 1x1 kernel yields half of the CUs — gemm1.hip — this one's share no longer matters: 128 .. 512 workgroups within 0.03 ms).
     if (share) grid = cus + cus / 2;
     if (grid > ntiles) grid = ntiles;
-    DSNT_LAUNCH((conv3s_kernel<CO, PRO, MODE, PW, MF>), dim3(grid), dim3(256), lds, st, p, ntiles);
+    if (SP) grid = 2 * ntiles;                  // (only asked for when that is at most a slot per workgroup)
+    DSNT_LAUNCH((conv3s_kernel<CO, PRO, MODE, PW, MF, SP>), dim3(grid), dim3(256), lds, st, p, ntiles);
+}
+
+// column split (SP) up to this many patches: DSNT_X_C3_SPLIT_TILES, A/B
+static int c3_split_tiles() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("DSNT_X_C3_SPLIT_TILES"); m = e ? atoi(e) : C3_SPLIT_TILES_DEFAULT; }
+    return m;
 }
 
 template <int CO, bool PRO, int MODE>
 static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
+    if constexpr (CO == 128 && MODE != 4) {
+        const bool w32 = p.W % 32 == 0 && p.H % 4 == 0;
+        const int ntiles = p.N * (p.H / (w32 ? 4 : 8)) * (p.W / (w32 ? 32 : 16));
+        if (ntiles <= c3_split_tiles()) {
+            if (w32) return c3_launch_k<64, PRO, MODE, 32, false, true>(p, st, share);
+            return c3_launch_k<64, PRO, MODE, 16, false, true>(p, st, share);
+        }
+    }
     if (p.W % 32 == 0 && p.H % 4 == 0) {
         if constexpr (CO == 128) {
             if (c3_mf16_modes() & (MODE == 4 ? 4 : MODE == 3 ? 2 : 1)) return c3_launch_k<CO, PRO, MODE, 32, true>(p, st, share);
