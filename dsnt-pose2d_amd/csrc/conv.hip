@@ -1450,6 +1450,9 @@ static void launch_fwd6(const ConvP& p, bool pro, hipStream_t st) {
     else DSNT_LAUNCH((conv_fwd_bf16x6_kernel<WM, WN, TM, TN, false, F16, 2>), gr, bl, lds, st, p);
 }
 
+#ifndef FWD6_BN64_ROWS_DEFAULT
+#define FWD6_BN64_ROWS_DEFAULT 8192
+#endif
 static bool g_force_gemm6 = false;      // debug/bench: route 3x3 convolutions through the implicit-GEMM kernel
 extern "C" int dsnt_debug_force_gemm6(int on) { g_force_gemm6 = on != 0; return DSNT_OK; }
 
@@ -1490,7 +1493,12 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     p.N = g->N; p.H = g->H; p.W = g->W; p.Cin = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo;
     p.Cout = g->Cout; p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad; p.dil = g->dil;
     p.M = g->N * g->Ho * g->Wo; p.K = g->R * g->S * g->Cin;
-    const int BN = g->Cout <= 64 ? 64 : 128;
+    // 64-column tiles also for wider outputs when there are few row tiles (the 16 x 16 level and below: 32-64 workgroups of 128 x 128
+    // on 256 CUs, each a prologue + 8-16 K-steps + an epilogue through LDS): twice the workgroups, half the epilogue each.
+    // DSNT_X_FWD6_BN64_ROWS: A/B
+    static long bn64_rows = -1;
+    if (bn64_rows < 0) { const char* e = getenv("DSNT_X_FWD6_BN64_ROWS"); bn64_rows = e ? atol(e) : FWD6_BN64_ROWS_DEFAULT; }
+    const int BN = (g->Cout <= 64 || (p.M <= bn64_rows && g->Cout % 64 == 0 && !conv3x3_halo_ok(g))) ? 64 : 128;
     p.mtiles = (p.M + 127) / 128; p.ntiles = (p.Cout + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
     DSNT_REQUIRE(!(p.tail.amax_bn && g_bnb), DSNT_ERR_ARG, "dsnt_conv_fwd_bf16x6_ex: dsnt_out_bounds.amax_bn excludes the batch-norm-backward epilogue");
