@@ -171,7 +171,7 @@ def dominant_kernel_roofline(batch, iters=20):
                                   'us_per_launch': round(ms6 * 1e3, 1)}
         twins['halo_tile_kernel_f16x3'] = {'achieved': round(flops / (ms16h * 1e-3) / 1e12, 2), 'peak': round(PEAK_BF16_MFMA / 3.0, 1),
                                            'us_per_launch': round(ms16h * 1e3, 1)}
-        kernel = ('conv3s_kernel<128,true,0> (fp16x3, persistent) 3x3 128->128 @64x64 B=%d' if streamed else
+        kernel = ('conv3s_kernel<128,true,0,32,MF> (fp16x3, 16x16x32 MFMAs, weight ring by LDS-DMA, persistent) 3x3 128->128 @64x64 B=%d' if streamed else
                   'conv3x3_bf16x6_kernel<2,true,F16> (fp16x3) 3x3 128->128 @64x64 B=%d') % batch
         note = ('algorithmic fp32 FLOPs; peak = 2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per product '
                 '(= %.0f fp16 TFLOP/s executed)' % (3 * achieved))
