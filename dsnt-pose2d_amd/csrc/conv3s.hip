@@ -23,6 +23,9 @@
 // chip holds a higher clock under the 4-pass MFMA (MI355X_MICROARCH "DVFS give-back"), an MFMA covers both K-steps of a pair, and the
 // LDS image needs no padding (60 KB per workgroup instead of 80).  Same products, same (chunk, tap) order of the pairs; inside a pair
 // the two steps are one 32-deep dot product, so the sums agree with the 32x32x16 form to fp32 rounding, not bit for bit.
+// Measured (profiles/r05_ab_switches.txt box J, r05_pmc_issue_accounting.txt last section): forward 92-95 us against 104-108 on the same
+// boxes — 192 k cycles at 2.08 GHz against 205 k at 1.90 GHz, the matrix pipe busy for the same 54-58 % of them: the form buys clock.
+// In the hg2 / hg8 steps the difference stays inside the run-to-run spread.
 // Contract: conv_fwd_bf16x6_kernel<..., F16> minus the second residual (dsnt_conv3s_ok).
 // Measured (DESIGN.md "round 3", profiles/r03_pmc_issue_accounting.txt): 3x3 128->128 @64x64, batch 32: 129 -> 104 us on one box
 // (matrix pipe 53 %, 1.15 PFLOP/s of fp16 MFMA at the ~1.9 GHz this load holds), -0.42 ms per hg2 step.  Built on the same pieces,
