@@ -338,15 +338,19 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
             a1 += (double)partial[((size_t)t * 2 + 1) * C + c];
         }
     }
-    r0[tid] = a0; r1[tid] = a1;
+    // the four tile-lanes of a wave by shuffles, the waves through LDS, summed by the block's first 16 threads in a fixed order
+    // (deterministic; ONE barrier — a seven-level tree over 1024 threads cost the chain ~0.5 us per BatchNorm, round 5)
+    a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64);
+    a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
+    if ((tid & 63) < 16) { r0[(tid >> 6) * 16 + cl] = a0; r1[(tid >> 6) * 16 + cl] = a1; }
     __syncthreads();
-    // tree over the 64 tile-lanes (fixed order: deterministic)
-    for (int h = FIN_P / 2; h >= 1; h >>= 1) {
-        if (part < h) { r0[tid] += r0[tid + h * 16]; r1[tid] += r1[tid + h * 16]; }
-        __syncthreads();
+    if (part == 0) {
+        a0 = 0.0; a1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < FIN_T / 64; ++w) { a0 += r0[w * 16 + cl]; a1 += r1[w * 16 + cl]; }
+        r0[tid] = a0; r1[tid] = a1;         // (tid = cl < 16: read again by the bound below, same thread)
     }
     if (part == 0 && c < C) {
-        a0 = r0[tid]; a1 = r1[tid];
         if (MODE == 0) {
             double mean, var;
             if (training) {
