@@ -2343,25 +2343,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x6_group_kernel(const W
 }
 
 // Slab reduction: 64 float4 columns x 4 split-lanes per block, 8 loads in flight per thread.
+// RC float4 columns x SL = 256 / RC slab lanes per 256-thread block: a block reads RC * 16 contiguous bytes of every slab (WRED_RC: A/B)
+#ifndef WRED_RC
+#define WRED_RC 32
+#endif
+#ifndef WRED_U
+#define WRED_U 8        /* independent 16-byte loads in flight per thread */
+#endif
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, float* __restrict__ dw,
                                                   float* __restrict__ dbias, int splits, int CK, int Cout,
                                                   int accumulate, int block) {
+    constexpr int RC = WRED_RC, SL = 256 / RC;
     __shared__ float4 red[256];
     const int total4 = CK / 4;
-    const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int i = block * 64 + col;
+    const int col = threadIdx.x % RC, sl = threadIdx.x / RC;
+    const int i = block * RC + col;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < total4) {
         int s = sl;
-        for (; s + 28 < splits; s += 32) {      // 8 independent 16-byte loads in flight
-            float4 v[8];
+        for (; s + (WRED_U - 1) * SL < splits; s += WRED_U * SL) {
+            float4 v[WRED_U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                v[u] = *reinterpret_cast<const float4*>(ws + (size_t)(s + 4 * u) * CK + (size_t)i * 4);
+            for (int u = 0; u < WRED_U; ++u)
+                v[u] = *reinterpret_cast<const float4*>(ws + (size_t)(s + SL * u) * CK + (size_t)i * 4);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+            for (int u = 0; u < WRED_U; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
         }
-        for (; s < splits; s += 4) {
+        for (; s < splits; s += SL) {
             const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)s * CK + (size_t)i * 4);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
@@ -2369,7 +2377,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, 
         // bias partials live behind the slabs: [splits][Cout]
         const int n0 = (i - total4) * 4;
         const float* b = ws + (size_t)splits * CK;
-        for (int s = sl; s < splits; s += 4) {
+        for (int s = sl; s < splits; s += SL) {
             const float* q = b + (size_t)s * Cout + n0;
             a.x += q[0]; if (n0 + 1 < Cout) a.y += q[1]; if (n0 + 2 < Cout) a.z += q[2]; if (n0 + 3 < Cout) a.w += q[3];
         }
@@ -2377,8 +2385,8 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, 
     red[threadIdx.x] = a;
     __syncthreads();
     if (sl == 0) {
-        for (int j = 1; j < 4; ++j) {
-            const float4 v = red[j * 64 + col];
+        for (int j = 1; j < SL; ++j) {
+            const float4 v = red[j * RC + col];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         if (i < total4) {
@@ -2406,14 +2414,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(const long long* 
     const long long* t = table + (size_t)blockIdx.y * 7;
     const int CK = (int)t[4], Cout = (int)t[5];
     const int total = CK / 4 + (Cout + 3) / 4;
-    if ((int)blockIdx.x * 64 >= total) return;
+    if ((int)blockIdx.x * WRED_RC >= total) return;
     wgrad_reduce_body(reinterpret_cast<const float*>(t[0]), reinterpret_cast<float*>(t[1]),
                       reinterpret_cast<float*>(t[2]), (int)t[3], CK, Cout, (int)t[6], blockIdx.x);
 }
 
 extern "C" int dsnt_wgrad_reduce_all(const int64_t* table, int rows, int max_blocks, void* stream) {
     DSNT_REQUIRE(table && rows > 0 && rows <= 65535 && max_blocks > 0, DSNT_ERR_ARG, "dsnt_wgrad_reduce_all: bad argument");
-    DSNT_LAUNCH(wgrad_reduce_all_kernel, dim3(max_blocks, rows), dim3(256), 0, (hipStream_t)stream,
+    // (max_blocks counts 64-column blocks: the interface's unit)
+    DSNT_LAUNCH(wgrad_reduce_all_kernel, dim3((max_blocks * 64 + WRED_RC - 1) / WRED_RC, rows), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)table);
     DSNT_CHECK_LAUNCH("dsnt_wgrad_reduce_all");
 }
@@ -2568,7 +2577,7 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
         if (dw) {
             const int CK = g->Cout * 16 * g->Cin;
             const int total = CK / 4 + (g->Cout + 3) / 4;
-            DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias, s4, CK,
+            DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + WRED_RC - 1) / WRED_RC), dim3(256), 0, st, ws, dw, dbias, s4, CK,
                         g->Cout, accumulate & 1);
         }
         DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_f16x3");
@@ -2589,7 +2598,7 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
         if (dw) {
             const int CK = g->Cout * 9 * g->Cin;
             const int total = CK / 4 + (g->Cout + 3) / 4;
-            DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias, pl.nslabs, CK,
+            DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + WRED_RC - 1) / WRED_RC), dim3(256), 0, st, ws, dw, dbias, pl.nslabs, CK,
                         g->Cout, accumulate & 1);
         }
         DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_f16x3");
@@ -2609,7 +2618,7 @@ extern "C" int dsnt_conv_wgrad_f16x3(const float* x, const float* in_scale, cons
         if (dw) {
             const int CK = g->Cout * g->Cin;
             const int total = CK / 4 + (g->Cout + 3) / 4;
-            DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias, p1.nsplits, CK,
+            DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + WRED_RC - 1) / WRED_RC), dim3(256), 0, st, ws, dw, dbias, p1.nsplits, CK,
                         g->Cout, accumulate & 1);
         }
         DSNT_CHECK_LAUNCH("dsnt_conv_wgrad_f16x3");
@@ -2683,7 +2692,7 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
     if (dw) {       // dw == nullptr: slabs only, the caller reduces later (dsnt_wgrad_reduce_all)
         const int CK = p.Cout * p.K;
         const int total = CK / 4 + (p.Cout + 3) / 4;
-        DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, dbias,
+        DSNT_LAUNCH(wgrad_reduce_kernel, dim3((total + WRED_RC - 1) / WRED_RC), dim3(256), 0, st, ws, dw, dbias,
                            p.splits, CK, p.Cout, accumulate);
     }
     DSNT_CHECK_LAUNCH("dsnt_conv_wgrad");
