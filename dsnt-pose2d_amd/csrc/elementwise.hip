@@ -330,6 +330,19 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
     __shared__ double r0[FIN_T], r1[FIN_T];
     const int tid = threadIdx.x, cl = tid & 15, part = tid >> 4;
     const int c = blockIdx.x * 16 + cl;
+    // everything the last step needs besides the sums is fetched NOW, under the row loop: the kernel's length is what a BatchNorm
+    // costs the dependency chain, and a load issued behind the reduction is a microsecond of it (round 5, box N)
+    const bool lead = part == 0 && c < C;
+    float pg = 1.f, pb = 0.f, prm = 0.f, prv = 0.f, po0 = 0.f, po1 = 0.f, psc = 0.f, pdz = 0.f;
+    if (MODE == 0 && lead) {
+        if (gamma) pg = gamma[c];
+        if (beta) pb = beta[c];
+        if (running_mean) { prm = running_mean[c]; prv = running_var[c]; }
+    }
+    if (MODE == 1) {
+        if (lead && accumulate) { if (o0) po0 = o0[c]; if (o1) po1 = o1[c]; }
+        if (bp.out) { pdz = bp.dz_amax[tid & 63]; if (lead) psc = bp.scale[c]; }
+    }
     double a0 = 0.0, a1 = 0.0;
     if (c < C && (MODE == 1 || training)) {
 #pragma unroll 4
@@ -358,32 +371,34 @@ __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
                 var = a1 * invM - mean * mean;
                 if (var < 0.0) var = 0.0;
                 if (running_mean) {
-                    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-                    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * unbias);
+                    running_mean[c] = (float)((1.0 - momentum) * prm + momentum * mean);
+                    running_var[c] = (float)((1.0 - momentum) * prv + momentum * var * unbias);
                 }
             } else {
-                mean = running_mean[c];
-                var = running_var[c];
+                mean = prm;
+                var = prv;
             }
             const float is = (float)(1.0 / sqrt(var + (double)eps));
             const float mu = (float)mean;
-            const float sc = gamma ? gamma[c] * is : is;
+            const float sc = gamma ? pg * is : is;
             o0[c] = mu; o1[c] = is; o2[c] = sc;
-            o3[c] = (beta ? beta[c] : 0.f) - mu * sc;
+            o3[c] = (beta ? pb : 0.f) - mu * sc;
         } else {
             // o0 = dgamma, o1 = dbeta, o2 = coef [2][C]
             const float sdz = (float)a0, sdzx = (float)a1;
-            if (o0) o0[c] = accumulate ? o0[c] + sdzx : sdzx;
-            if (o1) o1[c] = accumulate ? o1[c] + sdz : sdz;
+            if (o0) o0[c] = accumulate ? po0 + sdzx : sdzx;
+            if (o1) o1[c] = accumulate ? po1 + sdz : sdz;
             o2[c] = (float)(a0 * invM);
             o2[C + c] = (float)(a1 * invM);
         }
     }
     if (MODE == 1 && bp.out) {
-        const float dzmax = bound64(bp.dz_amax);                 // (every thread: the shuffles need whole waves)
+        float dzmax = pdz;                                       // (every thread: the shuffles need whole waves)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o, 64));
         float b = 0.f;
         if (part == 0 && c < C)
-            b = fabsf(bp.scale[c]) * (dzmax + fabsf((float)(r0[tid] * invM)) + fabsf((float)(r1[tid] * invM)) * bp.sqrtM);
+            b = fabsf(psc) * (dzmax + fabsf((float)(r0[tid] * invM)) + fabsf((float)(r1[tid] * invM)) * bp.sqrtM);
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
         if (tid == 0 && b > 0.f) atomicMax(bp.out + (blockIdx.x & 63), __float_as_uint(b));
