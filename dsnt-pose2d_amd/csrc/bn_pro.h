@@ -87,34 +87,44 @@ __device__ __forceinline__ void bn_pro_sums(const float* __restrict__ partial, i
 // scale / shift (its own workgroup's stores: visible after __syncthreads())
 template <int NT>
 __device__ __forceinline__ void bn_pro_forward(const BnProP& q, double* sh, bool writer) {
+    // (the affine parameters and the running statistics are fetched BEFORE the sums: behind them a load is a microsecond of every
+    // workgroup's prologue, i.e. of the dependency chain — elementwise.hip bn_finalize_kernel, round 5)
+    const int c = threadIdx.x;
+    float pg = 1.f, pb = 0.f, prm = 0.f, prv = 0.f;
+    if (c < q.C) {
+        if (q.gamma) pg = q.gamma[c];
+        if (q.beta) pb = q.beta[c];
+        if (writer && q.rmean) { prm = q.rmean[c]; prv = q.rvar[c]; }
+    }
     double a0, a1;
     bn_pro_sums<NT>(q.partial, q.tiles, q.C, sh, a0, a1);
-    const int c = threadIdx.x;
     if (c < q.C) {
         const double mean = a0 * q.invM;
         double var = a1 * q.invM - mean * mean;
         if (var < 0.0) var = 0.0;
         if (writer && q.rmean) {
-            q.rmean[c] = (float)((1.0 - q.momentum) * q.rmean[c] + q.momentum * mean);
-            q.rvar[c] = (float)((1.0 - q.momentum) * q.rvar[c] + q.momentum * var * q.unbias);
+            q.rmean[c] = (float)((1.0 - q.momentum) * prm + q.momentum * mean);
+            q.rvar[c] = (float)((1.0 - q.momentum) * prv + q.momentum * var * q.unbias);
         }
         const float is = (float)(1.0 / sqrt(var + (double)q.eps));
         const float mu = (float)mean;
-        const float sc = q.gamma ? q.gamma[c] * is : is;
+        const float sc = q.gamma ? pg * is : is;
         q.mean[c] = mu; q.invstd[c] = is; q.scale[c] = sc;
-        q.shift[c] = (q.beta ? q.beta[c] : 0.f) - mu * sc;
+        q.shift[c] = (q.beta ? pb : 0.f) - mu * sc;
     }
 }
 template <int NT>
 __device__ __forceinline__ void bn_pro_backward(const BnBwdProP& q, double* sh, bool writer) {
+    const int c = threadIdx.x;
+    float pdg = 0.f, pdb = 0.f;
+    if (c < q.C && writer && q.accumulate) { if (q.dgamma) pdg = q.dgamma[c]; if (q.dbeta) pdb = q.dbeta[c]; }
     double a0, a1;
     bn_pro_sums<NT>(q.partial, q.tiles, q.C, sh, a0, a1);
-    const int c = threadIdx.x;
     if (c < q.C) {
         if (writer) {
             const float sdz = (float)a0, sdzx = (float)a1;
-            if (q.dgamma) q.dgamma[c] = q.accumulate ? q.dgamma[c] + sdzx : sdzx;
-            if (q.dbeta) q.dbeta[c] = q.accumulate ? q.dbeta[c] + sdz : sdz;
+            if (q.dgamma) q.dgamma[c] = q.accumulate ? pdg + sdzx : sdzx;
+            if (q.dbeta) q.dbeta[c] = q.accumulate ? pdb + sdz : sdz;
         }
         q.coef[c] = (float)(a0 * q.invM);
         q.coef[q.C + c] = (float)(a1 * q.invM);

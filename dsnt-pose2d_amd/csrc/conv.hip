@@ -1020,6 +1020,28 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, __uint_as_float(f.b[q].w), acc, 0, 0, 0);
         }
     };
+    // the epilogue's operands (two rows per thread: rg, rg + 16 of column `col`) are fetched NOW, under the K loop: behind the
+    // reduction every one of them is a dependent load on a launch whose whole length is the dependency chain's (round 5, box N)
+    const int col = tid & 31, rg = tid >> 5;
+    const int n = ntile * 32 + col;
+    const bool vn = n < p.Cout;
+    const bool bnb = p.bnb_scale != nullptr;
+    float bias = 0.f, bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
+    if (!PRO) {
+        bias = (p.bias && vn) ? p.bias[n] : 0.f;
+        if (bnb && vn) { bsc = p.bnb_scale[n]; bsh = p.bnb_shift[n]; bmu = p.bnb_mean[n]; bis = p.bnb_invstd[n]; }
+    }
+    // (not in the variant with a BatchNorm prologue — the forward launches: it sits at 128 registers, and ten more are three waves per
+    // SIMD instead of four, one 512-thread workgroup per CU instead of two: hg2 +0.07 ms.  The data-gradient launches — mask operand and
+    // four BatchNorm-backward vectors in the epilogue — are the ones without a prologue)
+    float r1v[2] = {0.f, 0.f};
+    if (!PRO) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int mo = mtile * 32 + rg + 16 * j;
+            if (vn && mo < p.M && p.res1) r1v[j] = p.res1[(size_t)mo * p.Cout + n];
+        }
+    }
     if (c0 < c1) {
         // two chunks in flight beside the one being multiplied; three register sets in rotation (no copies)
         Frag f0 = load_next(), f1 = load_next(), f2;
@@ -1034,13 +1056,10 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) part[wave][(e & 3) + 8 * (e >> 2) + 4 * h][i] = acc[e];
     __syncthreads();
-    const int col = tid & 31, rg = tid >> 5;        // two rows per thread: rg, rg + 16
-    const int n = ntile * 32 + col;
-    const bool vn = n < p.Cout;
-    const bool bnb = p.bnb_scale != nullptr;
-    const float bias = (p.bias && vn) ? p.bias[n] : 0.f;
-    float bsc = 0.f, bsh = 0.f, bmu = 0.f, bis = 0.f;
-    if (bnb && vn) { bsc = p.bnb_scale[n]; bsh = p.bnb_shift[n]; bmu = p.bnb_mean[n]; bis = p.bnb_invstd[n]; }
+    if (PRO) {
+        bias = (p.bias && vn) ? p.bias[n] : 0.f;
+        if (bnb && vn) { bsc = p.bnb_scale[n]; bsh = p.bnb_shift[n]; bmu = p.bnb_mean[n]; bis = p.bnb_invstd[n]; }
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1052,13 +1071,13 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
         if (vn && mo < p.M) {
             const size_t o = (size_t)mo * p.Cout + n;
             if (bnb) {
-                const float xv = p.res1[o];
+                const float xv = PRO ? p.res1[o] : r1v[j];
                 if (p.bnb_relu && fmaf(xv, bsc, bsh) <= 0.f) v = 0.f;
                 p.y[o] = v;
                 s1 += v;
                 s2 = fmaf(v, (xv - bmu) * bis, s2);
             } else {
-                v += bias + (p.res1 ? p.res1[o] : 0.f) + (p.res2 ? p.res2[o] : 0.f);
+                v += bias + (PRO ? (p.res1 ? p.res1[o] : 0.f) : r1v[j]) + (p.res2 ? p.res2[o] : 0.f);
                 p.y[o] = v;
                 s1 += v;
                 s2 = fmaf(v, v, s2);
