@@ -33,7 +33,7 @@ int dsnt_device_cus(void) {
     return c;
 }
 
-extern "C" int dsnt_version(void) { return 112; }      // 112 (additive): dsnt_conv_dgrad_f16x3_stream_apply      // 110: dsnt_f16_prep_weights takes its row width; dsnt_conv1x1_bwd_*; 111 (additive): dsnt_conv1x1_fwd_*, DSNT_BN_FROZEN, dsnt_maxpool2_bwd_add
+extern "C" int dsnt_version(void) { return 113; }      // 113 (additive): dsnt_conv_fwd_stream_form      // 112 (additive): dsnt_conv_dgrad_f16x3_stream_apply      // 110: dsnt_f16_prep_weights takes its row width; dsnt_conv1x1_bwd_*; 111 (additive): dsnt_conv1x1_fwd_*, DSNT_BN_FROZEN, dsnt_maxpool2_bwd_add
 extern "C" const char* dsnt_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ launch lists

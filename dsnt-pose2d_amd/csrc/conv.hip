@@ -1592,6 +1592,7 @@ extern "C" int dsnt_conv_fwd_f16x3_stream(const float* x, const void* w_planes, 
                           stats_partial, g, bnb, tail, stream, a_bound, w_bound, true);
 }
 extern "C" int dsnt_conv_fwd_stream_ok(const dsnt_conv_geom* g) { return dsnt_conv3s_geom_ok(g) ? 1 : 0; }
+extern "C" int dsnt_conv_fwd_stream_form(const dsnt_conv_geom* g, int mode) { return dsnt_conv3s_form_of(g, mode); }
 
 // The data gradient of a 3x3 convolution whose OUTPUT feeds a train-mode BatchNorm, with that BatchNorm's backward folded into
 // the operand load (conv3s.hip MODE 4): instead of dL/dy the launch reads dz (the ReLU-masked, reduced gradient behind the

@@ -11,3 +11,6 @@ bool dsnt_conv3s_geom_ok(const dsnt_conv_geom* g);
 // share: the launch runs on a lane beside the dependency chain — fewer persistent workgroups, so that the chain's small
 // kernels find a CU with free LDS (two conv3s workgroups fill a CU's 160 KB)
 void dsnt_conv3s_launch(const ConvP& p, bool pro, hipStream_t st, bool share = false);
+// which form of the kernel the launch of `mode` (0 / 1 forward or plain data gradient, 3 BatchNorm-backward epilogue, 4 folded
+// BatchNorm backward) takes on this geometry: bit 0 column split, bit 1 the 16x16x32 form, bit 2 8 x 16 patches; -1: not conv3s's
+int dsnt_conv3s_form_of(const dsnt_conv_geom* g, int mode);

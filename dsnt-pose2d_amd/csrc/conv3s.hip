@@ -851,22 +851,33 @@ static int c3_split_tiles() {
     return m;
 }
 
+// the kernel form a launch takes — the ONE place that decides it (the launcher below and dsnt_conv3s_form, which lets a test ask
+// what ran): bit 0 column split (SP: two 64-column halves per patch), bit 1 the 16x16x32 form (MF), bit 2 8 x 16 patches
+static int c3_form(int cout, int mode, int N, int H, int W) {
+    const bool w32 = W % 32 == 0 && H % 4 == 0;
+    if (cout == 128 && mode != 4) {
+        const int ntiles = N * (H / (w32 ? 4 : 8)) * (W / (w32 ? 32 : 16));
+        if (ntiles <= c3_split_tiles()) return 1 | (w32 ? 0 : 4);
+    }
+    if (!w32) return 4;
+    if (cout == 128 && (c3_mf16_modes() & (mode == 4 ? 4 : mode == 3 ? 2 : 1))) return 2;
+    return 0;
+}
+
 template <int CO, bool PRO, int MODE>
 static void c3_launch_m(const ConvP& p, hipStream_t st, bool share) {
+    const int form = c3_form(CO, MODE, p.N, p.H, p.W);
     if constexpr (CO == 128 && MODE != 4) {
-        const bool w32 = p.W % 32 == 0 && p.H % 4 == 0;
-        const int ntiles = p.N * (p.H / (w32 ? 4 : 8)) * (p.W / (w32 ? 32 : 16));
-        if (ntiles <= c3_split_tiles()) {
-            if (w32) return c3_launch_k<64, PRO, MODE, 32, false, true>(p, st, share);
-            return c3_launch_k<64, PRO, MODE, 16, false, true>(p, st, share);
+        if (form & 1) {
+            if (form & 4) return c3_launch_k<64, PRO, MODE, 16, false, true>(p, st, share);
+            return c3_launch_k<64, PRO, MODE, 32, false, true>(p, st, share);
         }
     }
-    if (p.W % 32 == 0 && p.H % 4 == 0) {
-        if constexpr (CO == 128) {
-            if (c3_mf16_modes() & (MODE == 4 ? 4 : MODE == 3 ? 2 : 1)) return c3_launch_k<CO, PRO, MODE, 32, true>(p, st, share);
-        }
-        c3_launch_k<CO, PRO, MODE, 32, false>(p, st, share);
-    } else c3_launch_k<CO, PRO, MODE, 16, false>(p, st, share);
+    if constexpr (CO == 128) {
+        if (form & 2) return c3_launch_k<CO, PRO, MODE, 32, true>(p, st, share);
+    }
+    if (form & 4) c3_launch_k<CO, PRO, MODE, 16, false>(p, st, share);
+    else c3_launch_k<CO, PRO, MODE, 32, false>(p, st, share);
 }
 
 template <int CO>
@@ -883,4 +894,9 @@ static void c3_launch(const ConvP& p, bool pro, hipStream_t st, bool share) {
 void dsnt_conv3s_launch(const ConvP& p, bool pro, hipStream_t st, bool share) {
     if (p.Cout == 128) c3_launch<128>(p, pro, st, share);
     else c3_launch<64>(p, pro, st, share);
+}
+
+int dsnt_conv3s_form_of(const dsnt_conv_geom* g, int mode) {
+    if (!dsnt_conv3s_geom_ok(g) || mode < 0 || mode > 4 || mode == 2) return -1;
+    return c3_form(g->Cout, mode, g->N, g->H, g->W);
 }

@@ -186,6 +186,7 @@ PLAIN = {
     'dsnt_conv_wgrad_splits': (I, [GP]),
     'dsnt_conv_wgrad_halo_ok': (I, [GP]),
     'dsnt_conv_fwd_stream_ok': (I, [GP]),
+    'dsnt_conv_fwd_stream_form': (I, [GP, I]),
     'dsnt_conv_dgrad_strided_ok': (I, [GP]),
     'dsnt_conv_dgrad_strided_tiles': (I, [GP]),
     'dsnt_conv_fwd_pro_ok': (I, [GP, I, I]),

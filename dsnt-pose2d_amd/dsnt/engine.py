@@ -414,6 +414,12 @@ class Tape:
             first = next((i for i in range(pos + len(prep), len(self.fwd))
                           if self.fwd[i][0] is not None and self.fwd[i][2] in self._PREP_CONSUMERS
                           and id(self.fwd[i]) not in self._prep_exempt), len(self.fwd))
+            if relay is not None:
+                # the relay lane is taken to be idle up to here: an op (or a wait) traced onto it before `first` would put the main
+                # lane behind that op without anyone noticing — refuse at trace time instead
+                for ent in self.fwd[pos + len(prep):first]:
+                    busy = ent[3] == relay if ent[0] is not None else (ent[2] == 'sync' and relay in ent[1][:2])
+                    assert not busy, 'prep relay lane %d is in use before the first prep consumer (%s)' % (relay, ent[2])
             self.fwd.insert(first, (None, (side if relay is None else relay, 0, torch.cuda.Event()), 'sync', 0))
 
     def _use6(self, g):
@@ -1026,18 +1032,20 @@ class Tape:
         y.fold_ok = fuse1 and normed and res1 is None and res2 is None
         # the same for a 3x3 convolution on the persistent fp16x3 kernel (conv2 of a Bottleneck: bn3's backward rides in the operand
         # load of conv2's data gradient, csrc/conv3s.hip MODE 4), from DSNT_X_FOLD3_ROWS output rows
+        # (the predicate is the one emit_dgrad's fp16x3 stream branch needs — `d16 and d_stream and not native` — so that a geometry
+        # that branch refuses is decided HERE, while the consumer BatchNorm can still be told to apply by itself)
+        gd3 = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, p.dil * (p.R - 1) - p.pad, p.dil)
         fold3_ok = bool(self.fold3 and self.bwd1 and normed and self.training and res1 is None and res2 is None and slot is not None and
                         self.use_f16x3 and self.defer_reduce and p.R == 3 and p.S == 3 and p.stride == 1 and use16 and
-                        y.M >= self.fold3_rows and
-                        self.stream_ok(p, ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, p.dil * (p.R - 1) - p.pad, p.dil),
-                                       x.M, None))
+                        y.M >= self.fold3_rows and self._use6(gd3) and self.stream_ok(p, gd3, x.M, None))
         y.fold_ok = y.fold_ok or fold3_ok
 
         def backward():
             gy = y.grad
             ap = y.pending_apply
             fused = fuse1 and self.dgrad_planes16 is not None
-            fold3 = bool(fold3_ok and ap is not None and gy is None and self.dgrad_planes16 is not None and need_input_grad)
+            fold3 = bool(fold3_ok and ap is not None and gy is None and self.dgrad_planes16 is not None and need_input_grad and
+                         ap['bound'] is not None)
             if ap is not None and (not fused or gy is not None) and not fold3:
                 self.materialize_apply(y)
                 ap, gy = None, y.grad
@@ -1204,107 +1212,106 @@ class Tape:
                 def emit_dgrad():
                     if not need_input_grad:
                         return
-                    if True:
-                        nw = p.w.numel()
-                        pad_d = p.dil * (p.R - 1) - p.pad
-                        assert pad_d >= 0, 'data gradient needs pad <= dil * (R - 1)'
-                        native = p.stride != 1 and slot is not None and self.lib.dsnt_conv_dgrad_strided_ok(C.byref(g))
-                        if p.stride == 1:
-                            gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
-                        elif native:
-                            # strided convolution (ResNet stage transitions): dsnt_conv_dgrad_strided computes the pixels of dX
-                            # phase by phase straight from dY (csrc/dgrad_up.hip)
-                            gd = None
+                    nw = p.w.numel()
+                    pad_d = p.dil * (p.R - 1) - p.pad
+                    assert pad_d >= 0, 'data gradient needs pad <= dil * (R - 1)'
+                    native = p.stride != 1 and slot is not None and self.lib.dsnt_conv_dgrad_strided_ok(C.byref(g))
+                    if p.stride == 1:
+                        gd = ConvGeom(x.N, g.Ho, g.Wo, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
+                    elif native:
+                        # strided convolution (ResNet stage transitions): dsnt_conv_dgrad_strided computes the pixels of dX
+                        # phase by phase straight from dY (csrc/dgrad_up.hip)
+                        gd = None
+                    else:
+                        # ... or, for the shapes that kernel refuses: the stride-1 data gradient of dY with stride-1
+                        # zeros stuffed between the pixels
+                        Hs = x.H + 2 * p.pad - p.dil * (p.R - 1)
+                        Ws = x.W + 2 * p.pad - p.dil * (p.S - 1)
+                        stuffed = self.scratch('stuffed', x.N * Hs * Ws * p.Cout).view(-1)[:x.N * Hs * Ws * p.Cout]
+                        self.b('dsnt_zero_insert', gy, stuffed, x.N, g.Ho, g.Wo, p.Cout, Hs, Ws, p.stride)
+                        gy_d = stuffed
+                        gd = ConvGeom(x.N, Hs, Ws, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
+                    if slot is not None:
+                        wd = self.dgrad_f32[slot:slot + nw]
+                        wq, wq_stride = self.dgrad_planes[slot:slot + nw], self.dgrad_total
+                        d6 = gd is not None and self._use6(gd)
+                    else:       # stand-alone use without a parameter arena
+                        wd = self.scratch('wdgrad', nw)
+                        self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
+                        d6 = self._use6(gd) and nw % 8 == 0
+                        if d6:
+                            wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
+                            self.b('dsnt_split_bf16x3', wd, wq, nw)
+
+                    gsrc = gy if (p.stride == 1 or native) else gy_d
+
+                    g_amax = y.grad_amax if (self.use_f16x3 and p.stride == 1) else None
+                    d16 = d6 and g_amax is not None and slot is not None and self.dgrad_planes16 is not None
+                    if d16:
+                        wq16 = self.dgrad_planes16[slot:slot + nw]
+                        wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
+                        # (the data gradient's filter is [Cin][3][3][Cout]: its "Cout" is this convolution's Cin)
+                        d_stream = self.stream_ok(p, gd, x.M, None)
+                        self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total] +
+                                                 ([p.Cin, p.Cout] if d_stream else [0, 0]))
+
+                    def dgrad(out, res, part=None, bnb=None, tail=None):
+                        if native:
+                            self.b('dsnt_conv_dgrad_strided', gy, wd, out, res, part, g, bnb, tail)
+                        elif d16:
+                            e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
+                                       self.dgrad_total, wbd, g_amax, None, out, None,
+                                       None, 2 if ((d_stream or p.R == 1) and self.lane != 0 and self.conv_share) else 0, res, None, part, gd, bnb, tail)
+                            self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
+                        elif d6:
+                            self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
+                                   part, gd, bnb, tail)
                         else:
-                            # ... or, for the shapes that kernel refuses: the stride-1 data gradient of dY with stride-1
-                            # zeros stuffed between the pixels
-                            Hs = x.H + 2 * p.pad - p.dil * (p.R - 1)
-                            Ws = x.W + 2 * p.pad - p.dil * (p.S - 1)
-                            stuffed = self.scratch('stuffed', x.N * Hs * Ws * p.Cout).view(-1)[:x.N * Hs * Ws * p.Cout]
-                            self.b('dsnt_zero_insert', gy, stuffed, x.N, g.Ho, g.Wo, p.Cout, Hs, Ws, p.stride)
-                            gy_d = stuffed
-                            gd = ConvGeom(x.N, Hs, Ws, p.Cout, x.H, x.W, p.Cin, p.R, p.S, 1, pad_d, p.dil)
-                        if slot is not None:
-                            wd = self.dgrad_f32[slot:slot + nw]
-                            wq, wq_stride = self.dgrad_planes[slot:slot + nw], self.dgrad_total
-                            d6 = gd is not None and self._use6(gd)
-                        else:       # stand-alone use without a parameter arena
-                            wd = self.scratch('wdgrad', nw)
-                            self.b('dsnt_conv_pack_dgrad', p.w, wd, p.Cout, p.R, p.S, p.Cin)
-                            d6 = self._use6(gd) and nw % 8 == 0
-                            if d6:
-                                wq, wq_stride = self.scratch_bf16('wdgrad6', 3 * nw), nw
-                                self.b('dsnt_split_bf16x3', wd, wq, nw)
-
-                        gsrc = gy if (p.stride == 1 or native) else gy_d
-
-                        g_amax = y.grad_amax if (self.use_f16x3 and p.stride == 1) else None
-                        d16 = d6 and g_amax is not None and slot is not None and self.dgrad_planes16 is not None
-                        if d16:
-                            wq16 = self.dgrad_planes16[slot:slot + nw]
-                            wbd = self.dgrad_bounds[64 * slot_k:64 * slot_k + 64]
-                            # (the data gradient's filter is [Cin][3][3][Cout]: its "Cout" is this convolution's Cin)
-                            d_stream = self.stream_ok(p, gd, x.M, None)
-                            self._f16_dw_rows.append([wd.data_ptr(), wq16.data_ptr(), wbd.data_ptr(), nw, self.dgrad_total] +
-                                                     ([p.Cin, p.Cout] if d_stream else [0, 0]))
-
-                        def dgrad(out, res, part=None, bnb=None, tail=None):
-                            if native:
-                                self.b('dsnt_conv_dgrad_strided', gy, wd, out, res, part, g, bnb, tail)
-                            elif d16:
-                                e = self.b('dsnt_conv_fwd_f16x3_stream' if d_stream else 'dsnt_conv_fwd_f16x3_ex', gsrc, wq16,
-                                           self.dgrad_total, wbd, g_amax, None, out, None,
-                                           None, 2 if ((d_stream or p.R == 1) and self.lane != 0 and self.conv_share) else 0, res, None, part, gd, bnb, tail)
-                                self.f16_uses.append((e, dict(kind='dgrad', name=name, g=gsrc, g_bound=g_amax, w=wd, w_bound=wbd)))
-                            elif d6:
-                                self.b('dsnt_conv_fwd_bf16x6_ex', gsrc, wq, wq_stride, None, out, None, None, 0, res, None,
-                                       part, gd, bnb, tail)
-                            else:
-                                self.b('dsnt_conv_fwd_ex', gsrc, wd, None, out, None, None, 0, res, None, part, gd, bnb, tail)
-                        if normed:
-                            # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
-                            # data-gradient epilogue; only finalise + apply remain as separate launches
-                            # (fold: the 1x1 convolution that produced x forms this BatchNorm's dx in its own backward — dz then has
-                            # to outlive this op's launches, and its maximum is what the bound of dx is made from)
-                            fold = not native and self.fold_ok(src)
-                            dz = self.empty(x.M * x.C) if fold else self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
-                            if native:
-                                tiles = self.lib.dsnt_conv_dgrad_strided_tiles(C.byref(g))
-                            else:
-                                bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
-                                tiles = (x.M + bm - 1) // bm
-                            part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
-                            bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
-                                                _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
-                            tl, dz_amax = None, None
-                            if fold:
-                                tl, dz_amax = BnTail(), self.amax_slot()
-                                tl.amax = dz_amax.data_ptr()
-                            if fold3:
-                                assert d16 and d_stream and not native
-                                n2 = ap['n']
-                                aps = BnBwdApply(_lib.ptr(y.buf), _lib.ptr(n2.scale), _lib.ptr(n2.mean), _lib.ptr(n2.invstd), _lib.ptr(ap['coef']))
-                                shr = 2 if (self.lane != 0 and self.conv_share) else 0
-                                e = self.b('dsnt_conv_dgrad_f16x3_stream_apply', ap['dz'], aps, gy, wq16, self.dgrad_total, wbd, ap['bound'],
-                                           dz, part, shr, gd, bnb, tl)
-                                nb = 4 * y.buf.numel()          # (the tensor named inside the struct)
-                                self.bytes_bwd += nb
-                                self.bytes_by_name['dsnt_conv_dgrad_f16x3_stream_apply'] = self.bytes_by_name.get('dsnt_conv_dgrad_f16x3_stream_apply', 0) + nb
-                                self.f16_uses.append((e, dict(kind='dgrad', name=name, w=wd, w_bound=wbd, g_bound=ap['bound'],
-                                                              g_apply=dict(dz=ap['dz'], y=y.buf, scale=n2.scale, mean=n2.mean,
-                                                                           invstd=n2.invstd, coef=ap['coef']))))
-                            else:
-                                dgrad(dz, None, part, bnb, tl)
-                            self._norm_backward(src, dz, reduced=(part, tiles), dz_amax=dz_amax)
+                            self.b('dsnt_conv_fwd_ex', gsrc, wd, None, out, None, None, 0, res, None, part, gd, bnb, tail)
+                    if normed:
+                        # the ReLU mask and the two per-channel sums of the BatchNorm backward ride in the
+                        # data-gradient epilogue; only finalise + apply remain as separate launches
+                        # (fold: the 1x1 convolution that produced x forms this BatchNorm's dx in its own backward — dz then has
+                        # to outlive this op's launches, and its maximum is what the bound of dx is made from)
+                        fold = not native and self.fold_ok(src)
+                        dz = self.empty(x.M * x.C) if fold else self.scratch('da', x.M * x.C).view(-1)[:x.M * x.C]
+                        if native:
+                            tiles = self.lib.dsnt_conv_dgrad_strided_tiles(C.byref(g))
                         else:
-                            # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
-                            buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16, base_ok=True)
-                            base = self.take_base()         # (x's gradient continues one it does not own: the residual operand)
-                            tl = None
-                            if x.grad_amax is not None:
-                                tl = BnTail()
-                                tl.amax = x.grad_amax.data_ptr()
-                            dgrad(buf, base if base is not None else (buf if acc else None), tail=tl)
+                            bm = 128 if d6 else self.lib.dsnt_conv_fwd_bm(C.byref(gd))
+                            tiles = (x.M + bm - 1) // bm
+                        part = self.scratch('bnpart', tiles * 2 * x.C).view(-1)
+                        bnb = BnBwdEpilogue(_lib.ptr(x.buf), _lib.ptr(src.scale), _lib.ptr(src.shift),
+                                            _lib.ptr(src.mean), _lib.ptr(src.invstd), 1 if src.relu else 0)
+                        tl, dz_amax = None, None
+                        if fold:
+                            tl, dz_amax = BnTail(), self.amax_slot()
+                            tl.amax = dz_amax.data_ptr()
+                        if fold3:
+                            assert d16 and d_stream and not native
+                            n2 = ap['n']
+                            aps = BnBwdApply(_lib.ptr(y.buf), _lib.ptr(n2.scale), _lib.ptr(n2.mean), _lib.ptr(n2.invstd), _lib.ptr(ap['coef']))
+                            shr = 2 if (self.lane != 0 and self.conv_share) else 0
+                            e = self.b('dsnt_conv_dgrad_f16x3_stream_apply', ap['dz'], aps, gy, wq16, self.dgrad_total, wbd, ap['bound'],
+                                       dz, part, shr, gd, bnb, tl)
+                            nb = 4 * y.buf.numel()          # (the tensor named inside the struct)
+                            self.bytes_bwd += nb
+                            self.bytes_by_name['dsnt_conv_dgrad_f16x3_stream_apply'] = self.bytes_by_name.get('dsnt_conv_dgrad_f16x3_stream_apply', 0) + nb
+                            self.f16_uses.append((e, dict(kind='dgrad', name=name, w=wd, w_bound=wbd, g_bound=ap['bound'],
+                                                          g_apply=dict(dz=ap['dz'], y=y.buf, scale=n2.scale, mean=n2.mean,
+                                                                       invstd=n2.invstd, coef=ap['coef']))))
+                        else:
+                            dgrad(dz, None, part, bnb, tl)
+                        self._norm_backward(src, dz, reduced=(part, tiles), dz_amax=dz_amax)
+                    else:
+                        # (d6: the large-tile kernels; their epilogue can leave max|written gradient| as the next bound)
+                        buf, acc = self.grad_target(x, amax=(bool(d6) or bool(native)) and self.raw_f16, base_ok=True)
+                        base = self.take_base()         # (x's gradient continues one it does not own: the residual operand)
+                        tl = None
+                        if x.grad_amax is not None:
+                            tl = BnTail()
+                            tl.amax = x.grad_amax.data_ptr()
+                        dgrad(buf, base if base is not None else (buf if acc else None), tail=tl)
 
                 if fold3:
                     emit_dgrad()

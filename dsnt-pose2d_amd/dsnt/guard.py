@@ -34,12 +34,16 @@ class NanGuard:
         self.host = torch.zeros(2, dtype=torch.int32).pin_memory()
         self.event = None
         self.steps_checked = 0
+        self.checks_enqueued = 0        # host count of check() calls (the same sequence on every rank of a data-parallel job)
+        self.pre_update = None          # dsnt.parallel.DataParallel: exchanges the flag again if a check came after backward
 
     def check(self, loss):
         """Enqueue the non-finite test of `loss` (scalar or any fp32 tensor) on the current stream.
         Under dsnt.parallel.DataParallel call it before `loss.backward()` returns (the reference checks right after
         forward_loss: train.py:360): the flag is exchanged between the ranks once per backward, in the reducer's wait()
-        just before the gradients are published; a check enqueued after that would stay rank-local for this step."""
+        just before the gradients are published; a check enqueued after that is exchanged once more by the optimiser's
+        `pre_update` hook (a second small collective in front of the update — the price of checking late)."""
+        self.checks_enqueued += 1
         x = loss.detach()
         if x.dtype != torch.float32:
             x = x.float()

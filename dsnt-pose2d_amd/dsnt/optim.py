@@ -63,6 +63,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
         return self.runner.arena.logical(self.flat_state, key) if kind == 'arena' else self.extra_state[key]
 
     def _gather_grads(self):
+        if self.guard is not None and self.guard.pre_update is not None:
+            self.guard.pre_update()           # data-parallel: a check enqueued after backward() is exchanged before the update
         arena = self.runner.arena
         if arena.grads_published():           # the common case: every p.grad is the arena's own view
             return
@@ -100,19 +102,28 @@ class _FlatOptimizer(torch.optim.Optimizer):
         # Index order.  'model' (what this class writes) and NO marker (what torch.optim writes: bin/train.py:364,492 checkpoints
         # optimizer.state_dict()) both mean model.parameters() order.  A checkpoint of a dsnt.optim revision before round 3
         # numbered the parameters in ARENA order and carries no marker either — it cannot be told from torch's, so it has to be
-        # re-tagged by hand (param_groups[0]['dsnt_order'] = 'arena') and is then re-numbered here; anything else is refused.
+        # re-tagged by hand (param_groups[0]['dsnt_order'] = 'arena', or order='arena') and is then re-numbered here; a marker-less
+        # state that LOOKS like one (below) loads in model order with a warning; an unknown marker is refused.
         if order is None:
             order = groups[0].get('dsnt_order')
             if order is None:
                 order = 'model'
-                # torch.optim's own param_groups carry keys this class never wrote ('foreach', 'maximize', ...): a marker-less
-                # state WITHOUT them was written by a dsnt.optim revision before round 3, i.e. in arena order — it would load
-                # silently with the state of equal-shaped parameters permuted, which no shape check can see
-                if not any(k in groups[0] for k in ('foreach', 'maximize', 'capturable', 'differentiable')):
+                # What told the two apart before — keys of a modern torch.optim ('foreach', 'maximize', ...) — is absent from the
+                # checkpoints of the reference's own torch 0.3 as well, and those are the ones most likely to arrive here; a warning
+                # nudging THEM towards order='arena' would permute equal-shaped state.  What a pre-round-3 dsnt.optim state always
+                # carried and torch.optim of any age never did: per-entry 'step' stored as a 0-d float TENSOR together with an
+                # entry for EVERY parameter from step 0 on (torch 0.3: python int steps; torch >= 1.12: entries only for
+                # parameters that had a gradient, plus 'foreach' & co. in the group)
+                st0 = state_dict.get('state', {})
+                looks_old_dsnt = bool(st0) and len(st0) == len(self._where) and all(
+                    torch.is_tensor(e.get('step')) and e['step'].dim() == 0 and e['step'].dtype == torch.float32
+                    for e in st0.values()) and not any(
+                    k in groups[0] for k in ('foreach', 'maximize', 'capturable', 'differentiable'))
+                if looks_old_dsnt:
                     import warnings
-                    warnings.warn("dsnt.optim: the loaded state has no 'dsnt_order' marker and does not look like a torch.optim "
-                                  "state dict; taking its indices as model.parameters() order.  If it was written by a dsnt.optim "
-                                  "revision before round 3 (arena order), load it with load_state_dict(state, order='arena')",
+                    warnings.warn("dsnt.optim: the loaded state has no 'dsnt_order' marker and has the shape of a dsnt.optim state "
+                                  "written before round 3 (arena order); taking its indices as model.parameters() order.  If it "
+                                  "was written by such a revision, load it with load_state_dict(state, order='arena')",
                                   stacklevel=2)
         if order == 'arena':
             pos = {name: i for i, (name, _, _, _) in enumerate(self.runner.arena.slots)}

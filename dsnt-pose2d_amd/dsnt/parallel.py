@@ -41,10 +41,14 @@ class GradientAllReducer:
         # the non-finite guard's device flag (dsnt.guard.NanGuard.flag, int32): exchanged with MAX in `wait()` — after the last
         # bucket, before the gradients are published — so that EVERY rank takes the same skip decision in the optimiser kernels:
         # a NaN loss on one rank stops the whole job's update, as the reference's single process stops itself
-        # (bin/train.py:360-371).  In wait(), not beside the first bucket: `guard.check(loss)` may be enqueued before OR after
-        # `loss.backward()` and is covered either way (the collective is ordered after everything on the publishing stream);
-        # it queues right behind the last bucket's all-reduce, one small message
+        # (bin/train.py:360-371).  In wait(), not beside the first bucket: `guard.check(loss)` may be enqueued any time UP TO THE END
+        # of `loss.backward()` (before it, as bin/train.py does, or from a hook during it) and is covered — the collective is ordered
+        # after everything on the publishing stream at that point; it queues right behind the last bucket's all-reduce, one small
+        # message.  A check enqueued AFTER backward() has returned stays rank-local for that step (one rank would skip, the others
+        # update): DataParallel's optimiser hook exchanges the flag once more in front of the update for that case (`sync_flag`)
         self.flag = flag
+        self.guard = None                   # (DataParallel: the NanGuard that owns `flag`, for `sync_flag`)
+        self.flag_checks_seen = None        # guard.checks_enqueued at the last exchange
         self.exposed_ms = []                # diagnostics (bench.py): host time spent waiting for the collectives, per backward
         self.time_waits = False
         self.pending = []
@@ -75,6 +79,7 @@ class GradientAllReducer:
         self.reduce_all(late=True)
         if self.world > 1 and self.flag is not None:
             self.pending.append(dist.all_reduce(self.flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+            self.flag_checks_seen = self.guard.checks_enqueued if self.guard is not None else None
         if self.time_waits and self.pending and self.flat.is_cuda and self.stream_ordered():
             # exposed communication: what the publishing stream still has to wait for once backward has been enqueued
             # (device time between two events around the waits; read by `exposed_comm_ms` after a synchronisation)
@@ -89,6 +94,15 @@ class GradientAllReducer:
                 w.wait()
         self.pending = []
         self.fired = set()
+
+    def sync_flag(self):
+        """The optimiser's `pre_update` hook: if `guard.check` was called since the flag's exchange in wait() — i.e. AFTER backward()
+        returned — exchange it once more, so that no rank updates while another skips.  The call counts are host-side and the same
+        on every rank (one program), so every rank takes this branch together."""
+        if self.world > 1 and self.flag is not None and self.guard is not None and \
+                self.guard.checks_enqueued != self.flag_checks_seen:
+            dist.all_reduce(self.flag, op=dist.ReduceOp.MAX, group=self.group)
+            self.flag_checks_seen = self.guard.checks_enqueued
 
     def stream_ordered(self):
         """The backend's Work.wait() blocks the current STREAM (nccl = RCCL), not the host (gloo): only then do two events
@@ -138,6 +152,9 @@ class DataParallel:
         guard = getattr(optimizer, 'guard', None)
         self.reducer = GradientAllReducer(arena.fresh, arena.bucket_bounds, group,
                                           flag=guard.flag if guard is not None else None)
+        if guard is not None:
+            self.reducer.guard = guard
+            guard.pre_update = self.reducer.sync_flag
         self.runner.bucket_hook = self.reducer.bucket_ready
         self.runner.before_publish = self.reducer.wait
         # gradients are published as the MEAN over ranks (works with any optimiser)
@@ -163,6 +180,8 @@ class DataParallel:
         self._hooks = []
         self.runner.bucket_hook = None
         self.runner.before_publish = None
+        if self.reducer.guard is not None:
+            self.reducer.guard.pre_update = None
         self.runner.arena.publish_scale = 1.0
 
     def sync_running_stats(self):

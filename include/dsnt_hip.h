@@ -261,6 +261,12 @@ int dsnt_conv_fwd_f16x3_stream(const float* x, const void* w_planes, int64_t pla
                                float* stats_partial, const dsnt_conv_geom* g, const dsnt_bn_bwd_epilogue* bnb,
                                const dsnt_out_bounds* tail, void* stream);
 int dsnt_conv_fwd_stream_ok(const dsnt_conv_geom* g);
+/* Introspection (tests' launch census): the form of the csrc/conv3s.hip kernel a stream launch of `mode` takes on geometry g with
+ * this process's tuning — mode 0 / 1: forward or plain data gradient (without / with res1), 3: with bnb, 4:
+ * dsnt_conv_dgrad_f16x3_stream_apply.  Bit 0: 128 output columns as two 64-column halves per patch (few patches), bit 1: the
+ * v_mfma_f32_16x16x32_f16 form with the LDS-DMA weight ring, bit 2: 8 x 16 pixel patches (W % 32 != 0).  -1: not a stream
+ * geometry.  (/root/reference/src/dsnt/hourglass.py:22-23,36-40 is what every form computes.)  dsnt_version() >= 113. */
+int dsnt_conv_fwd_stream_form(const dsnt_conv_geom* g, int mode);
 /* out[0..63] = bound slots whose maximum is max |src[i]|; dst = two fp16 planes (plane_stride elements apart) of src * pow2(bound). */
 int dsnt_amax(const float* src, int64_t n, float* out, void* stream);
 int dsnt_split_f16x2(const float* src, void* dst, int64_t n, int64_t plane_stride, const float* bound, void* stream);

@@ -25,19 +25,43 @@ B1_ROWS = [(128, 256), (256, 128), (128, 128), (64, 64), (128, 64), (256, 256)]
 
 def tape_report(models):
     """Launch census over the train-mode programs of `models`: bwd1 launches by (Cout, Cin, rows), how many carried a
-    folded BatchNorm backward (dsnt_bn_bwd_apply != NULL), fwd1 launches by shape."""
-    rep = {'bwd1': {}, 'bwd1_folded': {}, 'bwd1_raw': {}, 'fwd1': {}, 'names_bwd': {}}
+    folded BatchNorm backward (dsnt_bn_bwd_apply != NULL), fwd1 launches by shape; `c3`: the launches of csrc/conv3s.hip by
+    (list f / b, Cout, Cin, rows, MODE, form) — MODE 0 / 1 plain, 3 BatchNorm-backward epilogue, 4 folded BatchNorm backward
+    (`fold3`); form bit 0 column split, 1 the 16x16x32 form, 2 8 x 16 patches; `wgrad_after_fold3`: folded launches whose
+    dy_out a later weight-gradient launch names."""
+    rep = {'bwd1': {}, 'bwd1_folded': {}, 'bwd1_raw': {}, 'fwd1': {}, 'names_bwd': {}, 'c3': {}, 'wgrad_after_fold3': 0}
+
+    def c3(lib, e, g, mode, which):
+        # the library itself says which form of csrc/conv3s.hip this launch takes in this process (dsnt_conv_fwd_stream_form)
+        form = lib.dsnt_conv_fwd_stream_form(g, mode)
+        assert form >= 0, (e[2], mode)
+        go = g._obj
+        k = '%s,%d,%d,%d,%d,%d' % (which, go.Cout, go.Cin, go.N * go.Ho * go.Wo, mode, form)
+        rep['c3'][k] = rep['c3'].get(k, 0) + 1
     for m in models:
         root = m.hg if hasattr(m, 'hg') else m
         for prog in root._runner().programs.values():
             if not prog.record:
                 continue
             tape = prog.tape
+            lib = tape.lib
             folded = {id(e) for e, u in tape.f16_uses if u.get('kind') == 'bwd1' and 'g_apply' in u}
+            dy_out = {}
             for e in tape.bwd:
                 if e[0] is None:
                     continue
                 rep['names_bwd'][e[2]] = rep['names_bwd'].get(e[2], 0) + 1
+                if e[2] == 'dsnt_conv_fwd_f16x3_stream':          # a 3x3 data gradient: ..., res1 [10], res2, part, g, bnb, tail
+                    c3(lib, e, e[1][-3], 3 if e[1][-2] is not None else (1 if e[1][10] is not None else 0), 'b')
+                elif e[2] == 'dsnt_conv_dgrad_f16x3_stream_apply':   # dz, ap, dy_out [2], ..., g, bnb, tail
+                    c3(lib, e, e[1][-3], 4, 'b')
+                    dy_out[e[1][2]] = False          # (device pointers are plain ints on the tape)
+                elif dy_out:
+                    # the dL/dy a folded launch wrote has to be what a weight gradient reads next (hourglass.py:36-40: conv2's)
+                    for v in e[1]:
+                        if isinstance(v, int) and v in dy_out and 'wgrad' in e[2] and not dy_out[v]:
+                            dy_out[v] = True
+                            rep['wgrad_after_fold3'] += 1
                 if e[2] == 'dsnt_conv1x1_bwd_f16x3':
                     g = e[1][-1]._obj
                     k = '%d,%d,%d' % (g.Cout, g.Cin, g.N * g.H * g.W)
@@ -47,6 +71,8 @@ def tape_report(models):
                     if not e[1][0]._obj.scale:
                         rep['bwd1_raw'][k] = rep['bwd1_raw'].get(k, 0) + 1
             for e in tape.fwd:
+                if e[0] is not None and e[2] == 'dsnt_conv_fwd_f16x3_stream':
+                    c3(lib, e, e[1][-3], 1 if e[1][10] is not None else 0, 'f')
                 if e[0] is not None and e[2] == 'dsnt_conv1x1_fwd_f16x3':
                     g = e[1][-2]._obj
                     k = '%d,%d,%d' % (g.Cout, g.Cin, g.N * g.H * g.W)

@@ -151,6 +151,20 @@ def test_optimizer_state_dict_is_torch_format():
         assert all(torch.equal(a, b) for a, b in zip(opt2.extra_state, opt.extra_state))
         if cls is optim.RMSprop:
             assert opt2._steps == 3 and opt2.param_groups[0]['lr'] == 2.5e-4
+            # marker-less states: a checkpoint of the reference's torch 0.3 (python-int steps, none of modern torch's group keys)
+            # loads silently in model order; only the shape of a pre-round-3 dsnt.optim state (0-d float tensor steps, an entry
+            # for every parameter, no modern keys) draws the `order='arena'` hint
+            import warnings
+            legacy = {'state': {i: {'step': 3, key: e[key]} for i, e in sd['state'].items()},
+                      'param_groups': [{'lr': 2.5e-4, 'alpha': 0.99, 'eps': 1e-8, 'weight_decay': 0, 'momentum': 0,
+                                        'centered': False, 'params': list(range(len(params)))}]}
+            with warnings.catch_warnings():
+                warnings.simplefilter('error')
+                cls(m, **kw).load_state_dict(legacy)
+                cls(m, **kw).load_state_dict(ref.state_dict())
+            old = {'state': sd['state'], 'param_groups': [{k: v for k, v in sd['param_groups'][0].items() if k != 'dsnt_order'}]}
+            with pytest.warns(UserWarning, match="order='arena'"):
+                cls(m, **kw).load_state_dict(old)
 
 
 def test_arena_survives_noop_apply_and_keeps_gradients():
@@ -175,3 +189,48 @@ def test_arena_survives_noop_apply_and_keeps_gradients():
     assert len(sig) == len(bns) == 53
     bns[-1].momentum = 0.5
     assert r._bn_signature() != sig
+
+
+def test_bench_starts_its_own_ranks_as_a_child_process(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` (the driver's command shape, no WORLD_SIZE in the environment) must launch
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD (never exec: a
+    process that may have touched the GPU must not be replaced), forward rank 0's JSON line and return the child's code."""
+    import importlib.util
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv('RANK', '3')
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    monkeypatch.setenv('MASTER_PORT', '1')
+    cmd, env = bench.launcher_command(8, ['--gpus', '8', '--steps', '5', '--warmup', '2'], 29517)
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert cmd[3:10] == ['--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1', '--master-port', '29517']
+    assert cmd[10] == os.path.join(root, 'bench.py') and cmd[11:] == ['--gpus', '8', '--steps', '5', '--warmup', '2']
+    assert env['MASTER_ADDR'] == '127.0.0.1' and env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert not any(k in env for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'))    # the launcher sets its own
+
+    # the forwarding: a stand-in child that prints noise + a JSON line and exits 0 / a child that fails
+    calls = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        calls['cmd'] = cmd
+        out = 'NCCL version banner\n' + json.dumps({'metric': 'images/sec', 'value': 1.0, 'n_gpus': 2}) + '\n'
+        return subprocess.CompletedProcess(cmd, calls.get('rc', 0), stdout=out if not calls.get('rc') else 'boom\n')
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    sink = open(tmp_path / 'line.txt', 'w+')
+    monkeypatch.setattr(bench, '_JSON_OUT', sink)
+    assert bench.launch_ranks(2, ['--gpus', '2']) == 0
+    sink.seek(0)
+    lines = sink.read().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+    assert '--nproc-per-node' in calls['cmd'] and calls['cmd'][-2:] == ['--gpus', '2']
+    calls['rc'] = 7
+    assert bench.launch_ranks(2, ['--gpus', '2']) == 7
+    # ... and the source never replaces the process
+    src = open(os.path.join(root, 'bench.py')).read()
+    assert 'os.exec' not in src and 'execv' not in src.replace('never exec', '')
