@@ -32,7 +32,7 @@ def _newer(a, b):
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'bn_pro.h'), os.path.join(CSRC, 'conv_split.h'),
-            os.path.join(CSRC, 'wgrad3.h'), os.path.join(CSRC, 'gemm1.h'), os.path.join(CSRC, 'conv3s.h'), os.path.join(CSRC, 'bwd1.h'), os.path.join(CSRC, 'fwd1.h'), os.path.join(CSRC, 'stem4.h'),
+            os.path.join(CSRC, 'wgrad3.h'), os.path.join(CSRC, 'gemm1.h'), os.path.join(CSRC, 'conv3s.h'), os.path.join(CSRC, 'bwd1.h'), os.path.join(CSRC, 'fwd1.h'), os.path.join(CSRC, 'stem4.h'), os.path.join(CSRC, 'stage.h'), os.path.join(CSRC, 'ew_bodies.h'),
             os.path.join(HERE, '..', 'include', 'dsnt_hip.h'), os.path.join(HERE, '..', 'include', 'dsnt_hip_debug.h')]
     objs, jobs = [], []
     bdir = 'build' if not os.environ.get('DSNT_LIB_NAME') else 'build_' + os.path.splitext(os.environ['DSNT_LIB_NAME'])[0]

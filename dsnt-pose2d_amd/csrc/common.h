@@ -60,6 +60,21 @@ int dsnt_device_cus(void);
 #ifdef __HIPCC__
 #include <functional>
 void dsnt_record_launch(dsnt_list* l, int lane, std::function<void(hipStream_t)>&& fn);
+// (code, gx, gy, nt, params: what a launch that can join a persistent stage leaves besides the closure — stage.h; code 0: nothing)
+void dsnt_record_launch_op(dsnt_list* l, int lane, std::function<void(hipStream_t)>&& fn, int code, int gx, int gy, int nt,
+                           const void* params, size_t bytes);
+// a kernel whose ONLY argument is the parameter struct `p` (<= DSNT_STAGE_PARAM_BYTES, trivially copyable), 1-D or 2-D grid
+#define DSNT_LAUNCH_OP(code, kernel, grid, block, lds, stream, p)                                            \
+    do {                                                                                                     \
+        static_assert(sizeof(p) <= 496, "stage op parameter block");                                         \
+        const dim3 g_ = (grid), b_ = (block);                                                                \
+        if (dsnt_list* rec_ = dsnt_recording())                                                              \
+            dsnt_record_launch_op(rec_, (int)(intptr_t)(stream), [=](hipStream_t s_) {                       \
+                hipLaunchKernelGGL(kernel, g_, b_, lds, s_, p);                                              \
+            }, (code), (int)g_.x, (int)g_.y, (int)b_.x, &(p), sizeof(p));                                    \
+        else                                                                                                 \
+            hipLaunchKernelGGL(kernel, g_, b_, lds, (hipStream_t)(stream), p);                               \
+    } while (0)
 #define DSNT_LAUNCH(kernel, grid, block, lds, stream, ...)                                                   \
     do {                                                                                                     \
         if (dsnt_list* rec_ = dsnt_recording())                                                              \
@@ -108,7 +123,8 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red) {
 // max |value|: wave shuffles, four LDS floats, ONE fire-and-forget integer atomic on the float bits per workgroup,
 // slot = workgroup index mod 64 (order-independent: the result is bit-reproducible).
 // (`which` = 0 / 1: two commits in a row use separate LDS floats, so the second needs no barrier against the first)
-__device__ __forceinline__ void amax_commit(float am, unsigned* amax, int which = 0) {
+// (`wg`: the workgroup index that picks the slot — blockIdx.x unless a persistent stage passes the recorded launch's, stage.h)
+__device__ __forceinline__ void amax_commit(float am, unsigned* amax, int which = 0, int wg = -1) {
     __shared__ float amax_w2[32];
     float* amax_w = amax_w2 + 16 * which;
 #pragma unroll
@@ -118,7 +134,7 @@ __device__ __forceinline__ void amax_commit(float am, unsigned* amax, int which 
     if (threadIdx.x == 0) {
         const int nw = (blockDim.x + 63) >> 6;
         for (int w = 1; w < nw; ++w) am = fmaxf(am, amax_w[w]);
-        if (am > 0.f) atomicMax(amax + (blockIdx.x & 63), __float_as_uint(am));
+        if (am > 0.f) atomicMax(amax + ((wg < 0 ? (int)blockIdx.x : wg) & 63), __float_as_uint(am));
     }
 }
 __device__ __forceinline__ float block_max(float v, float* red) {

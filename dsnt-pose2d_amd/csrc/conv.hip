@@ -22,6 +22,7 @@
 #include "wgrad3.h"
 #include "gemm1.h"
 #include "conv3s.h"
+#include "stage.h"
 #include "stem4.h"
 #include <string.h>
 #include <stdlib.h>
@@ -929,19 +930,22 @@ static int check_geom(const dsnt_conv_geom* g, const char* who) {
 // 45 / 49 us, 3x3 512->512 at M = 512 51 / 43 / 41 us, the hourglass's 128-channel forms 18 / 16.5 / 18.8 us (CW = 32
 // holds 96 load registers: occupancy 3-4 waves per SIMD); resnet34 batch 8 5.18 / 5.02 / 5.05 ms per step, hg2 batch 32
 // 13.58 / 13.57 / 13.74 ms.  CW = 16 ships.  Needs Cin % CW == 0 (a chunk never straddles a filter tap); else CW = 8.
+// The kernel's body is a device function of a VIRTUAL workgroup index `vb`: the stand-alone launch passes blockIdx.x, the
+// persistent low-resolution stage (stage.h, the end of this file) walks the same indices from a loop — same instructions, same
+// summation order, bit-identical results.  `part`: 8 x 32 x 33 floats of LDS; `finalise`: false when THIS workgroup has already run
+// the prologue's finalisation for this launch (a stage workgroup that takes a second tile: the vectors are in memory).
 template <bool PRO, int CW>
-__global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
+__device__ __forceinline__ void conv_ksplit_body(const ConvP& p, const int vb, float (*part)[32][33], const bool finalise) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int NL = CW / 8;                      // 16-byte loads per operand, lane and chunk
-    __shared__ __attribute__((aligned(16))) float part[8][32][33];
     const int nt32 = (p.Cout + 31) >> 5;
-    const int ntile = blockIdx.x % nt32, mtile = blockIdx.x / nt32;
+    const int ntile = vb % nt32, mtile = vb / nt32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const unsigned OOB = 0xF0000000u;
-    if (PRO && p.pro.partial) {          // the A operand's BatchNorm is finalised here (bn_pro.h: bn_pro_forward)
-        bn_pro_forward<512>(p.pro, reinterpret_cast<double*>(&part[0][0][0]), blockIdx.x == 0);
+    if (PRO && p.pro.partial && finalise) {          // the A operand's BatchNorm is finalised here (bn_pro.h: bn_pro_forward)
+        bn_pro_forward<512>(p.pro, reinterpret_cast<double*>(&part[0][0][0]), vb == 0);
         __syncthreads();                 // this workgroup's stores to in_scale / in_shift are visible to its loads
     }
     // the BatchNorm vectors of the A operand live in LDS during the loop (in `part`, which is only written after it; Cin <=
@@ -1099,6 +1103,11 @@ __global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
         }
     }
 }
+template <bool PRO, int CW>
+__global__ __launch_bounds__(512) void conv_ksplit_kernel(ConvP p) {
+    __shared__ __attribute__((aligned(16))) float part[8][32][33];
+    conv_ksplit_body<PRO, CW>(p, blockIdx.x, part, true);
+}
 
 // rows up to which the K-split kernel replaces the 32 x 128 tiling (measured crossover: 2048)
 static long ksplit_rows() {
@@ -1176,8 +1185,9 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, floa
 #define KS_CW 16
 #endif
         if (p.Cin % KS_CW == 0) {
-            if (pro) DSNT_LAUNCH((conv_ksplit_kernel<true, KS_CW>), dim3(grid), dim3(512), 0, st, p);
-            else DSNT_LAUNCH((conv_ksplit_kernel<false, KS_CW>), dim3(grid), dim3(512), 0, st, p);
+            // (these two can join a persistent stage: stage.h)
+            if (pro) DSNT_LAUNCH_OP(KS_CW == 16 ? DSNT_ST_KSPLIT_PRO : DSNT_ST_NONE, (conv_ksplit_kernel<true, KS_CW>), dim3(grid), dim3(512), 0, st, p);
+            else DSNT_LAUNCH_OP(KS_CW == 16 ? DSNT_ST_KSPLIT : DSNT_ST_NONE, (conv_ksplit_kernel<false, KS_CW>), dim3(grid), dim3(512), 0, st, p);
         } else if (pro) DSNT_LAUNCH((conv_ksplit_kernel<true, 8>), dim3(grid), dim3(512), 0, st, p);
         else DSNT_LAUNCH((conv_ksplit_kernel<false, 8>), dim3(grid), dim3(512), 0, st, p);
     } else if (BM == 128 && BN == 128) launch_fwd<2, 2, 2, 2>(p, pro, st);
@@ -2716,4 +2726,90 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
                            p.splits, CK, p.Cout, accumulate);
     }
     DSNT_CHECK_LAUNCH("dsnt_conv_wgrad");
+}
+
+// =====================================================================================================================
+// The persistent low-resolution stage (stage.h): one launch for a run of small dependent launches of one lane.
+#include "ew_bodies.h"
+
+// Chip-wide barrier between two recorded launches: one lane per workgroup adds to the stage's counter with an agent-scope release
+// (the workgroup's stores are in L2 behind the __syncthreads and leave it with the release) and polls it with agent-scope acquire
+// loads (s_sleep between polls) until every workgroup has arrived; profiles/r02_grid_barrier.txt: 0.9 / 2.4 / 3.9 us for 16 / 64 /
+// 128 workgroups against a ~5 us launch boundary in the traced step.  The spin is BOUNDED: a workgroup that gives up raises the
+// stage's error word and every workgroup leaves the kernel — a wrong result the host can see, never a hung device.
+__device__ __forceinline__ bool stage_barrier(unsigned* sync, const unsigned want, int* s_abort) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned guard = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if ((++guard & 1023u) == 0 &&
+                (guard >= (1u << 21) || __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_abort = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();          // (scalar loads of the next launch's operands must not hit lines read before the barrier)
+    return *s_abort == 0;
+}
+
+__global__ __launch_bounds__(DSNT_STAGE_NT) void dsnt_stage_kernel(const DsntStageOp* __restrict__ ops, const int nops, unsigned* sync) {
+    __shared__ __attribute__((aligned(16))) float part[8][32][33];          // the K-split kernel's tile sums; the head of it serves the others
+    __shared__ int s_abort;
+    const int G = gridDim.x, wg = blockIdx.x;
+    if (threadIdx.x == 0) s_abort = 0;
+    __syncthreads();
+    for (int k = 0; k < nops; ++k) {
+        const DsntStageOp& op = ops[k];
+        const int code = op.code, gx = op.gx, gy = op.gy;
+        const int nvb = gx * gy;
+        bool first = true;
+        for (int vb = wg; vb < nvb; vb += G) {
+            __syncthreads();                                              // the previous virtual workgroup is done with the LDS
+            switch (code) {
+            case DSNT_ST_KSPLIT_PRO:
+                conv_ksplit_body<true, 16>(*reinterpret_cast<const ConvP*>(op.params), vb, part, first); break;
+            case DSNT_ST_KSPLIT:
+                conv_ksplit_body<false, 16>(*reinterpret_cast<const ConvP*>(op.params), vb, part, first); break;
+            case DSNT_ST_APPLY_FIXED:
+                bn_act_bwd_apply_body<true>(*reinterpret_cast<const BnApplyP*>(op.params), vb, nvb, reinterpret_cast<double*>(&part[0][0][0]), first); break;
+            case DSNT_ST_APPLY:
+                bn_act_bwd_apply_body<false>(*reinterpret_cast<const BnApplyP*>(op.params), vb, nvb, reinterpret_cast<double*>(&part[0][0][0]), first); break;
+            case DSNT_ST_TILE_POOL:
+                tile_op_stats_body<0>(*reinterpret_cast<const TileOpP*>(op.params), vb % gx, vb / gx, gy, &part[0][0][0]); break;
+            case DSNT_ST_TILE_UPADD:
+                tile_op_stats_body<1>(*reinterpret_cast<const TileOpP*>(op.params), vb % gx, vb / gx, gy, &part[0][0][0]); break;
+            case DSNT_ST_POOL_BWD:
+                maxpool2_bwd_body(*reinterpret_cast<const PoolBwdP*>(op.params), vb, nvb); break;
+            case DSNT_ST_UP_BWD:
+                upsample2_bwd_body(*reinterpret_cast<const UpBwdP*>(op.params), vb, nvb); break;
+            case DSNT_ST_FIN_FWD:
+                bn_finalize_body<0, DSNT_STAGE_NT>(*reinterpret_cast<const BnFinP*>(op.params), vb,
+                                                   reinterpret_cast<double*>(&part[0][0][0]), reinterpret_cast<double*>(&part[0][0][0]) + 256); break;
+            case DSNT_ST_FIN_BWD:
+                bn_finalize_body<1, DSNT_STAGE_NT>(*reinterpret_cast<const BnFinP*>(op.params), vb,
+                                                   reinterpret_cast<double*>(&part[0][0][0]), reinterpret_cast<double*>(&part[0][0][0]) + 256); break;
+            default: break;
+            }
+            first = false;
+        }
+        if (k + 1 < nops && !stage_barrier(sync, (unsigned)(k + 1) * (unsigned)G, &s_abort)) break;
+    }
+    // the last workgroup to leave hands the counters back as it found them (every workgroup is past its last poll by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned d = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == (unsigned)G - 1u) {
+            __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+void dsnt_stage_launch(const DsntStageOp* ops_dev, int nops, unsigned* sync_dev, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(dsnt_stage_kernel, dim3(grid), dim3(DSNT_STAGE_NT), 0, st, ops_dev, nops, sync_dev);
 }

@@ -8,8 +8,8 @@
 #include <string.h>
 #include "bn_pro.h"
 #include "conv_split.h"
-
-#define TILE_ROWS 128
+#include "ew_bodies.h"
+#include "stage.h"
 
 // Thread mapping of the tile kernels below, shared so that their sums stay bit-identical to each other: a workgroup
 // covers `cgs` float4 column groups x (256 / cgs) row lanes of one 128-row tile.  Large tensors: all columns in one
@@ -116,124 +116,6 @@ extern "C" int dsnt_bn_stats(const float* x, float* partial, int64_t M, int C, v
 // cost one more read of it: 18 launches per hg2 step).  OP 0: y = maxpool2(a) (+ arg-max byte), a is [N][2Ho][2Wo][C];
 // OP 1: y = a + upsample2(b), b is [N][Ho/2][Wo/2][C].  OP 2: y = relu?(a * bn_scale + bn_shift) (the stem's materialised
 // BatchNorm + ReLU, hourglass.py:157-159).  Ho, Wo: OUTPUT size.
-template <int OP>
-__global__ __launch_bounds__(256) void tile_op_stats_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                            float* __restrict__ y, unsigned char* __restrict__ idx,
-                                                            float* partial, int N, int Ho, int Wo, int C, int cgs,
-                                                            OutBoundsP tail, const float* __restrict__ bn_scale = nullptr,
-                                                            const float* __restrict__ bn_shift = nullptr, int bn_relu = 0) {
-    __shared__ __attribute__((aligned(16))) float red[256 * 8];
-    const int tid = threadIdx.x;
-    const int C4 = C >> 2;
-    const int rpar = 256 / cgs;
-    const int cg_l = tid % cgs, rl = tid / cgs;
-    const bool active = rl < rpar;
-    const long M = (long)N * Ho * Wo;
-    const long row0 = (long)blockIdx.x * TILE_ROWS;
-    const long row1 = row0 + TILE_ROWS < M ? row0 + TILE_ROWS : M;
-    float am = 0.f;                                  // max |written value| (tail.amax: fp16x3 bound of a raw consumer)
-    float am2 = 0.f;                                 // max |relu?(written value * scale + shift)| (tail.amax_bn)
-    const float am2lo = tail.amax_relu ? 0.f : -__builtin_inff();
-    for (int cg0 = blockIdx.y * cgs; cg0 < C4; cg0 += cgs * gridDim.y) {
-        const int cg = cg0 + cg_l;
-        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-        if (active && cg < C4) {
-            // batches of UB rows: every load of the batch is issued before the first use (a workgroup of a small level is
-            // pure latency), rows are then consumed in the same order as one by one — the sums stay bit-identical to
-            // tile_reduce_kernel<0>.  (Built WITHOUT the SLP vectoriser: see build.py.)
-#ifndef DSNT_TILE_UB
-#define DSNT_TILE_UB 1        // measured: 4 is no faster once small tensors use the 16-lane mapping
-#endif
-            constexpr int UB = DSNT_TILE_UB;
-            float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), bh = bs;
-            if (tail.amax_bn) {
-                bs = reinterpret_cast<const float4*>(tail.amax_scale)[cg];
-                bh = reinterpret_cast<const float4*>(tail.amax_shift)[cg];
-            }
-            for (long rb = row0 + rl; rb < row1; rb += (long)UB * rpar) {
-                float4 in[UB][OP == 0 ? 4 : 2];
-                float4 osc = make_float4(0.f, 0.f, 0.f, 0.f), osh = osc;
-                if (OP == 2) {
-                    osc = reinterpret_cast<const float4*>(bn_scale)[cg];
-                    osh = reinterpret_cast<const float4*>(bn_shift)[cg];
-                }
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const long r = rb + (long)u * rpar < row1 ? rb + (long)u * rpar : row1 - 1;     // clamped: never used
-                    const int ow = (int)(r % Wo);
-                    const long t = r / Wo;
-                    const int oh = (int)(t % Ho), n = (int)(t / Ho);
-                    if (OP == 0) {
-                        const int W = Wo * 2;
-                        const float4* base = reinterpret_cast<const float4*>(a) + (((long)n * (Ho * 2) + 2 * oh) * W + 2 * ow) * C4 + cg;
-                        in[u][0] = base[0]; in[u][1] = base[C4];
-                        in[u][OP == 0 ? 2 : 0] = base[(long)W * C4]; in[u][OP == 0 ? 3 : 1] = base[(long)W * C4 + C4];
-                    } else if (OP == 1) {
-                        in[u][0] = reinterpret_cast<const float4*>(a)[r * C4 + cg];
-                        in[u][1] = reinterpret_cast<const float4*>(b)[(((long)n * (Ho >> 1) + (oh >> 1)) * (Wo >> 1) + (ow >> 1)) * C4 + cg];
-                    } else {
-                        in[u][0] = reinterpret_cast<const float4*>(a)[r * C4 + cg];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const long r = rb + (long)u * rpar;
-                    if (r >= row1) break;
-                    float4 v;
-                    if (OP == 0) {
-                        const float4 v1 = in[u][1], v2 = in[u][OP == 0 ? 2 : 0], v3 = in[u][OP == 0 ? 3 : 1];
-                        v = in[u][0];
-                        uchar4 k = make_uchar4(0, 0, 0, 0);
-#define POOL_STEP(V, P)                                  \
-                        if (V.x > v.x || V.x != V.x) { v.x = V.x; k.x = P; } \
-                        if (V.y > v.y || V.y != V.y) { v.y = V.y; k.y = P; } \
-                        if (V.z > v.z || V.z != V.z) { v.z = V.z; k.z = P; } \
-                        if (V.w > v.w || V.w != V.w) { v.w = V.w; k.w = P; }
-                        POOL_STEP(v1, 1) POOL_STEP(v2, 2) POOL_STEP(v3, 3)
-#undef POOL_STEP
-                        reinterpret_cast<uchar4*>(idx)[r * C4 + cg] = k;
-                    } else if (OP == 1) {
-                        const float4 uu = in[u][0], l = in[u][1];
-                        v = make_float4(uu.x + l.x, uu.y + l.y, uu.z + l.z, uu.w + l.w);
-                    } else {
-                        const float4 xv = in[u][0];
-                        v = make_float4(fmaf(xv.x, osc.x, osh.x), fmaf(xv.y, osc.y, osh.y), fmaf(xv.z, osc.z, osh.z),
-                                        fmaf(xv.w, osc.w, osh.w));
-                        if (bn_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    }
-                    reinterpret_cast<float4*>(y)[r * C4 + cg] = v;
-                    am = fmaxf(fmaxf(am, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w))));
-                    if (tail.amax_bn)
-                        am2 = fmaxf(fmaxf(am2, fabsf(fmaxf(fmaf(v.x, bs.x, bh.x), am2lo))),
-                                    fmaxf(fabsf(fmaxf(fmaf(v.y, bs.y, bh.y), am2lo)),
-                                          fmaxf(fabsf(fmaxf(fmaf(v.z, bs.z, bh.z), am2lo)), fabsf(fmaxf(fmaf(v.w, bs.w, bh.w), am2lo)))));
-                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                    s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
-                    s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
-                }
-            }
-        }
-        if (!partial) continue;                       // eval mode: only the operand bound is wanted (uniform)
-        __syncthreads();
-        float* mine = red + tid * 8;
-        mine[0] = s1.x; mine[1] = s1.y; mine[2] = s1.z; mine[3] = s1.w;
-        mine[4] = s2.x; mine[5] = s2.y; mine[6] = s2.z; mine[7] = s2.w;
-        __syncthreads();
-        if (tid < cgs && cg0 + tid < C4) {
-            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int j = 0; j < rpar; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += red[(j * cgs + tid) * 8 + e];
-            float* p0 = partial + ((size_t)blockIdx.x * 2 + 0) * C + (size_t)(cg0 + tid) * 4;
-            float* p1 = partial + ((size_t)blockIdx.x * 2 + 1) * C + (size_t)(cg0 + tid) * 4;
-            *reinterpret_cast<float4*>(p0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            *reinterpret_cast<float4*>(p1) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        }
-    }
-    if (tail.amax) amax_commit(am, tail.amax);
-    if (tail.amax_bn) amax_commit(am2, tail.amax_bn, 1);
-}
-
 extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, float* partial, int N, int H, int W,
                                        int C, const dsnt_out_bounds* g_tail, void* stream) {
     OutBoundsP tail;
@@ -245,8 +127,8 @@ extern "C" int dsnt_maxpool2_fwd_stats(const float* x, float* y, uint8_t* idx, f
                  (((uintptr_t)idx) & 3) == 0, DSNT_ERR_ALIGN, "dsnt_maxpool2_fwd_stats: alignment");
     const long M = (long)N * (H / 2) * (W / 2);
     const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
-    DSNT_LAUNCH(tile_op_stats_kernel<0>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, nullptr, y, idx, partial, N, H / 2, W / 2, C, tile_cgs(tiles, C / 4), tail);
+    const TileOpP q{x, nullptr, y, idx, partial, N, H / 2, W / 2, C, tile_cgs(tiles, C / 4), tail, nullptr, nullptr, 0};
+    DSNT_LAUNCH_OP(DSNT_ST_TILE_POOL, tile_op_stats_kernel<0>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_fwd_stats");
 }
 
@@ -261,8 +143,8 @@ extern "C" int dsnt_upsample2_add_fwd_stats(const float* up, const float* low, f
                  dsnt_aligned16(partial), DSNT_ERR_ALIGN, "dsnt_upsample2_add_fwd_stats: alignment");
     const long M = (long)N * H * W;
     const long tiles = (M + TILE_ROWS - 1) / TILE_ROWS;
-    DSNT_LAUNCH(tile_op_stats_kernel<1>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, up, low, out, nullptr, partial, N, H, W, C, tile_cgs(tiles, C / 4), tail);
+    const TileOpP q{up, low, out, nullptr, partial, N, H, W, C, tile_cgs(tiles, C / 4), tail, nullptr, nullptr, 0};
+    DSNT_LAUNCH_OP(DSNT_ST_TILE_UPADD, tile_op_stats_kernel<1>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_upsample2_add_fwd_stats");
 }
 
@@ -276,9 +158,8 @@ extern "C" int dsnt_bn_act_fwd_stats(const float* x, const float* scale, const f
     const long tiles = ((long)M + TILE_ROWS - 1) / TILE_ROWS;
     // rows are flat here: N = 1, Ho = 1, Wo = M would overflow int for nothing — the kernel only needs M = N*Ho*Wo
     DSNT_REQUIRE(M < (1ll << 31), DSNT_ERR_SHAPE, "dsnt_bn_act_fwd_stats: M too large");
-    DSNT_LAUNCH(tile_op_stats_kernel<2>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, nullptr, y, nullptr, partial, 1, 1, (int)M, C, tile_cgs(tiles, C / 4), tail,
-                       scale, shift, relu);
+    const TileOpP q{x, nullptr, y, nullptr, partial, 1, 1, (int)M, C, tile_cgs(tiles, C / 4), tail, scale, shift, relu};
+    DSNT_LAUNCH_OP(DSNT_ST_NONE, tile_op_stats_kernel<2>, dim3((unsigned)tiles, tile_grid_y(tiles, C / 4)), dim3(256), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_bn_act_fwd_stats");
 }
 
@@ -310,101 +191,6 @@ extern "C" int dsnt_bn_add_act_bwd_reduce(const float* da, const float* y, const
     DSNT_CHECK_LAUNCH("dsnt_bn_add_act_bwd_reduce");
 }
 
-// Combine tile partials: 16 channels x 64 tile-lanes per 1024-thread block (the kernel is pure
-// latency: many independent loads in flight matter, not bandwidth), fp64 accumulation.
-// MODE 0: forward statistics.  MODE 1: backward sums.
-#ifndef FIN_T
-#define FIN_T 1024
-#endif
-#define FIN_P (FIN_T / 16)
-// MODE 1, optional: the bound of dx = scale (dz - coef0 - xhat coef1) for a consumer that forms dx in registers
-// (dsnt_conv1x1_bwd_f16x3): max_c |scale_c| (max|dz| + |coef0_c| + |coef1_c| sqrt(M)), |xhat| <= sqrt(M) for the batch
-// statistics of M samples; raised into the 64 slots of `out` like every other bound
-struct BnBoundP { const float* scale; const float* dz_amax; float sqrtM; unsigned* out; };
-template <int MODE>
-__global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(
-    const float* __restrict__ partial, int ntiles, double invM, double unbias, int C,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-    float* running_var, float momentum, float eps, int training, float* o0, float* o1, float* o2,
-    float* o3, int accumulate, BnBoundP bp) {
-    __shared__ double r0[FIN_T], r1[FIN_T];
-    const int tid = threadIdx.x, cl = tid & 15, part = tid >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    // everything the last step needs besides the sums is fetched NOW, under the row loop: the kernel's length is what a BatchNorm
-    // costs the dependency chain, and a load issued behind the reduction is a microsecond of it (round 5, box N)
-    const bool lead = part == 0 && c < C;
-    float pg = 1.f, pb = 0.f, prm = 0.f, prv = 0.f, po0 = 0.f, po1 = 0.f, psc = 0.f, pdz = 0.f;
-    if (MODE == 0 && lead) {
-        if (gamma) pg = gamma[c];
-        if (beta) pb = beta[c];
-        if (running_mean) { prm = running_mean[c]; prv = running_var[c]; }
-    }
-    if (MODE == 1) {
-        if (lead && accumulate) { if (o0) po0 = o0[c]; if (o1) po1 = o1[c]; }
-        if (bp.out) { pdz = bp.dz_amax[tid & 63]; if (lead) psc = bp.scale[c]; }
-    }
-    double a0 = 0.0, a1 = 0.0;
-    if (c < C && (MODE == 1 || training)) {
-#pragma unroll 4
-        for (int t = part; t < ntiles; t += FIN_P) {
-            a0 += (double)partial[((size_t)t * 2 + 0) * C + c];
-            a1 += (double)partial[((size_t)t * 2 + 1) * C + c];
-        }
-    }
-    // the four tile-lanes of a wave by shuffles, the waves through LDS, summed by the block's first 16 threads in a fixed order
-    // (deterministic; ONE barrier — a seven-level tree over 1024 threads cost the chain ~0.5 us per BatchNorm, round 5)
-    a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64);
-    a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
-    if ((tid & 63) < 16) { r0[(tid >> 6) * 16 + cl] = a0; r1[(tid >> 6) * 16 + cl] = a1; }
-    __syncthreads();
-    if (part == 0) {
-        a0 = 0.0; a1 = 0.0;
-#pragma unroll
-        for (int w = 0; w < FIN_T / 64; ++w) { a0 += r0[w * 16 + cl]; a1 += r1[w * 16 + cl]; }
-        r0[tid] = a0; r1[tid] = a1;         // (tid = cl < 16: read again by the bound below, same thread)
-    }
-    if (part == 0 && c < C) {
-        if (MODE == 0) {
-            double mean, var;
-            if (training) {
-                mean = a0 * invM;
-                var = a1 * invM - mean * mean;
-                if (var < 0.0) var = 0.0;
-                if (running_mean) {
-                    running_mean[c] = (float)((1.0 - momentum) * prm + momentum * mean);
-                    running_var[c] = (float)((1.0 - momentum) * prv + momentum * var * unbias);
-                }
-            } else {
-                mean = prm;
-                var = prv;
-            }
-            const float is = (float)(1.0 / sqrt(var + (double)eps));
-            const float mu = (float)mean;
-            const float sc = gamma ? pg * is : is;
-            o0[c] = mu; o1[c] = is; o2[c] = sc;
-            o3[c] = (beta ? pb : 0.f) - mu * sc;
-        } else {
-            // o0 = dgamma, o1 = dbeta, o2 = coef [2][C]
-            const float sdz = (float)a0, sdzx = (float)a1;
-            if (o0) o0[c] = accumulate ? po0 + sdzx : sdzx;
-            if (o1) o1[c] = accumulate ? po1 + sdz : sdz;
-            o2[c] = (float)(a0 * invM);
-            o2[C + c] = (float)(a1 * invM);
-        }
-    }
-    if (MODE == 1 && bp.out) {
-        float dzmax = pdz;                                       // (every thread: the shuffles need whole waves)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o, 64));
-        float b = 0.f;
-        if (part == 0 && c < C)
-            b = fabsf(psc) * (dzmax + fabsf((float)(r0[tid] * invM)) + fabsf((float)(r1[tid] * invM)) * bp.sqrtM);
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
-        if (tid == 0 && b > 0.f) atomicMax(bp.out + (blockIdx.x & 63), __float_as_uint(b));
-    }
-}
-
 extern "C" int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int C,
                                 const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, float momentum, float eps, int training,
@@ -417,9 +203,9 @@ extern "C" int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int
     DSNT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), DSNT_ERR_ARG,
                  "dsnt_bn_finalize: running_mean/var must be given together");
     const double unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
-    DSNT_LAUNCH(bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
-                       partial, ntiles, 1.0 / (double)M, unbias, C, gamma, beta, running_mean,
-                       running_var, momentum, eps, training, mean, invstd, scale, shift, 0, BnBoundP{nullptr, nullptr, 0.f, nullptr});
+    const BnFinP q{partial, ntiles, 1.0 / (double)M, unbias, C, gamma, beta, running_mean, running_var, momentum, eps, training,
+                   mean, invstd, scale, shift, 0, BnBoundP{nullptr, nullptr, 0.f, nullptr}};
+    DSNT_LAUNCH_OP(DSNT_ST_FIN_FWD, bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(FIN_T), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_bn_finalize");
 }
 
@@ -461,9 +247,9 @@ extern "C" int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M,
                  "dsnt_bn_bwd_finalize: bad argument");
     // DSNT_BN_FROZEN: the forward ran on fixed (running) statistics — dx = scale dz, both coefficients zero; dgamma / dbeta as always
     const double invM = (accumulate & DSNT_BN_FROZEN) ? 0.0 : 1.0 / (double)M;
-    DSNT_LAUNCH(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
-                       partial, ntiles, invM, 1.0, C, nullptr, nullptr, nullptr, nullptr,
-                       0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate & 1, BnBoundP{nullptr, nullptr, 0.f, nullptr});
+    const BnFinP q{partial, ntiles, invM, 1.0, C, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 1, dgamma, dbeta, coef, nullptr,
+                   accumulate & 1, BnBoundP{nullptr, nullptr, 0.f, nullptr}};
+    DSNT_LAUNCH_OP(DSNT_ST_FIN_BWD, bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize");
 }
 
@@ -475,10 +261,9 @@ extern "C" int dsnt_bn_bwd_finalize_bound(const float* partial, int ntiles, int6
                                           float* bound_out, void* stream) {
     DSNT_REQUIRE(partial && coef && scale && dz_amax && bound_out && ntiles > 0 && C > 0 && M > 0, DSNT_ERR_ARG,
                  "dsnt_bn_bwd_finalize_bound: bad argument");
-    DSNT_LAUNCH(bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, (hipStream_t)stream,
-                       partial, ntiles, 1.0 / (double)M, 1.0, C, nullptr, nullptr, nullptr, nullptr,
-                       0.f, 0.f, 1, dgamma, dbeta, coef, nullptr, accumulate,
-                       BnBoundP{scale, dz_amax, sqrtf((float)M), reinterpret_cast<unsigned*>(bound_out)});
+    const BnFinP q{partial, ntiles, 1.0 / (double)M, 1.0, C, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 1, dgamma, dbeta, coef, nullptr,
+                   accumulate, BnBoundP{scale, dz_amax, sqrtf((float)M), reinterpret_cast<unsigned*>(bound_out)}};
+    DSNT_LAUNCH_OP(DSNT_ST_FIN_BWD, bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize_bound");
 }
 
@@ -512,79 +297,6 @@ extern "C" int dsnt_bn_act_fwd(const float* x, const float* scale, const float* 
                        (const float4*)x, (const float4*)scale, (const float4*)shift, relu, (float4*)y,
                        n4, C / 4);
     DSNT_CHECK_LAUNCH("dsnt_bn_act_fwd");
-}
-
-// FIXED: the grid stride is a multiple of C/4, so a thread stays on ONE channel group — its six per-channel vectors are
-// loaded once instead of with every element (they were two thirds of the kernel's load instructions), and two elements are
-// in flight per iteration.  Same arithmetic, element for element.
-struct BnApplyVec { float4 sc, sh, mu, is, c0, c1; };
-__device__ __forceinline__ float4 bn_apply_one(const float4 g, const float4 xv, const BnApplyVec& v, int relu) {
-    float4 dz = g;
-    if (relu) {
-        if (fmaf(xv.x, v.sc.x, v.sh.x) <= 0.f) dz.x = 0.f;
-        if (fmaf(xv.y, v.sc.y, v.sh.y) <= 0.f) dz.y = 0.f;
-        if (fmaf(xv.z, v.sc.z, v.sh.z) <= 0.f) dz.z = 0.f;
-        if (fmaf(xv.w, v.sc.w, v.sh.w) <= 0.f) dz.w = 0.f;
-    }
-    float4 o;
-    o.x = v.sc.x * (dz.x - v.c0.x - (xv.x - v.mu.x) * v.is.x * v.c1.x);
-    o.y = v.sc.y * (dz.y - v.c0.y - (xv.y - v.mu.y) * v.is.y * v.c1.y);
-    o.z = v.sc.z * (dz.z - v.c0.z - (xv.z - v.mu.z) * v.is.z * v.c1.z);
-    o.w = v.sc.w * (dz.w - v.c0.w - (xv.w - v.mu.w) * v.is.w * v.c1.w);
-    return o;
-}
-template <bool FIXED>
-__global__ void bn_act_bwd_apply_kernel(const float4* __restrict__ da, const float4* __restrict__ x,
-                                        const float4* __restrict__ scale, const float4* __restrict__ shift,
-                                        const float4* __restrict__ mean, const float4* __restrict__ invstd,
-                                        const float4* coef, int relu, float4* dx,
-                                        const float4* base, long n4, int C4, unsigned* __restrict__ amax, BnBwdProP pro) {
-    // base: what the result is added to — null (dx = value), dx itself (accumulate in place) or ANOTHER tensor (dx = base + value:
-    // the gradient it continues stays intact for a reader that comes later, dsnt_bn_act_bwd_apply_base)
-    const bool accumulate = base != nullptr;
-    if (pro.partial) {                   // dsnt_bn_act_bwd_apply_pro: coef / dgamma / dbeta from the tile sums, here
-        __shared__ double pro_sh[256];
-        bn_pro_backward<256>(pro, pro_sh, blockIdx.x == 0);
-        __syncthreads();                 // this workgroup's stores to coef are visible to its loads below
-    }
-    float am = 0.f;
-    const long stride = (long)gridDim.x * blockDim.x;
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    auto vec = [&](int cg) {
-        BnApplyVec v;
-        v.sc = scale[cg]; v.sh = shift[cg]; v.mu = mean[cg]; v.is = invstd[cg]; v.c0 = coef[cg]; v.c1 = coef[C4 + cg];
-        return v;
-    };
-    auto amx = [&](const float4 o) { am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am); };
-    if (FIXED) {
-        const BnApplyVec v = vec((int)(i % C4));
-        for (; i + stride < n4; i += 2 * stride) {
-            const float4 g0 = da[i], x0 = x[i], g1 = da[i + stride], x1 = x[i + stride];
-            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-            if (accumulate) { p0 = base[i]; p1 = base[i + stride]; }
-            float4 o0 = bn_apply_one(g0, x0, v, relu), o1 = bn_apply_one(g1, x1, v, relu);
-            if (accumulate) {
-                o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
-                o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
-            }
-            dx[i] = o0; dx[i + stride] = o1;
-            amx(o0); amx(o1);
-        }
-        if (i < n4) {
-            float4 o = bn_apply_one(da[i], x[i], v, relu);
-            if (accumulate) { const float4 p = base[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-            dx[i] = o;
-            amx(o);
-        }
-    } else {
-        for (; i < n4; i += stride) {
-            float4 o = bn_apply_one(da[i], x[i], vec((int)(i % C4)), relu);
-            if (accumulate) { const float4 p = base[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-            dx[i] = o;
-            amx(o);
-        }
-    }
-    if (amax) amax_commit(am, amax);      // max |dx| for the fp16x3 consumers
 }
 
 static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* scale, const float* shift,
@@ -633,16 +345,12 @@ static int bn_act_bwd_apply_impl(const float* da, const float* x, const float* s
         // every workgroup re-reads the tile sums in its prologue: few, fat workgroups (these launches are latency-bound)
         if (grid > 128) grid = 128;
     }
+    const BnApplyP ap{(const float4*)da, (const float4*)x, (const float4*)scale, (const float4*)shift, (const float4*)mean,
+                      (const float4*)invstd, (const float4*)coef, relu, (float4*)dx, (const float4*)base, n4, C / 4, (unsigned*)amax, q};
     if (((long)grid * 256) % (C / 4) == 0)
-        DSNT_LAUNCH(bn_act_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0,
-                    (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
-                    (const float4*)shift, (const float4*)mean, (const float4*)invstd,
-                    (const float4*)coef, relu, (float4*)dx, (const float4*)base, n4, C / 4, (unsigned*)amax, q);
+        DSNT_LAUNCH_OP(DSNT_ST_APPLY_FIXED, bn_act_bwd_apply_kernel<true>, dim3(grid), dim3(256), 0, stream, ap);
     else
-        DSNT_LAUNCH(bn_act_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0,
-                    (hipStream_t)stream, (const float4*)da, (const float4*)x, (const float4*)scale,
-                    (const float4*)shift, (const float4*)mean, (const float4*)invstd,
-                    (const float4*)coef, relu, (float4*)dx, (const float4*)base, n4, C / 4, (unsigned*)amax, q);
+        DSNT_LAUNCH_OP(DSNT_ST_APPLY, bn_act_bwd_apply_kernel<false>, dim3(grid), dim3(256), 0, stream, ap);
     DSNT_CHECK_LAUNCH("dsnt_bn_act_bwd_apply");
 }
 
@@ -721,36 +429,7 @@ extern "C" int dsnt_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int N, 
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_fwd");
 }
 
-// (`extra`, optional: a second gradient of x — same layout as dx — added in the same pass: dx (+)= extra + the routed dy)
-__global__ void maxpool2_bwd_kernel(const float4* __restrict__ dy, const uchar4* __restrict__ idx,
-                                    float4* dx, int accumulate, const float4* __restrict__ extra,
-                                    int N, int H, int W, int C4, unsigned* amax) {
-    const int Ho = H >> 1, Wo = W >> 1;
-    const long total = (long)N * Ho * Wo * C4;
-    float am = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % C4);
-        long t = i / C4;
-        const int ow = (int)(t % Wo); t /= Wo;
-        const int oh = (int)(t % Ho);
-        const int n = (int)(t / Ho);
-        const float4 g = dy[i];
-        const uchar4 k = idx[i];
-        float4* base = dx + (((long)n * H + 2 * oh) * W + 2 * ow) * C4 + cg;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float4* q = base + (p >> 1) * (long)W * C4 + (p & 1) * C4;
-            float4 o = make_float4(k.x == p ? g.x : 0.f, k.y == p ? g.y : 0.f, k.z == p ? g.z : 0.f,
-                                   k.w == p ? g.w : 0.f);
-            if (accumulate) { const float4 c = *q; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
-            if (extra) { const float4 e = extra[q - dx]; o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
-            *q = o;
-            am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am);
-        }
-    }
-    if (amax) amax_commit(am, amax);
-}
+__global__ void maxpool2_bwd_kernel(PoolBwdP q) { maxpool2_bwd_body(q, blockIdx.x, gridDim.x); }
 
 static int maxpool2_bwd_impl(const float* dy, const uint8_t* idx, float* dx, int accumulate, const float* extra, int N, int H, int W,
                              int C, float* amax, void* stream);
@@ -773,8 +452,8 @@ static int maxpool2_bwd_impl(const float* dy, const uint8_t* idx, float* dx, int
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_maxpool2_bwd: H and W must be even");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dy) && dsnt_aligned16(dx), DSNT_ERR_ALIGN, "dsnt_maxpool2_bwd: alignment");
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-    DSNT_LAUNCH(maxpool2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, (const float4*)extra, N, H, W, C / 4, (unsigned*)amax);
+    const PoolBwdP q{(const float4*)dy, (const uchar4*)idx, (float4*)dx, accumulate, (const float4*)extra, N, H, W, C / 4, (unsigned*)amax};
+    DSNT_LAUNCH_OP(DSNT_ST_POOL_BWD, maxpool2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_maxpool2_bwd");
 }
 
@@ -806,28 +485,7 @@ extern "C" int dsnt_upsample2_add_fwd(const float* up, const float* low, float* 
     DSNT_CHECK_LAUNCH("dsnt_upsample2_add_fwd");
 }
 
-__global__ void upsample2_bwd_kernel(const float4* __restrict__ dout, float4* dlow, int accumulate,
-                                     int N, int H, int W, int C4, unsigned* amax) {
-    const int Hl = H >> 1, Wl = W >> 1;
-    const long total = (long)N * Hl * Wl * C4;
-    float am = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % C4);
-        long t = i / C4;
-        const int w = (int)(t % Wl); t /= Wl;
-        const int h = (int)(t % Hl);
-        const int n = (int)(t / Hl);
-        const float4* b = dout + (((long)n * H + 2 * h) * W + 2 * w) * C4 + cg;
-        const float4 v0 = b[0], v1 = b[C4], v2 = b[(long)W * C4], v3 = b[(long)W * C4 + C4];
-        float4 o = make_float4((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y),
-                               (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w));
-        if (accumulate) { const float4 c = dlow[i]; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
-        dlow[i] = o;
-        am = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))), am);
-    }
-    if (amax) amax_commit(am, amax);
-}
+__global__ void upsample2_bwd_kernel(UpBwdP q) { upsample2_bwd_body(q, blockIdx.x, gridDim.x); }
 
 static int upsample2_bwd_impl(const float* dout, float* dlow, int accumulate, int N, int H, int W, int C, float* amax,
                               void* stream);
@@ -845,8 +503,8 @@ static int upsample2_bwd_impl(const float* dout, float* dlow, int accumulate, in
     DSNT_REQUIRE(H % 2 == 0 && W % 2 == 0, DSNT_ERR_SHAPE, "dsnt_upsample2_bwd: H and W must be even");
     DSNT_REQUIRE(C % 4 == 0 && dsnt_aligned16(dout) && dsnt_aligned16(dlow), DSNT_ERR_ALIGN, "dsnt_upsample2_bwd: alignment");
     const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
-    DSNT_LAUNCH(upsample2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)dout, (float4*)dlow, accumulate, N, H, W, C / 4, (unsigned*)amax);
+    const UpBwdP q{(const float4*)dout, (float4*)dlow, accumulate, N, H, W, C / 4, (unsigned*)amax};
+    DSNT_LAUNCH_OP(DSNT_ST_UP_BWD, upsample2_bwd_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_upsample2_bwd");
 }
 

@@ -181,6 +181,11 @@ PLAIN = {
     'dsnt_list_segments': (I, [P]),
     'dsnt_list_size': (I, [P]),
     'dsnt_list_replay': (I, [P, I, C.POINTER(C.c_void_p), I]),
+    'dsnt_list_fuse_bytes': (C.c_int64, [P, I, I]),
+    'dsnt_list_fuse': (I, [P, P, C.c_int64, I, I, I]),
+    'dsnt_list_stages': (I, [P, C.POINTER(C.c_int)]),
+    'dsnt_list_fuse_plan': (I, [P, I, I, C.POINTER(C.c_int)]),
+    'dsnt_list_stage_errors': (I, [P]),
     'dsnt_conv_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_bf16x6_ok': (I, [GP]),
     'dsnt_conv_wgrad_splits': (I, [GP]),

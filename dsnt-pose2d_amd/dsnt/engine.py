@@ -155,6 +155,12 @@ class Tape:
         self.fold3 = 'fold3' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
         self.fold3_rows = int(os.environ.get('DSNT_X_FOLD3_ROWS', '16384'))
         self.stem4 = 'stem4' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')    # the stem's forward (csrc/stem4.hip)
+        # round 6: runs of small dependent launches of one lane as ONE persistent launch (csrc/stage.h; DSNT_OFF=stage: separate launches)
+        self.stage = 'stage' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
+        self.stage_min_run = int(os.environ.get('DSNT_X_STAGE_MIN_RUN', '3'))
+        self.stage_max_vgrid = int(os.environ.get('DSNT_X_STAGE_MAX_VGRID', '512'))
+        self.stage_grid = int(os.environ.get('DSNT_X_STAGE_GRID', '64'))
+        self.stage_census = []      # (stage launches, recorded launches inside) per compiled list
         self._f16_w_stream = {}
         # DSNT_CONV_SHARE_CHIP on the side lanes' launches of the two persistent kernels (3x3: 3/2 workgroups per CU; 1x1: half of
         # the CUs): both hold most of a CU's LDS for the whole launch, and the chain's kernels need LDS too (-0.2 ms)
@@ -635,10 +641,35 @@ class Tape:
             if self.use_lanes:
                 for lane in range(1, self.n_lanes):
                     self._rc(lib.dsnt_list_sync(h, lane, 0), 'dsnt_list_sync')
+            self._fuse_stages(h)
         except Exception:
             lib.dsnt_list_destroy(h)
             raise
         return h, marks
+
+    def _fuse_stages(self, h):
+        """Runs of small dependent launches of one lane (the 8 x 8 / 4 x 4 hourglass levels) -> persistent stage launches
+        (include/dsnt_hip.h: dsnt_list_fuse).  The tables and counters live in a tensor this tape owns."""
+        if not self.stage or self.device.type != 'cuda':
+            return
+        lib = self.lib
+        need = lib.dsnt_list_fuse_bytes(h, self.stage_min_run, self.stage_max_vgrid)
+        if need <= 0:
+            return
+        ws = torch.zeros((need + 63) // 64 * 64, dtype=torch.uint8, device=self.device)
+        self._keep.append(ws)
+        rc = lib.dsnt_list_fuse(h, C.c_void_p(ws.data_ptr()), ws.numel(), self.stage_min_run, self.stage_max_vgrid, self.stage_grid)
+        if rc < 0:
+            self._rc(rc, 'dsnt_list_fuse')
+        inside = C.c_int(0)
+        n = lib.dsnt_list_stages(h, C.byref(inside))
+        self.stage_census.append((n, inside.value))
+
+    def stage_errors(self):
+        """Persistent stages of this tape's compiled lists whose barrier gave up (a workgroup never arrived) since they were
+        built: 0 in a healthy process.  Synchronises the device (diagnostic / tests)."""
+        torch.cuda.synchronize()
+        return sum(max(0, self.lib.dsnt_list_stage_errors(h)) for h, _ in self._clists.values())
 
     def _rc(self, rc, name):
         if rc != 0:

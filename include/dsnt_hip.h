@@ -671,6 +671,25 @@ int dsnt_list_mark(dsnt_list* l);
 int dsnt_list_segments(const dsnt_list* l);
 int dsnt_list_size(const dsnt_list* l);
 int dsnt_list_replay(const dsnt_list* l, int segment, void* const* streams, int nstreams);
+/* Persistent stages (round 6; dsnt_version() >= 114).  On the 8 x 8 and 4 x 4 levels of an hourglass
+ * (/root/reference/src/dsnt/hourglass.py:78-90) a step is ~70 dependent launches per hourglass of a few microseconds each, every
+ * one behind a ~5-us launch boundary on the critical path.  dsnt_list_fuse rewrites a RECORDED list: every run of >= min_run
+ * consecutive launches of one lane that can take part (the K-split convolution, the BatchNorm-backward apply, max-pool /
+ * upsample + add with statistics and their backward; each with at most max_vgrid workgroups; no lane synchronisation or segment
+ * mark touching the lane inside the run) becomes ONE launch of a persistent kernel of min(grid_cap, the run's widest launch)
+ * co-resident 512-thread workgroups, which walk the recorded launches' workgroup indices through the same device functions
+ * (bit-identical results) with a chip-wide barrier where a kernel boundary was.  workspace: caller-owned device memory of
+ * dsnt_list_fuse_bytes(l, min_run, max_vgrid) bytes, 64-byte aligned, alive and untouched as long as the list is replayed (launch
+ * tables + per-stage counters; written here by a blocking copy).  Returns the number of stage launches created (0: nothing to
+ * fuse), negative on error.  A stage whose barrier gives up (2^21 polls: a workgroup never arrived) raises word 2 of its counter
+ * line and every workgroup leaves the kernel: wrong results the caller can detect, never a hung device.
+ * dsnt_list_stages: stage launches in the list and (launches_inside) the recorded launches they replaced;
+ * dsnt_list_stage_errors: how many of them have given up since the list was fused (blocking device reads; 0 when healthy). */
+int64_t dsnt_list_fuse_bytes(const dsnt_list* l, int min_run, int max_vgrid);
+int dsnt_list_fuse(dsnt_list* l, void* workspace, int64_t bytes, int min_run, int max_vgrid, int grid_cap);
+int dsnt_list_fuse_plan(const dsnt_list* l, int min_run, int max_vgrid, int* launches);   /* what fuse would do; no device needed */
+int dsnt_list_stages(const dsnt_list* l, int* launches_inside);
+int dsnt_list_stage_errors(const dsnt_list* l);
 
 /* ------------------------------------------------------------------ metrics
  * evaluator.py:66-81 + train.py:243-258: PCKh hits on device.

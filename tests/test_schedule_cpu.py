@@ -235,3 +235,27 @@ def test_resnet34_train_schedule(monkeypatch_module):
     assert bn.count('dsnt_wgrad_reduce_all') >= 1 and bn.count('dsnt_wgrad_reduce_all') <= 6
     assert not any(n.startswith('dsnt_axpy') for n in fn)
     assert len(fwd) <= 180 and len(bwd) <= 330, (len(fwd), len(bwd))
+
+
+def test_persistent_stage_runs_of_the_recorded_lists(tape):
+    """Round 6 (csrc/stage.h): the 8 x 8 / 4 x 4 levels of every hourglass (hourglass.py:78-90) are runs of small dependent launches
+    of one lane that dsnt_list_fuse turns into persistent stage launches.  Recording a list needs no GPU (launches are captured, not
+    enqueued); dsnt_list_fuse_plan runs the same run finder as dsnt_list_fuse."""
+    import ctypes as C
+    from dsnt import _lib
+    lib = _lib.load()
+    for lst, lo, hi in ((tape.fwd, 2 * 24, 2 * 32), (tape.bwd, 2 * 40, 2 * 56)):
+        h, marks = tape._compile(lst)
+        try:
+            size = lib.dsnt_list_size(h)
+            n = C.c_int(0)
+            s = lib.dsnt_list_fuse_plan(h, 3, 512, C.byref(n))
+            # per hourglass: the 4 x 4 chain, the two 8 x 8 runs around it and the 8 x 8 skip branch on its side lane
+            assert 2 * 3 <= s <= 2 * 5, (s, n.value)
+            assert lo <= n.value <= hi, (s, n.value)
+            assert lib.dsnt_list_fuse_bytes(h, 3, 512) == 512 * n.value + 64 * s
+            # nothing to fuse if runs had to be longer than any run is / launches narrower than any of these are
+            assert lib.dsnt_list_fuse_plan(h, 64, 512, None) == 0 and lib.dsnt_list_fuse_plan(h, 3, 1, None) == 0
+            assert lib.dsnt_list_size(h) == size        # planning changes nothing
+        finally:
+            lib.dsnt_list_destroy(h)

@@ -1,0 +1,84 @@
+"""The persistent low-resolution stage (csrc/stage.h, round 6) against the separate launches it replaces.
+
+On the 8 x 8 and 4 x 4 levels of an hourglass (/root/reference/src/dsnt/hourglass.py:78-90: the inner `_hour_glass_forward`
+recursions) a train step is runs of small dependent launches of one lane; `dsnt_list_fuse` replays each run as ONE persistent
+kernel that walks the recorded launches' workgroup indices through the SAME device functions, with a chip-wide barrier where a
+kernel boundary was.  Same instructions, same summation order: every output of a step — loss, coordinates, heat-maps, running
+statistics, every parameter gradient — must be BIT-identical with the stage on and off (DSNT_OFF=stage), the stages must have
+replaced the launches they were built for (census), and no barrier may have given up.  (This is HIP-vs-HIP by construction; the
+oracle statement comes from the goldens and every-gradient tests of tests/test_model_gpu.py, which run with the stage ON — the
+default — and from tests/test_fused_inmodel_gpu.py.)"""
+import pytest
+import torch
+
+from dsnt import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _step(base, batch, size, steps=1):
+    from dsnt.model import build_mpii_pose_model
+    from dsnt import optim
+    m = build_mpii_pose_model(base=base, output_strat='dsnt', reg='js')
+    synthetic.fill_state_dict(m, seed=0)
+    m.cuda().train()
+    x, t, k = synthetic.batch(batch, size=size, seed=1, mask_p=0.9)
+    x, t, k = x.to(DEV), t.to(DEV), k.to(DEV)
+    opt = optim.RMSprop(m, lr=2.5e-4)
+    for _ in range(steps):
+        out = m(x)
+        loss = m.forward_loss(out, t, k)
+        opt.zero_grad()
+        loss.backward()
+        if steps > 1:
+            opt.step()
+    torch.cuda.synchronize()
+    runner = m.hg._runner()
+    prog = [p for p in runner.programs.values() if p.training][0]
+    res = {'loss': loss.detach().clone(), 'coords': [o.detach().clone() for o in out],
+           'heatmaps': m.heatmaps.detach().clone(),
+           'grads': {n: p.grad.detach().clone() for n, p in m.named_parameters()},
+           'buffers': {n: b.detach().clone() for n, b in m.named_buffers()},
+           'params': {n: p.detach().clone() for n, p in m.named_parameters()}}
+    return res, prog.tape
+
+
+def _assert_identical(a, b):
+    assert torch.equal(a['loss'], b['loss']), (a['loss'].item(), b['loss'].item())
+    for u, v in zip(a['coords'], b['coords']):
+        assert torch.equal(u, v)
+    assert torch.equal(a['heatmaps'], b['heatmaps'])
+    for group in ('grads', 'buffers', 'params'):
+        bad = [n for n in a[group] if not torch.equal(a[group][n], b[group][n])]
+        assert not bad, (group, len(bad), bad[:5])
+
+
+@pytest.mark.parametrize('base,batch,size,steps', [('hg2', 2, 256, 1), ('hg8', 2, 128, 1), ('hg2', 4, 128, 3)])
+def test_stage_is_bit_identical_to_the_launches_it_replaces(monkeypatch, base, batch, size, steps):
+    monkeypatch.delenv('DSNT_OFF', raising=False)
+    on, tape_on = _step(base, batch, size, steps)
+    stacks = int(base[2:])
+    n_stage = sum(s for s, _ in tape_on.stage_census)
+    n_inside = sum(n for _, n in tape_on.stage_census)
+    # per hourglass and direction: the 4 x 4 chain, the 8 x 8 runs around it, the 8 x 8 skip branch (more on these small inputs,
+    # whose 16 x 16 / 32 x 32 levels are K-split sized too)
+    assert n_stage >= 2 * 3 * stacks and n_inside >= 2 * 25 * stacks, tape_on.stage_census
+    assert tape_on.stage_errors() == 0
+    monkeypatch.setenv('DSNT_OFF', 'stage')
+    off, tape_off = _step(base, batch, size, steps)
+    assert tape_off.stage_census == [] and tape_off.stage_errors() == 0
+    _assert_identical(on, off)
+
+
+def test_stage_full_size_steps_are_identical_and_reproducible(monkeypatch):
+    """hg2 at batch 32 / 256 px (BASELINE config 3): the production run structure (8 stages per list: profiles/r06_*), three
+    optimiser steps with the stage on twice and off once — same bits everywhere."""
+    monkeypatch.delenv('DSNT_OFF', raising=False)
+    a, tape = _step('hg2', 32, 256, 3)
+    assert sum(s for s, _ in tape.stage_census) == 16 and tape.stage_errors() == 0, tape.stage_census
+    b, _ = _step('hg2', 32, 256, 3)
+    _assert_identical(a, b)
+    monkeypatch.setenv('DSNT_OFF', 'stage')
+    c, _ = _step('hg2', 32, 256, 3)
+    _assert_identical(a, c)
