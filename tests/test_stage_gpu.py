@@ -25,6 +25,7 @@ def _step(base, batch, size, steps=1):
     m.cuda().train()
     x, t, k = synthetic.batch(batch, size=size, seed=1, mask_p=0.9)
     x, t, k = x.to(DEV), t.to(DEV), k.to(DEV)
+    m.hg._runner().ensure(torch.device(DEV))
     opt = optim.RMSprop(m, lr=2.5e-4)
     for _ in range(steps):
         out = m(x)
