@@ -2742,7 +2742,9 @@ __device__ __forceinline__ bool stage_barrier(unsigned* sync, const unsigned wan
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         unsigned guard = 0;
-        while (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        // (relaxed polls and ONE acquire fence behind them: an acquire load per poll invalidates this CU's vector cache — and the
+        // non-local lines of the XCD's L2 — every time, under the kernels of the other lanes that share them)
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             if ((++guard & 1023u) == 0 &&
                 (guard >= (1u << 21) || __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                 __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2751,6 +2753,7 @@ __device__ __forceinline__ bool stage_barrier(unsigned* sync, const unsigned wan
             }
             __builtin_amdgcn_s_sleep(1);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();          // (scalar loads of the next launch's operands must not hit lines read before the barrier)

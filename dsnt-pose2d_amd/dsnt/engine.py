@@ -155,8 +155,11 @@ class Tape:
         self.fold3 = 'fold3' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
         self.fold3_rows = int(os.environ.get('DSNT_X_FOLD3_ROWS', '16384'))
         self.stem4 = 'stem4' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')    # the stem's forward (csrc/stem4.hip)
-        # round 6: runs of small dependent launches of one lane as ONE persistent launch (csrc/stage.h; DSNT_OFF=stage: separate launches)
-        self.stage = 'stage' not in os.environ.get('DSNT_OFF', '').replace('+', ',').split(',')
+        # round 6: runs of small dependent launches of one lane as ONE persistent launch (csrc/stage.h).  OFF by default — built,
+        # bit-identical to the launches it replaces (tests/test_stage_gpu.py), and measured SLOWER: hg2 batch 32 11.06 -> 11.97 ms,
+        # hg8 batch 16 24.1 -> 25.7 ms with every run fused; 11.17 / 24.04 (no gain) with only the <= 64-workgroup launches of the
+        # 4 x 4 level inside (profiles/r06_stage_ab.txt).  DSNT_STAGE=1 turns it on (A/B, tests).
+        self.stage = os.environ.get('DSNT_STAGE', '0') == '1'
         self.stage_min_run = int(os.environ.get('DSNT_X_STAGE_MIN_RUN', '3'))
         self.stage_max_vgrid = int(os.environ.get('DSNT_X_STAGE_MAX_VGRID', '512'))
         self.stage_grid = int(os.environ.get('DSNT_X_STAGE_GRID', '64'))
