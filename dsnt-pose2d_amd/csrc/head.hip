@@ -620,6 +620,7 @@ __global__ __launch_bounds__(HB) void head_loss_grad_kernel(const float* __restr
                                                             float sigma, float k, int kind, float reg_coeff) {
     __shared__ float red[16];
     __shared__ __attribute__((aligned(16))) float exy[HEAD_SEP_MAX];
+    __shared__ __attribute__((aligned(16))) float pos[HEAD_SEP_MAX];
     const size_t r = blockIdx.x;
     const int hw = h * w;
     // the row's scalars first, then the 16 KB row: everything is in flight together
@@ -639,10 +640,17 @@ __global__ __launch_bounds__(HB) void head_loss_grad_kernel(const float* __restr
     const float gr = kind >= 0 ? wm * reg_coeff : 0.f;
     float gv[16];
     float acc[2] = {0.f, 0.f};              // regulariser value, sum_j p_j dL/dp_j
-    if (kind == 0 && w + h <= HEAD_SEP_MAX) {
+    // the pixel positions x_w = (2w - (W-1)) / W, y_h = (2h - (H-1)) / H once per workgroup (W + H true divisions) instead of
+    // one or two per element: round 6 — with them in the element loop the kernel was ALU-bound at 1.4-1.8x its HBM time
+    const bool tab = w + h <= HEAD_SEP_MAX;
+    if (tab) {
+        for (int i = threadIdx.x; i < w + h; i += HB)
+            pos[i] = i < w ? (2.f * i - g.offx) / (float)w : (2.f * (i - w) - g.offy) / (float)h;
+    }
+    if (kind == 0 && tab) {
         // separable target Gaussian: ex[0..w), ey[0..h)
         for (int i = threadIdx.x; i < w + h; i += HB) {
-            const float t = i < w ? (2.f * i - g.offx) / (float)w - tx : (2.f * (i - w) - g.offy) / (float)h - ty;
+            const float t = (i < w ? (2.f * i - g.offx) / (float)w - tx : (2.f * (i - w) - g.offy) / (float)h - ty);
             exy[i] = expf(t * t * k);
         }
         __syncthreads();
@@ -650,17 +658,18 @@ __global__ __launch_bounds__(HB) void head_loss_grad_kernel(const float* __restr
         for (int i = threadIdx.x; i < w + h; i += HB) sxy[i < w ? 0 : 1] += exy[i];
         block_sum<2>(sxy, red);
         const float invz = 1.f / (sxy[0] * sxy[1] + 1e-24f);
-        auto elem = [&](int slot, float p, float x, float y, float qx, float qy) {
-            const float q = qx * qy;
+        auto finish = [&](int slot, float p, float x, float y, float dr) {
+            const float v = fmaf(ax, x, ay * y) + gr * dr;
+            gv[slot] = v;
+            acc[1] = fmaf(p, v, acc[1]);
+        };
+        auto elem = [&](int slot, float p, float x, float y, float q) {
             const float m = 0.5f * (p + q);
             // logarithms in the log2 domain (v_log_f32), ln 2 folded into the two places they are used
             const float lm = __builtin_amdgcn_logf(m + REG_EPS);
             const float dp = __builtin_amdgcn_logf(p + REG_EPS) - lm, dq = __builtin_amdgcn_logf(q + REG_EPS) - lm;
             acc[0] = fmaf(0.5f * LN2, fmaf(p, dp, q * dq), acc[0]);
-            const float dr = 0.5f * (fmaf(LN2, dp, p * __builtin_amdgcn_rcpf(p + REG_EPS)) - m * __builtin_amdgcn_rcpf(m + REG_EPS));
-            const float v = fmaf(ax, x, ay * y) + gr * dr;
-            gv[slot] = v;
-            acc[1] = fmaf(p, v, acc[1]);
+            finish(slot, p, x, y, 0.5f * (fmaf(LN2, dp, p * __builtin_amdgcn_rcpf(p + REG_EPS)) - m * __builtin_amdgcn_rcpf(m + REG_EPS)));
         };
         if (VEC == 4 && (w & 3) == 0) {
             // four consecutive pixels of one heat-map row per thread and chunk: one division for the position
@@ -669,19 +678,48 @@ __global__ __launch_bounds__(HB) void head_loss_grad_kernel(const float* __restr
                 const int i = (kk * HB + threadIdx.x) * 4;
                 if (i < hw) {
                     const int rr = i / w, cc = i - rr * w;
-                    const float y = (2.f * rr - g.offy) / (float)h;
+                    const float y = pos[w + rr];
                     const float qy = exy[w + rr] * invz;
                     const float4 qx = *reinterpret_cast<const float4*>(exy + cc);
-                    const float qxs[4] = {qx.x, qx.y, qx.z, qx.w};
+                    const float4 xv = *reinterpret_cast<const float4*>(pos + cc);
+                    const float qs[4] = {qx.x * qy, qx.y * qy, qx.z * qy, qx.w * qy};
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+                    const float* pv = row.v + 4 * kk;
+                    // The five transcendentals per element (3 v_log_f32, 2 v_rcp_f32: quarter rate) are the kernel's ALU time; two
+                    // wave-uniform shortcuts that are EXACT in fp32 take most of them away:
+                    //  * every p of the wave's 256 pixels > 1e-16: p / (p + 1e-24) and m / (m + 1e-24) (m >= p / 2) are 1 - <= 2e-8,
+                    //    which rounds to 1.0f — the two reciprocals drop out, d reg / d p = (ln 2 / 2) (log2(p + eps) - log2(m + eps));
+                    //  * ... and every q < 1e-30 (the target Gaussian has underflowed: all but ~26 of the 64 rows at sigma = 1 px):
+                    //    m = p / 2 exactly, log2(p + eps) - log2(m + eps) = 1, q (..) < 1e-28 — no transcendental at all.
+                    const float pmin = fminf(fminf(pv[0], pv[1]), fminf(pv[2], pv[3]));
+                    const float qmax = fmaxf(fmaxf(qs[0], qs[1]), fmaxf(qs[2], qs[3]));
+                    const bool big = pmin > 1e-16f, far = qmax < 1e-30f;
+                    if (__all(big && far)) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        elem(4 * kk + e, row.v[4 * kk + e], (2.f * (cc + e) - g.offx) / (float)w, y, qxs[e], qy);
+                        for (int e = 0; e < 4; ++e) {
+                            acc[0] = fmaf(0.5f * LN2, pv[e], acc[0]);
+                            finish(4 * kk + e, pv[e], xs[e], y, 0.5f * LN2);
+                        }
+                    } else if (__all(big)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pe = pv[e], q = qs[e];
+                            const float m = 0.5f * (pe + q);
+                            const float lm = __builtin_amdgcn_logf(m + REG_EPS);
+                            const float dp = __builtin_amdgcn_logf(pe + REG_EPS) - lm, dq = __builtin_amdgcn_logf(q + REG_EPS) - lm;
+                            acc[0] = fmaf(0.5f * LN2, fmaf(pe, dp, q * dq), acc[0]);
+                            finish(4 * kk + e, pe, xs[e], y, (0.5f * LN2) * dp);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) elem(4 * kk + e, pv[e], xs[e], y, qs[e]);
+                    }
                 }
             }
         } else {
             row.each_slot([&](int slot, int i, float p) {
                 const int rr = i / w, cc = i - rr * w;
-                elem(slot, p, (2.f * cc - g.offx) / (float)w, (2.f * rr - g.offy) / (float)h, exy[cc], exy[w + rr] * invz);
+                elem(slot, p, pos[cc], pos[w + rr], exy[cc] * (exy[w + rr] * invz));
             });
         }
         block_sum<2>(acc, red);
@@ -692,13 +730,31 @@ __global__ __launch_bounds__(HB) void head_loss_grad_kernel(const float* __restr
             c = reg_context(row, g, tx, ty, k, kind, red);
             val = reg_value(row, g, c, tx, ty, k, sigma, kind, red);
         }
-        row.each_slot([&](int slot, int i, float p) {
-            float x, y; g.xy(i, x, y);
+        if (tab) __syncthreads();               // `pos` (written above; reg_context / reg_value may not have synchronised)
+        auto one = [&](int slot, float p, float x, float y) {
             float v = ax * x + ay * y;
             if (kind >= 0 && gr != 0.f) v += gr * reg_grad(p, x, y, c, tx, ty, k, sigma, kind);
             gv[slot] = v;
             acc[1] = fmaf(p, v, acc[1]);
-        });
+        };
+        if (VEC == 4 && (w & 3) == 0 && tab) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int i = (kk * HB + threadIdx.x) * 4;
+                if (i < hw) {
+                    const int rr = i / w, cc = i - rr * w;
+                    const float y = pos[w + rr];
+                    const float4 xv = *reinterpret_cast<const float4*>(pos + cc);
+                    one(4 * kk, row.v[4 * kk], xv.x, y); one(4 * kk + 1, row.v[4 * kk + 1], xv.y, y);
+                    one(4 * kk + 2, row.v[4 * kk + 2], xv.z, y); one(4 * kk + 3, row.v[4 * kk + 3], xv.w, y);
+                }
+            }
+        } else {
+            row.each_slot([&](int slot, int i, float p) {
+                float x, y; g.xy(i, x, y);
+                one(slot, p, x, y);
+            });
+        }
         float s1[1] = {acc[1]};
         block_sum<1>(s1, red);
         acc[0] = val; acc[1] = s1[0];

@@ -11,7 +11,16 @@ must agree to fp32 rounding of another summation order: loss, coordinates, every
 The backward-only switches leave the forward bit-identical, so on the real network every parameter gradient agrees to 1e-4
 relative L2: a wrong BatchNorm coefficient vector, a stale `Act.base` or a shared gradient read after it was accumulated
 into on ONE layer fails that by orders of magnitude.  The forward switches move last bits of every activation (max-pool
-arg-max ties and ReLU masks may flip): the bulk to 1e-4 on the smooth network, the flip-tolerant bar with the ReLUs on.  (Reference: /root/reference/src/dsnt/hourglass.py:30-50,155-177.)"""
+arg-max ties and ReLU masks may flip): the bulk to 1e-4 on the smooth network, the flip-tolerant bar with the ReLUs on.  (Reference: /root/reference/src/dsnt/hourglass.py:30-50,155-177.)
+
+WHAT THIS FILE IS NOT: an oracle test.  Both sides of every comparison are HIP paths of this repository — "new kernels = the
+kernels they replace" at sizes no CPU oracle run reaches.  It becomes a statement about the reference only through the chain
+  old kernels = oracle   at oracle sizes: tests/test_model_gpu.py (goldens hg1/hg2/hg8, every gradient of hg2 / hg8 on all three
+                         matrix-core paths), tests/test_conv_gpu.py (each kernel against torch fp64)
+  new kernels = oracle   at oracle sizes with the production forms FORCED onto the small models: tests/test_fused_inmodel_gpu.py
+                         (one-pass 1x1 kernels, every conv3s form incl. the folded BatchNorm backward and its direct weight gradient)
+  new = old              at FULL size: here.
+Each link is needed: the first two never see 131072-row launches, this one never sees the oracle."""
 import os
 import subprocess
 import sys
