@@ -191,13 +191,6 @@ extern "C" int dsnt_bn_add_act_bwd_reduce(const float* da, const float* y, const
     DSNT_CHECK_LAUNCH("dsnt_bn_add_act_bwd_reduce");
 }
 
-// statistics of many tiles: 4 channels x 256 tile-lanes per workgroup (ew_bodies.h; DSNT_X_FIN_WIDE_TILES: A/B, 0 = never)
-static bool fin_wide(int ntiles) {
-    static int t = -1;
-    if (t < 0) { const char* e = getenv("DSNT_X_FIN_WIDE_TILES"); t = e ? atoi(e) : FIN_WIDE_TILES; }
-    return t > 0 && ntiles >= t;
-}
-
 extern "C" int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int C,
                                 const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, float momentum, float eps, int training,
@@ -212,8 +205,7 @@ extern "C" int dsnt_bn_finalize(const float* partial, int ntiles, int64_t M, int
     const double unbias = M > 1 ? (double)M / (double)(M - 1) : 1.0;
     const BnFinP q{partial, ntiles, 1.0 / (double)M, unbias, C, gamma, beta, running_mean, running_var, momentum, eps, training,
                    mean, invstd, scale, shift, 0, BnBoundP{nullptr, nullptr, 0.f, nullptr}};
-    if (fin_wide(ntiles)) DSNT_LAUNCH_OP(DSNT_ST_NONE, (bn_finalize_kernel<0, 4>), dim3((C + 3) / 4), dim3(FIN_T), 0, stream, q);
-    else DSNT_LAUNCH_OP(DSNT_ST_FIN_FWD, bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(FIN_T), 0, stream, q);
+    DSNT_LAUNCH_OP(DSNT_ST_FIN_FWD, bn_finalize_kernel<0>, dim3((C + 15) / 16), dim3(FIN_T), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_bn_finalize");
 }
 
@@ -257,8 +249,7 @@ extern "C" int dsnt_bn_bwd_finalize(const float* partial, int ntiles, int64_t M,
     const double invM = (accumulate & DSNT_BN_FROZEN) ? 0.0 : 1.0 / (double)M;
     const BnFinP q{partial, ntiles, invM, 1.0, C, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 1, dgamma, dbeta, coef, nullptr,
                    accumulate & 1, BnBoundP{nullptr, nullptr, 0.f, nullptr}};
-    if (fin_wide(ntiles)) DSNT_LAUNCH_OP(DSNT_ST_NONE, (bn_finalize_kernel<1, 4>), dim3((C + 3) / 4), dim3(FIN_T), 0, stream, q);
-    else DSNT_LAUNCH_OP(DSNT_ST_FIN_BWD, bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, stream, q);
+    DSNT_LAUNCH_OP(DSNT_ST_FIN_BWD, bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize");
 }
 
@@ -272,8 +263,7 @@ extern "C" int dsnt_bn_bwd_finalize_bound(const float* partial, int ntiles, int6
                  "dsnt_bn_bwd_finalize_bound: bad argument");
     const BnFinP q{partial, ntiles, 1.0 / (double)M, 1.0, C, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 1, dgamma, dbeta, coef, nullptr,
                    accumulate, BnBoundP{scale, dz_amax, sqrtf((float)M), reinterpret_cast<unsigned*>(bound_out)}};
-    if (fin_wide(ntiles)) DSNT_LAUNCH_OP(DSNT_ST_NONE, (bn_finalize_kernel<1, 4>), dim3((C + 3) / 4), dim3(FIN_T), 0, stream, q);
-    else DSNT_LAUNCH_OP(DSNT_ST_FIN_BWD, bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, stream, q);
+    DSNT_LAUNCH_OP(DSNT_ST_FIN_BWD, bn_finalize_kernel<1>, dim3((C + 15) / 16), dim3(FIN_T), 0, stream, q);
     DSNT_CHECK_LAUNCH("dsnt_bn_bwd_finalize_bound");
 }
 

@@ -299,25 +299,19 @@ struct BnFinP {
 // stage.h) carries FIN_T / NT of them per thread — virtual thread tid + v NT, i.e. virtual wave (tid >> 6) + v NT / 64 —, and
 // every partial sum is formed and combined in the order of the 1024-thread kernel: the results are bit-identical.
 // vb: workgroup index (16 channels each).  r0, r1: 256 doubles of LDS each.
-// CL: channels per workgroup — 16 (64 tile-lanes of 16 channels: the form of rounds 1-5, and the one a stage runs) or 4 (256
-// tile-lanes, four times the workgroups: round 6, for statistics of >= FIN_WIDE_TILES tiles, where a thread's serial chain over
-// its tiles is the launch's length).  The summation order depends on CL only.
-#define FIN_WIDE_TILES 256
-template <int MODE, int NT, int CL = 16>
+template <int MODE, int NT>
 __device__ __forceinline__ void bn_finalize_body(const BnFinP& q, const int vb, double* r0, double* r1) {
     constexpr int VP = FIN_T / NT;
-    constexpr int CLS = CL == 16 ? 4 : 2;            // log2(CL)
-    constexpr int PARTS = FIN_T / CL;                // tile lanes
     const float* __restrict__ partial = q.partial; const int ntiles = q.ntiles; const double invM = q.invM, unbias = q.unbias;
     const int C = q.C; const float* __restrict__ gamma = q.gamma; const float* __restrict__ beta = q.beta;
     float* running_mean = q.running_mean; float* running_var = q.running_var; const float momentum = q.momentum, eps = q.eps;
     const int training = q.training; float* o0 = q.o0; float* o1 = q.o1; float* o2 = q.o2; float* o3 = q.o3;
     const int accumulate = q.accumulate; const BnBoundP bp = q.bp;
-    const int tid = threadIdx.x, cl = tid & (CL - 1);
-    const int c = vb * CL + cl;
+    const int tid = threadIdx.x, cl = tid & 15;
+    const int c = vb * 16 + cl;
     // everything the last step needs besides the sums is fetched NOW, under the row loop: the kernel's length is what a BatchNorm
     // costs the dependency chain, and a load issued behind the reduction is a microsecond of it (round 5, box N)
-    const bool lead = tid < CL && c < C;                    // (virtual part 0)
+    const bool lead = tid < 16 && c < C;                    // (virtual part 0)
     float pg = 1.f, pb = 0.f, prm = 0.f, prv = 0.f, po0 = 0.f, po1 = 0.f, psc = 0.f, pdz = 0.f;
     if (MODE == 0 && lead) {
         if (gamma) pg = gamma[c];
@@ -332,10 +326,10 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinP& q, const int vb, 
 #pragma unroll
     for (int v = 0; v < VP; ++v) {
         a0[v] = 0.0; a1[v] = 0.0;
-        const int part = (tid + v * NT) >> CLS;
+        const int part = (tid + v * NT) >> 4;
         if (c < C && (MODE == 1 || training)) {
 #pragma unroll 4
-            for (int t = part; t < ntiles; t += PARTS) {
+            for (int t = part; t < ntiles; t += FIN_P) {
                 a0[v] += (double)partial[((size_t)t * 2 + 0) * C + c];
                 a1[v] += (double)partial[((size_t)t * 2 + 1) * C + c];
             }
@@ -345,17 +339,17 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinP& q, const int vb, 
     // (deterministic; ONE barrier — a seven-level tree over 1024 threads cost the chain ~0.5 us per BatchNorm, round 5)
 #pragma unroll
     for (int v = 0; v < VP; ++v) {
-#pragma unroll
-        for (int o = CL; o < 64; o <<= 1) { a0[v] += __shfl_xor(a0[v], o, 64); a1[v] += __shfl_xor(a1[v], o, 64); }
-        if ((tid & 63) < CL) { r0[(((tid + v * NT) >> 6)) * CL + cl] = a0[v]; r1[(((tid + v * NT) >> 6)) * CL + cl] = a1[v]; }
+        a0[v] += __shfl_xor(a0[v], 16, 64); a1[v] += __shfl_xor(a1[v], 16, 64);
+        a0[v] += __shfl_xor(a0[v], 32, 64); a1[v] += __shfl_xor(a1[v], 32, 64);
+        if ((tid & 63) < 16) { r0[(((tid + v * NT) >> 6)) * 16 + cl] = a0[v]; r1[(((tid + v * NT) >> 6)) * 16 + cl] = a1[v]; }
     }
     __syncthreads();
     double s0 = 0.0, s1 = 0.0;
-    if (tid < CL) {
+    if (tid < 16) {
 #pragma unroll
-        for (int w = 0; w < FIN_T / 64; ++w) { s0 += r0[w * CL + cl]; s1 += r1[w * CL + cl]; }
+        for (int w = 0; w < FIN_T / 64; ++w) { s0 += r0[w * 16 + cl]; s1 += r1[w * 16 + cl]; }
     }
-    if (tid < CL && c < C) {
+    if (tid < 16 && c < C) {
         if (MODE == 0) {
             double mean, var;
             if (training) {
@@ -389,16 +383,16 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinP& q, const int vb, 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o, 64));
         float b = 0.f;
-        if (tid < CL && c < C)
+        if (tid < 16 && c < C)
             b = fabsf(psc) * (dzmax + fabsf((float)(s0 * invM)) + fabsf((float)(s1 * invM)) * bp.sqrtM);
 #pragma unroll
-        for (int o = CL / 2; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+        for (int o = 8; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
         if (tid == 0 && b > 0.f) atomicMax(bp.out + (vb & 63), __float_as_uint(b));
     }
 }
-template <int MODE, int CL = 16>
+template <int MODE>
 __global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(BnFinP q) {
     __shared__ double r0[256], r1[256];
-    bn_finalize_body<MODE, FIN_T, CL>(q, blockIdx.x, r0, r1);
+    bn_finalize_body<MODE, FIN_T>(q, blockIdx.x, r0, r1);
 }
 
