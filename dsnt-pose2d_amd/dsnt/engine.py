@@ -194,7 +194,10 @@ class Tape:
         # DSNT_WGRAD_RELEASE_ROWS rows.  Issued as they come, the weight gradients share the chip with the large
         # data-gradient kernels and are gone by the time the small levels start; held back, they run beside them.
         # Only while a release point is still ahead in the backward order (a ResNet has none: nothing is held back).
-        self.release_rows = int(os.environ.get('DSNT_X_RELEASE_ROWS', '8192'))
+        # (8192 -> 4096 in round 6: at batch 32 the 16 x 16 level — 8192 rows — still fills the chip by itself; released one level
+        # further in, the held weight gradients run beside the 8 x 8 / 4 x 4 chains only: hg2 -0.07 ms, hg8 batch 16 unchanged — its
+        # 16 x 16 level has 4096 rows; profiles/r06_ab_switches.txt box A)
+        self.release_rows = int(os.environ.get('DSNT_X_RELEASE_ROWS', '4096'))
         self._release_total, self._release_left = 0, 0
         self._held = []
         self.acts = []          # every activation in creation order (debugging / introspection)

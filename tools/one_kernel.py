@@ -29,6 +29,22 @@ if which in ('stem4', 'stem4w'):
             assert _lib.fn('dsnt_conv_wgrad_f16x3')(ptr(x), None, None, 0, ptr(gy), ptr(ws), None, None, 0, ptr(ab), ptr(gb), C.byref(g), st) == 0
     torch.cuda.synchronize()
     sys.exit(0)
+if which == 'head':
+    # the DSNT head's two train-step kernels at batch 1024 (16384 rows of 64 x 64): dsnt_head_fwd, dsnt_head_loss_grad with JS
+    rows, h, w = 1024 * 16, 64, 64
+    logits = torch.randn(rows, h * w, device=dev) * 3
+    hm = torch.empty_like(logits); g0 = torch.empty_like(logits)
+    coords = torch.empty(rows, 2, device=dev); target = torch.rand(rows, 2, device=dev) * 2 - 1
+    mask = torch.ones(rows, device=dev); dist = torch.empty(rows, device=dev); reg = torch.empty(rows, device=dev)
+    denom2 = torch.empty(2, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert _lib.fn('dsnt_mask_denom')(ptr(mask), ptr(denom2), rows, st) == 0
+    for it in range(int(os.environ.get('ONE_KERNEL_REPS', '5'))):
+        assert _lib.fn('dsnt_head_fwd')(ptr(logits), ptr(hm), ptr(coords), rows, h, w, st) == 0
+        assert _lib.fn('dsnt_head_loss_grad')(ptr(hm), ptr(coords), ptr(target), ptr(mask), ptr(denom2), ptr(dist), ptr(reg), ptr(g0),
+                                               rows, h, w, 2.0 / 64, 0, 1.0, st) == 0
+    torch.cuda.synchronize()
+    sys.exit(0)
 H, Cin, Cout, k = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (64, 128, 128, 3)
 g = ConvGeom(B, H, H, Cin, H, H, Cout, k, k, 1, k // 2, 1)
 x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(Cout, k, k, Cin, device=dev) * 0.05

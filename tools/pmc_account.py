@@ -23,9 +23,14 @@ for name, c in rows:
     tot += c
 print('    %-30s %5.1f %%' % ('sum (issue-busy)', 100 * tot / simd))
 m = v['SQ_INSTS_MFMA']
-print('  instructions per MFMA: VALU %.2f, LDS %.2f, scalar %.2f, VMEM %.2f   (SQ_INSTS_*; %.3g MFMAs)' % (
+if m <= 0:      # a kernel without matrix instructions (the DSNT head): per-wave-instruction counts instead
+    print('  instructions: VALU %.4g, LDS %.4g, scalar %.4g, VMEM %.4g (SQ_INSTS_*; no MFMA)' % (v['SQ_INSTS_VALU'], v['SQ_INSTS_LDS'], v['SQ_INSTS_SALU'], v['SQ_INSTS_VMEM']))
+    m = float('nan')
+else:
+  print('  instructions per MFMA: VALU %.2f, LDS %.2f, scalar %.2f, VMEM %.2f   (SQ_INSTS_*; %.3g MFMAs)' % (
     v['SQ_INSTS_VALU'] / m, v['SQ_INSTS_LDS'] / m, v['SQ_INSTS_SALU'] / m, v['SQ_INSTS_VMEM'] / m, m))
-print('  MFMA and VALU co-executing: %.1f %% of the matrix-pipe time' % (100 * v['SQ_VALU_MFMA_COEXEC_CYCLES'] / v['SQ_VALU_MFMA_BUSY_CYCLES']))
+if v['SQ_VALU_MFMA_BUSY_CYCLES'] > 0:
+    print('  MFMA and VALU co-executing: %.1f %% of the matrix-pipe time' % (100 * v['SQ_VALU_MFMA_COEXEC_CYCLES'] / v['SQ_VALU_MFMA_BUSY_CYCLES']))
 print('  LDS unit: active %.1f %% of the CU cycles, bank conflicts %.1f %% of that, unaligned stalls %.0f' % (
     100 * v['SQ_LDS_IDX_ACTIVE'] / (kc * 256), 100 * v['SQ_LDS_BANK_CONFLICT'] / max(1.0, v['SQ_LDS_IDX_ACTIVE']), v['SQ_LDS_UNALIGNED_STALL']))
 print('  waves: waiting (s_waitcnt / barrier) %.0f %% of their resident cycles, issue-stalled %.0f %%, issuing %.0f %%' % (
