@@ -14,9 +14,9 @@ LIB = os.path.join(CSRC, 'libdsnt_hip.so')
 SOURCES = ['api.cpp', 'conv.hip', 'wgrad3.hip', 'wgrad1.hip', 'gemm1.hip', 'bwd1.hip', 'fwd1.hip', 'stem4.hip', 'conv3s.hip', 'dgrad_up.hip', 'elementwise.hip', 'head.hip', 'heatmap.hip', 'debug.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result']
-if os.environ.get('DSNT_TIMELINE'):      # wave timeline stamps in the conv kernels (tools/archive/timeline*.py)
+if os.environ.get('DSNT_TIMELINE'):      # wave timeline stamps in the conv kernels (diagnostic scripts of rounds 1-3, removed in round 6: git history)
     FLAGS.append('-DDSNT_TIMELINE')
-if os.environ.get('DSNT_TIMELINE') == '2':  # loader stamps split into wait / stage (tools/archive/timeline6.py)
+if os.environ.get('DSNT_TIMELINE') == '2':  # loader stamps split into wait / stage (same)
     FLAGS.append('-DDSNT_TIMELINE2')
 # kernel experiments: extra compiler flags and another output name (load it with DSNT_HIP_LIB=<path>), e.g.
 #   DSNT_CXXFLAGS=-DDSNT_WG6U_SCHED DSNT_LIB_NAME=libdsnt_exp.so python dsnt-pose2d_amd/build.py --force
