@@ -51,6 +51,27 @@ def _worker(rank, world, port, q):
         ok_sum = ok_sum and len(red3.pending) == 2
         red3.wait()
         ok_sum = ok_sum and flag0.tolist() == [0, 0] and red3.exposed_comm_ms() is None
+        # a check enqueued AFTER backward() returned: wait() has already exchanged the flag for this step, so the
+        # optimiser's pre_update hook (reducer.sync_flag) exchanges it once more — every rank skips, none diverges; with no late
+        # check there is no second collective
+        class _Guard:                          # the two fields of dsnt.guard.NanGuard the reducer looks at
+            def __init__(self, flag):
+                self.flag, self.checks_enqueued = flag, 0
+        flag4 = torch.zeros(2, dtype=torch.int32)
+        g4 = _Guard(flag4)
+        red4 = parallel.GradientAllReducer(torch.ones(4) * (rank + 1), [(0, 4)], flag=flag4)
+        red4.guard = g4
+        g4.checks_enqueued += 1                # the usual check, before backward: clean on both ranks
+        red4.reduce_all()
+        red4.wait()
+        seen = red4.flag_checks_seen
+        red4.sync_flag()                       # nothing new: no collective, nothing changes
+        ok_sum = ok_sum and seen == 1 and flag4.tolist() == [0, 0]
+        g4.checks_enqueued += 1                # a LATE check: rank 1's loss was not finite
+        if rank == 1:
+            flag4[0] = 1
+        red4.sync_flag()
+        ok_sum = ok_sum and flag4.tolist() == [1, 0] and red4.flag_checks_seen == 2
         # broadcast rank 0's weights
         w = torch.full((17,), float(rank + 5))
         parallel.broadcast_flat(w, 0)
