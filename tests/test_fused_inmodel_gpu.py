@@ -152,7 +152,7 @@ def test_hg2_every_gradient_vs_oracle_on_the_production_kernels(tmp_path, kind, 
     _check_c3(rep, variant, 2)
 
 
-@pytest.mark.parametrize('variant', ['prod', 'mf'])
+@pytest.mark.parametrize('variant', ['prod'])        # ('mf' passes too; 25 s of GPU time per variant)
 def test_hg8_every_gradient_vs_oracle_on_the_production_kernels(tmp_path, variant):
     """hg8's 1464 gradients (batch 2, 128 px, smooth network) inside the oracle's own fp32-vs-fp64 envelope
     (tests/test_model_gpu.py::test_hg8_every_gradient_vs_oracle_on_the_smooth_network) with the production forms forced."""
