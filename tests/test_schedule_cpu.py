@@ -257,5 +257,11 @@ def test_persistent_stage_runs_of_the_recorded_lists(tape):
             # nothing to fuse if runs had to be longer than any run is / launches narrower than any of these are
             assert lib.dsnt_list_fuse_plan(h, 64, 512, None) == 0 and lib.dsnt_list_fuse_plan(h, 3, 1, None) == 0
             assert lib.dsnt_list_size(h) == size        # planning changes nothing
+            # argument checks of the fusing call come before anything touches the device: more than 256 stage workgroups cannot be
+            # co-resident (the barrier would wait for ever — bounded, but wrong); the workspace is the caller's and must be big enough
+            assert lib.dsnt_list_fuse(h, None, 0, 3, 512, 300) != 0 and b'grid_cap' in lib.dsnt_last_error()
+            assert lib.dsnt_list_fuse(h, None, 0, 3, 512, 64) != 0 and b'workspace' in lib.dsnt_last_error()
+            assert lib.dsnt_list_fuse(h, C.c_void_p(64), 64, 3, 512, 64) != 0 and b'workspace' in lib.dsnt_last_error()
+            assert lib.dsnt_list_size(h) == size and lib.dsnt_list_stages(h, None) == 0
         finally:
             lib.dsnt_list_destroy(h)
