@@ -649,6 +649,10 @@ def main():
     rehearsal = world > 1 and os.environ.get('DSNT_BENCH_REHEARSAL', '0') == '1'
     if rehearsal:
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit('bench.py --gpus %d: rank %d needs cuda:%d but this node has %d device(s) (one process per GPU; '
+                         'DSNT_BENCH_REHEARSAL=1 rehearses the control flow on one device over gloo)'
+                         % (args.gpus, rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
