@@ -2738,6 +2738,14 @@ static int conv_wgrad_impl(const float* x, const float* in_scale, const float* i
 // 128 workgroups against a ~5 us launch boundary in the traced step.  The spin is BOUNDED: a workgroup that gives up raises the
 // stage's error word and every workgroup leaves the kernel — a wrong result the host can see, never a hung device.
 __device__ __forceinline__ bool stage_barrier(unsigned* sync, const unsigned want, int* s_abort) {
+    // EVERY wave releases at agent scope before the workgroup barrier: __syncthreads() only fences LDS (s_waitcnt lgkmcnt), so
+    // without this a wave can sit in the barrier with global stores still in flight, lane 0 of the workgroup then announces the
+    // launch as done, and a workgroup on another XCD reads the old bytes — seen as a 3 % error in one layer's gradients of the
+    // first hg8 step (tests/test_fallback_gpu.py under DSNT_STAGE=1; a kernel boundary waits for every store, a barrier must too)
+    // (workgroup scope is enough per wave — s_waitcnt vmcnt(0): its stores are in the XCD's L2 —; ONE agent-scope release, lane 0's
+    // below, then writes that L2 back.  Every wave releasing at agent scope is correct too and costs the step 2.5 ms more.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), whatever the fence above was lowered to
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -2753,8 +2761,8 @@ __device__ __forceinline__ bool stage_barrier(unsigned* sync, const unsigned wan
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (one invalidate of this CU's vector cache and the XCD's non-local L2 lines: the waves
+    }                                                       //  of the workgroup are parked at the barrier below and share that cache)
     __syncthreads();
     __builtin_amdgcn_s_dcache_inv();          // (scalar loads of the next launch's operands must not hit lines read before the barrier)
     return *s_abort == 0;

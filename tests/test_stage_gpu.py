@@ -86,3 +86,21 @@ def test_stage_full_size_steps_are_identical_and_reproducible(monkeypatch):
     monkeypatch.delenv('DSNT_STAGE')
     c, _ = _step('hg2', 32, 256, 3)
     _assert_identical(a, c)
+
+
+def test_stage_first_step_of_a_cold_process_hg8(tmp_path, monkeypatch):
+    """The case that exposed the one real bug of the stage: the FIRST step of hg8 at batch 16 in a fresh process.  `__syncthreads()`
+    fences LDS only, so a wave could wait in the stage's barrier with global stores still in flight while lane 0 announced the launch
+    as done — a workgroup on another XCD then read stale bytes (3 % error in ONE layer's gradients, found by running the whole suite
+    under DSNT_STAGE=1).  Every wave now releases at agent scope in front of the barrier (csrc/conv.hip `stage_barrier`); this run
+    compares every gradient of that first step, stage on against off, bit for bit, each in a child process of its own."""
+    import test_fallback_gpu as tf
+    monkeypatch.setenv('DSNT_STAGE', '1')
+    on = tf._run(tmp_path, 'stage_on', None, 'hg8', 16, 256)
+    monkeypatch.delenv('DSNT_STAGE')
+    off = tf._run(tmp_path, 'stage_off', None, 'hg8', 16, 256)
+    assert on['loss'] == off['loss'] and torch.equal(on['coords'], off['coords'])
+    bad = [n for n, v in off['grads'].items() if not torch.equal(on['grads'][n], v)]
+    assert not bad, (len(bad), bad[:5])
+    for n, v in off['running'].items():
+        assert torch.equal(on['running'][n], v), n
