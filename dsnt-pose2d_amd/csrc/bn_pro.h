@@ -84,7 +84,7 @@ __device__ __forceinline__ void bn_pro_sums(const float* __restrict__ partial, i
 }
 
 // sh: NT doubles of LDS nobody else is using; ends WITHOUT a barrier — the caller puts one before the first read of
-// scale / shift (its own workgroup's stores: visible after __syncthreads())
+// scale / shift (its own workgroup's stores: waited for at the end of this function, visible after the caller's __syncthreads())
 template <int NT>
 __device__ __forceinline__ void bn_pro_forward(const BnProP& q, double* sh, bool writer) {
     // (the affine parameters and the running statistics are fetched BEFORE the sums: behind them a load is a microsecond of every
@@ -112,6 +112,9 @@ __device__ __forceinline__ void bn_pro_forward(const BnProP& q, double* sh, bool
         q.mean[c] = mu; q.invstd[c] = is; q.scale[c] = sc;
         q.shift[c] = (q.beta ? pb : 0.f) - mu * sc;
     }
+    // the caller's __syncthreads() fences LDS only: this thread's global stores are waited for HERE, so that the other waves of
+    // the workgroup read the new vectors behind the barrier by construction, not by the in-order habit of the L1 path (round 6)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
 template <int NT>
 __device__ __forceinline__ void bn_pro_backward(const BnBwdProP& q, double* sh, bool writer) {
@@ -129,6 +132,7 @@ __device__ __forceinline__ void bn_pro_backward(const BnBwdProP& q, double* sh, 
         q.coef[c] = (float)(a0 * q.invM);
         q.coef[q.C + c] = (float)(a1 * q.invM);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (as in bn_pro_forward)
 }
 
 // host side: validate and copy a dsnt_out_bounds into its device-side image (null = nothing asked for)
