@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libdsnt_hip.so')
-SOURCES = ['api.cpp', 'conv.hip', 'wgrad3.hip', 'wgrad1.hip', 'gemm1.hip', 'bwd1.hip', 'fwd1.hip', 'stem4.hip', 'conv3s.hip', 'skinny.hip', 'dgrad_up.hip', 'elementwise.hip', 'head.hip', 'heatmap.hip', 'debug.hip']
+SOURCES = ['api.cpp', 'conv.hip', 'wgrad3.hip', 'wgrad1.hip', 'gemm1.hip', 'bwd1.hip', 'fwd1.hip', 'stem4.hip', 'conv3s.hip', 'dgrad_up.hip', 'elementwise.hip', 'head.hip', 'heatmap.hip', 'debug.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value',
          '-Wno-unused-result']
 if os.environ.get('DSNT_TIMELINE'):      # wave timeline stamps in the conv kernels (diagnostic scripts of rounds 1-3, removed in round 6: git history)
@@ -32,7 +32,7 @@ def _newer(a, b):
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     deps = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'bn_pro.h'), os.path.join(CSRC, 'conv_split.h'),
-            os.path.join(CSRC, 'wgrad3.h'), os.path.join(CSRC, 'gemm1.h'), os.path.join(CSRC, 'conv3s.h'), os.path.join(CSRC, 'bwd1.h'), os.path.join(CSRC, 'fwd1.h'), os.path.join(CSRC, 'stem4.h'), os.path.join(CSRC, 'stage.h'), os.path.join(CSRC, 'skinny.h'), os.path.join(CSRC, 'ew_bodies.h'),
+            os.path.join(CSRC, 'wgrad3.h'), os.path.join(CSRC, 'gemm1.h'), os.path.join(CSRC, 'conv3s.h'), os.path.join(CSRC, 'bwd1.h'), os.path.join(CSRC, 'fwd1.h'), os.path.join(CSRC, 'stem4.h'), os.path.join(CSRC, 'stage.h'), os.path.join(CSRC, 'ew_bodies.h'),
             os.path.join(HERE, '..', 'include', 'dsnt_hip.h'), os.path.join(HERE, '..', 'include', 'dsnt_hip_debug.h')]
     objs, jobs = [], []
     bdir = 'build' if not os.environ.get('DSNT_LIB_NAME') else 'build_' + os.path.splitext(os.environ['DSNT_LIB_NAME'])[0]

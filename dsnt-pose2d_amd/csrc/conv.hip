@@ -23,7 +23,6 @@
 #include "gemm1.h"
 #include "conv3s.h"
 #include "stage.h"
-#include "skinny.h"
 #include "stem4.h"
 #include <string.h>
 #include <stdlib.h>
@@ -1538,9 +1537,6 @@ static int conv_fwd6_impl(const float* x, const void* w_planes, int64_t plane_st
     if (g_ap) {
         p.ap_y = g_ap->y; p.ap_scale = g_ap->scale; p.ap_mean = g_ap->mean; p.ap_invstd = g_ap->invstd; p.ap_coef = g_ap->coef;
         p.ap_out = ap_out;
-    }
-    if (!stream_w && dsnt_skinny_launch(p, a_bound != nullptr, st)) {     // 16 channels on one side: a streaming pass (skinny.hip)
-        DSNT_CHECK_LAUNCH("dsnt_conv_fwd (skinny)");
     }
     if (stream_w) {                  // 3x3, weights in the stream layout: the symmetric kernel (conv3s.hip)
         DSNT_REQUIRE(dsnt_conv3s_ok(p), DSNT_ERR_SHAPE, "dsnt_conv_fwd_f16x3_stream: launch not supported (dsnt_conv_fwd_stream_ok; "
